@@ -1,0 +1,32 @@
+"""The SA backbone of the single-stage detector: the loop of
+lib/modeling/single_stage_detector.py:115-125 (network_forward) over the ARCHITECTURE rows, without
+the detection head (out of scope)."""
+import torch
+
+from .builder.layer_builder import LayerBuilder
+from .utils import layers_util
+from .utils.weights import VariableStore
+
+
+class SABackbone:
+    def __init__(self, arch, params, device="cuda:0", max_translate_range=(-3.0, -2.0, -3.0),
+                 aggregation_sa_feature=True):
+        self.device = torch.device(device)
+        self.variables = VariableStore(params, self.device)
+        layers_util.AGGREGATION_SA_FEATURE = bool(aggregation_sa_feature)
+        layers_util.MAX_TRANSLATE_RANGE = tuple(max_translate_range)
+        self.layers = [LayerBuilder(i, False, arch, variables=self.variables) for i in range(len(arch))]
+
+    def forward(self, point_cloud):
+        """point_cloud [B,n,3+C] fp32 on the GPU -> (xyz_list, feature_list, fps_idx_list); the backbone
+        output is the last entry of xyz_list / feature_list."""
+        l0_xyz = point_cloud[:, :, 0:3].contiguous()
+        l0_points = point_cloud[:, :, 3:].contiguous()
+        xyz_list, feature_list, fps_idx_list = [l0_xyz], [l0_points], [None]
+        out = {}
+        for layer in self.layers:
+            xyz_list, feature_list, fps_idx_list = layer.build_layer(xyz_list, feature_list, fps_idx_list,
+                                                                     None, out)
+        return xyz_list, feature_list, fps_idx_list
+
+    __call__ = forward

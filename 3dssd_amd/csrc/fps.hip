@@ -1,0 +1,269 @@
+// Farthest-point sampling for gfx950: D-FPS on coordinates, generic c-channel FPS, and FPS on
+// a precomputed distance matrix (F-FPS).  One 1024-thread workgroup (16 wave64) per frame, like
+// the reference launch (lib/utils/tf_ops/sampling/tf_sampling_g.cu:392-398), but:
+//   * the frame's coordinates and the running min-distance live in VGPRs for the whole kernel
+//     (16 points x 4 floats per thread at n = 16384) -- the reference re-reads both from global
+//     memory in every one of the m-1 dependent iterations;
+//   * the per-iteration arg-max is a 6-step wave64 all-reduce (DPP + permlane swaps) plus one
+//     16-entry cross-wave stage in LDS with ONE __syncthreads, instead of a 10-level
+//     shared-memory tree with a barrier per level (tf_sampling_g.cu:161-171).
+// Semantics follow tf_sampling_g.cu:123-230 exactly, including the (k mod 1024, k) tie-break:
+// thread t owns k = t, t+1024, ... and keeps its first strict maximum; among equal wave maxima
+// the lowest lane wins, among equal workgroup maxima the lowest wave wins.
+// Distance arithmetic: d = fmaf(diff, diff, d) over channels ascending (nvcc -fmad=true form of
+// tf_sampling_g.cu:146-150); built with -ffp-contract=off so only the explicit fmaf fuses.
+#include "sa_common.h"
+
+namespace {
+
+constexpr int kBlock = 1024;
+constexpr int kWaves = kBlock / 64;
+constexpr float kInit = 1e38f;      // tf_sampling_g.cu:136
+constexpr float kAbsent = -3.0e38f; // slot of a thread that owns no point: never beats best = -1
+
+// Cross-wave stage shared by all three kernels.  Wave w has published (value, payload) in slot w of
+// buffer `par`; returns the payload of the winning wave to every thread.
+__device__ __forceinline__ float4 cross_wave_pick(const float (*s_val)[kWaves],
+                                                  const float4 (*s_pt)[kWaves], int par, int lane) {
+    float v = s_val[par][lane & (kWaves - 1)];
+    float M = sa::row16_allmax(v);
+    unsigned long long eq = __ballot(v == M);
+    int ws = __builtin_ctzll(eq) & (kWaves - 1);   // lowest wave holding the maximum
+    return s_pt[par][ws];
+}
+
+// ---- D-FPS, c == 3, n <= 1024*PPT, everything register resident ------------------------------
+template <int PPT>
+__global__ __launch_bounds__(kBlock) void fps3_reg_kernel(int n, int m, const float *__restrict__ inp,
+                                                          int *__restrict__ out, int out_stride,
+                                                          int idx_off) {
+    __shared__ float s_val[2][kWaves];
+    __shared__ float4 s_pt[2][kWaves];
+    const int b = blockIdx.x;
+    const float *p = inp + (size_t)b * n * 3;
+    int *o = out + (size_t)b * out_stride;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+
+    // ext_vector_type keeps each array in consecutive VGPRs, so the winner's coordinates can be
+    // fetched with one indexed register read (s_set_gpr_idx) instead of a PPT-long select chain.
+    typedef float vecf __attribute__((ext_vector_type(PPT)));
+    vecf px, py, pz, td;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        int k = t + kBlock * j;
+        bool ok = k < n;
+        int kk = ok ? k : 0;
+        px[j] = p[kk * 3 + 0];
+        py[j] = p[kk * 3 + 1];
+        pz[j] = p[kk * 3 + 2];
+        td[j] = ok ? kInit : kAbsent;
+    }
+    float ox = p[0], oy = p[1], oz = p[2];          // old = 0, tf_sampling_g.cu:130-133
+    if (t == 0) o[0] = idx_off;
+
+    for (int it = 1; it < m; ++it) {
+        float best = -1.0f;                         // :141
+        int bj = 0;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            float dx = px[j] - ox, dy = py[j] - oy, dz = pz[j] - oz;
+            float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            float t2 = sa::fmin_nn(d, td[j]);       // :151-153
+            td[j] = t2;
+            bool g = t2 > best;                     // strict: first maximum wins, :154
+            best = g ? t2 : best;
+            bj = g ? j : bj;
+        }
+        const float wmax = sa::wave_allmax(best);
+        const unsigned long long cand = __ballot(best == wmax);
+        const int first = __builtin_ctzll(cand);
+        const int par = it & 1;
+        if (lane == first) {
+            const int ju = __builtin_amdgcn_readfirstlane(bj);   // one active lane: its own bj
+            s_val[par][w] = wmax;
+            s_pt[par][w] = make_float4(px[ju], py[ju], pz[ju], __int_as_float(t + kBlock * ju));
+        }
+        __syncthreads();
+        const float4 wp = cross_wave_pick(s_val, s_pt, par, lane);
+        ox = wp.x; oy = wp.y; oz = wp.z;
+        if (t == 0) o[it] = __float_as_int(wp.w) + idx_off;
+    }
+}
+
+// ---- FPS on a precomputed [n,n] distance matrix (F-FPS), n <= 1024*PPT ------------------------
+template <int PPT>
+__global__ __launch_bounds__(kBlock) void fpsdist_reg_kernel(int n, int m,
+                                                             const float *__restrict__ dist,
+                                                             int *__restrict__ out, int out_stride,
+                                                             int idx_off) {
+    __shared__ float s_val[2][kWaves];
+    __shared__ float4 s_pt[2][kWaves];
+    const int b = blockIdx.x;
+    const float *D = dist + (size_t)b * n * n;
+    int *o = out + (size_t)b * out_stride;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+
+    float td[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) td[j] = (t + kBlock * j) < n ? kInit : kAbsent;
+    int old = 0;
+    if (t == 0) o[0] = idx_off;
+
+    for (int it = 1; it < m; ++it) {
+        const float *row = D + (size_t)old * n;     // tf_sampling_g.cu:202
+        float dv[PPT];
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            int k = t + kBlock * j;
+            dv[j] = k < n ? row[k] : 0.0f;
+        }
+        float best = -1.0f;
+        int bk = 0;                                 // besti starts at 0, :190-191
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            float t2 = sa::fmin_nn(dv[j], td[j]);
+            td[j] = t2;
+            bool g = t2 > best;
+            best = g ? t2 : best;
+            bk = g ? (t + kBlock * j) : bk;
+        }
+        const float wmax = sa::wave_allmax(best);
+        const unsigned long long cand = __ballot(best == wmax);
+        const int first = __builtin_ctzll(cand);
+        const int par = it & 1;
+        if (lane == first) {
+            s_val[par][w] = wmax;
+            s_pt[par][w] = make_float4(0.f, 0.f, 0.f, __int_as_float(bk));
+        }
+        __syncthreads();
+        const float4 wp = cross_wave_pick(s_val, s_pt, par, lane);
+        old = __builtin_amdgcn_readfirstlane(__float_as_int(wp.w));
+        if (t == 0) o[it] = old + idx_off;
+    }
+}
+
+// ---- generic fallback: any c, any n; running min-distance in global `temp` like the reference --
+// MODE 0: c-channel points inp[b,n,c].  MODE 1: distance matrix inp[b,n,n].
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void fps_generic_kernel(int n, int c, int m,
+                                                             const float *__restrict__ inp,
+                                                             float *__restrict__ temp,
+                                                             int *__restrict__ out, int out_stride,
+                                                             int idx_off) {
+    __shared__ float s_val[2][kWaves];
+    __shared__ float4 s_pt[2][kWaves];
+    const int b = blockIdx.x;
+    const float *p = inp + (size_t)b * n * (MODE == 0 ? (size_t)c : (size_t)n);
+    float *td = temp + (size_t)b * n;
+    int *o = out + (size_t)b * out_stride;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+
+    for (int k = t; k < n; k += kBlock) td[k] = kInit;
+    int old = 0;
+    if (t == 0) o[0] = idx_off;
+
+    for (int it = 1; it < m; ++it) {
+        float best = -1.0f;
+        int bk = 0;
+        const float *po = p + (size_t)old * (MODE == 0 ? c : n);
+        for (int k = t; k < n; k += kBlock) {
+            float d;
+            if (MODE == 0) {
+                const float *pk = p + (size_t)k * c;
+                d = 0.0f;
+                for (int l = 0; l < c; ++l) {
+                    float diff = pk[l] - po[l];
+                    d = __builtin_fmaf(diff, diff, d);
+                }
+            } else {
+                d = po[k];
+            }
+            float t2 = sa::fmin_nn(d, td[k]);
+            td[k] = t2;
+            if (t2 > best) { best = t2; bk = k; }
+        }
+        const float wmax = sa::wave_allmax(best);
+        const unsigned long long cand = __ballot(best == wmax);
+        const int first = __builtin_ctzll(cand);
+        const int par = it & 1;
+        if (lane == first) {
+            s_val[par][w] = wmax;
+            s_pt[par][w] = make_float4(0.f, 0.f, 0.f, __int_as_float(bk));
+        }
+        __syncthreads();
+        const float4 wp = cross_wave_pick(s_val, s_pt, par, lane);
+        old = __builtin_amdgcn_readfirstlane(__float_as_int(wp.w));
+        if (t == 0) o[it] = old + idx_off;
+    }
+}
+
+int ppt_for(int n) {
+    int ppt = (n + kBlock - 1) / kBlock;
+    int r = 1;
+    while (r < ppt) r <<= 1;
+    return r;
+}
+
+}  // namespace
+
+// Internal launchers with an output row stride / index offset so that an SA layer can write the
+// F-FPS and D-FPS halves straight into one [b, npoint_total] index tensor (layers_util.py:96-108).
+extern "C" int sa_fps_ex(int b, int n, int c, int m, const float *inp, float *temp, int *out,
+                         int out_stride, int idx_off, hipStream_t stream) {
+    if (b <= 0 || n <= 0 || c <= 0 || m <= 0 || !inp || !out || out_stride < m) return SA_ERR_INVALID;
+    const int ppt = ppt_for(n);
+    if (c == 3 && ppt <= 16) {
+        switch (ppt) {
+#define SA_FPS3(P) case P: hipLaunchKernelGGL(fps3_reg_kernel<P>, dim3(b), dim3(kBlock), 0, stream, n, m, inp, out, out_stride, idx_off); break;
+            SA_FPS3(1) SA_FPS3(2) SA_FPS3(4) SA_FPS3(8) SA_FPS3(16)
+#undef SA_FPS3
+        }
+    } else {
+        if (!temp) return SA_ERR_INVALID;
+        hipLaunchKernelGGL(fps_generic_kernel<0>, dim3(b), dim3(kBlock), 0, stream, n, c, m, inp, temp,
+                           out, out_stride, idx_off);
+    }
+    SA_CHECK_LAUNCH();
+    return SA_OK;
+}
+
+extern "C" int sa_fps_with_distance_ex(int b, int n, int m, const float *dist, float *temp, int *out,
+                                       int out_stride, int idx_off, hipStream_t stream) {
+    if (b <= 0 || n <= 0 || m <= 0 || !dist || !out || out_stride < m) return SA_ERR_INVALID;
+    const int ppt = ppt_for(n);
+    if (ppt <= 16) {
+        switch (ppt) {
+#define SA_FPSD(P) case P: hipLaunchKernelGGL(fpsdist_reg_kernel<P>, dim3(b), dim3(kBlock), 0, stream, n, m, dist, out, out_stride, idx_off); break;
+            SA_FPSD(1) SA_FPSD(2) SA_FPSD(4) SA_FPSD(8) SA_FPSD(16)
+#undef SA_FPSD
+        }
+    } else {
+        if (!temp) return SA_ERR_INVALID;
+        hipLaunchKernelGGL(fps_generic_kernel<1>, dim3(b), dim3(kBlock), 0, stream, n, 0, m, dist, temp,
+                           out, out_stride, idx_off);
+    }
+    SA_CHECK_LAUNCH();
+    return SA_OK;
+}
+
+// Force the generic (global-temp) kernels: used by tests to cover the n > 16384 path at small n.
+extern "C" int sa_fps_generic(int b, int n, int c, int m, const float *inp, float *temp, int *out,
+                              int mode, hipStream_t stream) {
+    if (b <= 0 || n <= 0 || m <= 0 || !inp || !temp || !out) return SA_ERR_INVALID;
+    if (mode == 0)
+        hipLaunchKernelGGL(fps_generic_kernel<0>, dim3(b), dim3(kBlock), 0, stream, n, c, m, inp, temp, out, m, 0);
+    else
+        hipLaunchKernelGGL(fps_generic_kernel<1>, dim3(b), dim3(kBlock), 0, stream, n, 0, m, inp, temp, out, m, 0);
+    SA_CHECK_LAUNCH();
+    return SA_OK;
+}
+
+// Reference launcher signatures (lib/utils/tf_ops/sampling/tf_sampling.cpp:131,164) + stream.
+extern "C" int sa_farthest_point_sample(int b, int n, int c, int m, const float *inp, float *temp,
+                                        int *out, hipStream_t stream) {
+    return sa_fps_ex(b, n, c, m, inp, temp, out, m, 0, stream);
+}
+extern "C" int sa_farthest_point_sample_with_distance(int b, int n, int m, const float *dist,
+                                                      float *temp, int *out, hipStream_t stream) {
+    return sa_fps_with_distance_ex(b, n, m, dist, temp, out, m, 0, stream);
+}

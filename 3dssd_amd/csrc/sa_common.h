@@ -1,0 +1,92 @@
+// Shared device/host helpers for the gfx950 set-abstraction kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SA_OK 0
+#define SA_ERR_INVALID (-1)   // bad shape / attribute (the reference's OP_REQUIRES checks)
+#define SA_ERR_LAUNCH (-2)    // hipGetLastError() after a launch
+#define SA_ERR_UNSUPPORTED (-3)
+
+#define SA_CHECK_LAUNCH()                                  \
+    do {                                                   \
+        hipError_t e__ = hipGetLastError();                \
+        if (e__ != hipSuccess) return SA_ERR_LAUNCH;       \
+    } while (0)
+
+namespace sa {
+
+// ---- DPP cross-lane moves (wave64, gfx9 encodings) ---------------------------------------
+// quad_perm(1,0,3,2)=0xB1  quad_perm(2,3,0,1)=0x4E  row_half_mirror=0x141  row_mirror=0x140
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_mov(unsigned x) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, true);
+}
+
+// The library is built with -fno-honor-nans, so these lower to single v_max_f32 / v_min_f32
+// without the IEEE canonicalisation fmaxf() otherwise drags in; inputs are never NaN on this path.
+__device__ __forceinline__ float fmax_nn(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ float fmin_nn(float a, float b) { return __builtin_fminf(a, b); }
+
+// all-reduce max inside each 16-lane row
+__device__ __forceinline__ float row16_allmax(float x) {
+    x = fmax_nn(x, dpp_mov<0xB1>(x));
+    x = fmax_nn(x, dpp_mov<0x4E>(x));
+    x = fmax_nn(x, dpp_mov<0x141>(x));
+    x = fmax_nn(x, dpp_mov<0x140>(x));
+    return x;
+}
+__device__ __forceinline__ unsigned row16_allmin_u32(unsigned x) {
+    unsigned y;
+    y = dpp_mov<0xB1>(x);  x = y < x ? y : x;
+    y = dpp_mov<0x4E>(x);  x = y < x ? y : x;
+    y = dpp_mov<0x141>(x); x = y < x ? y : x;
+    y = dpp_mov<0x140>(x); x = y < x ? y : x;
+    return x;
+}
+
+// all-reduce max over the 64 lanes of a wave: 4 DPP steps + the gfx950 row/half swaps.
+__device__ __forceinline__ float wave_allmax(float x) {
+    x = row16_allmax(x);
+    {
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+        x = fmax_nn(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    {
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+        x = fmax_nn(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    return x;
+}
+__device__ __forceinline__ unsigned wave_allmin_u32(unsigned x) {
+    x = row16_allmin_u32(x);
+    {
+        auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+        x = r[0] < r[1] ? r[0] : r[1];
+    }
+    {
+        auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+        x = r[0] < r[1] ? r[0] : r[1];
+    }
+    return x;
+}
+
+// ---- bf16 split helpers --------------------------------------------------------------------
+// round-to-nearest-even fp32 -> bf16 bit pattern (inputs finite)
+__device__ __forceinline__ unsigned bf16_rne_bits(float x) {
+    unsigned u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+// x ~= hi + lo with hi, lo bf16: hi = rne(x), lo = rne(x - hi)
+__device__ __forceinline__ void bf16_split(float x, unsigned &hi, unsigned &lo) {
+    hi = bf16_rne_bits(x);
+    float r = x - __uint_as_float(hi << 16);
+    lo = bf16_rne_bits(r);
+}
+
+}  // namespace sa

@@ -1,0 +1,106 @@
+"""Seeded synthetic inputs and weights for the SA backbone.
+
+There is no dataset and no checkpoint in this environment, so the benchmark and the parity tests
+use KITTI-shape synthetic frames and random-init weights.  The generator is fixed here (seeds are
+part of the contract) so that the CPU oracle and the HIP path see identical tensors.
+"""
+import numpy as np
+
+FRAME_SEED = 20260925
+WEIGHT_SEED = 1234
+
+
+def kitti_like_frame(frame_id, n=16384, dup_fraction=0.0):
+    """One [n,4] fp32 frame: LiDAR-like polar density inside POINT_CLOUD_RANGE
+    (configs/kitti/3dssd/3dssd.yaml:3), channel 3 = intensity in [0,1].
+
+    dup_fraction > 0 overwrites that fraction of the tail rows with copies of earlier rows, which
+    mirrors the with-replacement padding of lib/dataset/dataloader/kitti_dataloader.py:142-147 and
+    exercises the FPS tie-break.
+    """
+    rng = np.random.default_rng(FRAME_SEED + int(frame_id))
+    m = int(1.25 * n) + 64
+    r = rng.uniform(2.0, 70.0, m).astype(np.float32)
+    th = rng.uniform(-np.pi / 4, np.pi / 4, m).astype(np.float32)
+    x = (r * np.sin(th)).astype(np.float32)
+    z = (r * np.cos(th)).astype(np.float32)
+    y = np.clip(1.6 - np.abs(rng.normal(0.0, 0.5, m)), -5.0, 3.0).astype(np.float32)
+    inten = rng.uniform(0.0, 1.0, m).astype(np.float32)
+    keep = np.abs(x) <= 40.0
+    pts = np.stack([x, y, z, inten], 1)[keep][:n]
+    assert pts.shape[0] == n, "synthetic frame generator ran short"
+    if dup_fraction > 0:
+        k = int(n * dup_fraction)
+        src = rng.integers(0, n - k, k)
+        pts[n - k:] = pts[src]
+    return np.ascontiguousarray(pts, np.float32)
+
+
+def kitti_like_batch(batch, n=16384, first_frame=0, dup_fraction=0.0):
+    return np.stack([kitti_like_frame(first_frame + i, n, dup_fraction) for i in range(batch)])
+
+
+def _xavier(rng, cin, cout):
+    lim = np.sqrt(6.0 / (cin + cout))  # tf.contrib.layers.xavier_initializer, tf_util.py:41
+    return rng.uniform(-lim, lim, (cin, cout)).astype(np.float32)
+
+
+def _bn(rng, c, p, scope):
+    p[scope + "/bn/gamma"] = rng.uniform(0.5, 1.5, c).astype(np.float32)
+    p[scope + "/bn/beta"] = rng.normal(0.0, 0.1, c).astype(np.float32)
+    p[scope + "/bn/moving_mean"] = rng.normal(0.0, 0.1, c).astype(np.float32)
+    p[scope + "/bn/moving_variance"] = rng.uniform(0.5, 1.5, c).astype(np.float32)
+
+
+def random_backbone_params(arch, in_feature_channels=1, seed=WEIGHT_SEED, aggregation=True):
+    """Random-init parameters for the SA_Layer / Vote_Layer rows of `arch`, keyed by the
+    reference's TF variable names (lib/utils/layers_util.py:17-19,175,185;
+    lib/utils/tf_util.py:96,111,439-442): <scope>/conv<i>_<j>/{weights,biases,bn/*},
+    <scope>/ensemble/..., <scope>/vote_layer_<i>/..., <scope>/vote_offsets/...
+    conv2d kernels are [1,1,cin,cout], conv1d kernels [1,cin,cout]; biases start at zero."""
+    rng = np.random.default_rng(seed)
+    p = {}
+    feat_ch = [in_feature_channels]
+    for row in arch:
+        feature_index, radius_list, mlp_list, bn = row[1], row[2], row[4], row[5]
+        layer_type, scope, agg = row[11], row[12], row[15]
+        cin_feat = feat_ch[feature_index[0]]
+        if layer_type == "SA_Layer":
+            if radius_list:
+                outs = 0
+                for i, mlp in enumerate(mlp_list):
+                    cin = cin_feat + 3
+                    for j, cout in enumerate(mlp):
+                        s = "%s/conv%d_%d" % (scope, i, j)
+                        p[s + "/weights"] = _xavier(rng, cin, cout).reshape(1, 1, cin, cout)
+                        p[s + "/biases"] = np.zeros(cout, np.float32)
+                        if bn:
+                            _bn(rng, cout, p, s)
+                        cin = cout
+                    outs += cin
+                if aggregation:
+                    s = scope + "/ensemble"
+                    p[s + "/weights"] = _xavier(rng, outs, agg).reshape(1, outs, agg)
+                    p[s + "/biases"] = np.zeros(agg, np.float32)
+                    if bn:
+                        _bn(rng, agg, p, s)
+                    outs = agg
+                feat_ch.append(outs)
+            else:
+                feat_ch.append(cin_feat)
+        elif layer_type == "Vote_Layer":
+            cin = cin_feat
+            for i, cout in enumerate(mlp_list):
+                s = "%s/vote_layer_%d" % (scope, i)
+                p[s + "/weights"] = _xavier(rng, cin, cout).reshape(1, cin, cout)
+                p[s + "/biases"] = np.zeros(cout, np.float32)
+                if bn:
+                    _bn(rng, cout, p, s)
+                cin = cout
+            s = scope + "/vote_offsets"
+            p[s + "/weights"] = _xavier(rng, cin, 3).reshape(1, cin, 3)
+            p[s + "/biases"] = np.zeros(3, np.float32)
+            feat_ch.append(cin)
+        else:
+            raise NotImplementedError(layer_type)
+    return p

@@ -1,0 +1,68 @@
+"""ctypes binding of lib3dssd_sa.so (the C ABI declared in include/sa_ops.h).
+
+The HIP library is the product: there is no CPU or PyTorch fallback.  If the shared object is
+missing or a symbol cannot be resolved, importing/calling fails loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "lib3dssd_sa.so")
+
+_c_int, _c_long, _c_float, _vp = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p
+
+# name -> argtypes; every function returns int status.  Pointers are passed as raw addresses.
+SIGNATURES = {
+    "sa_farthest_point_sample": [_c_int] * 4 + [_vp, _vp, _vp, _vp],
+    "sa_farthest_point_sample_with_distance": [_c_int] * 3 + [_vp, _vp, _vp, _vp],
+    "sa_gather_point": [_c_int] * 4 + [_vp, _vp, _vp, _vp],
+    "sa_query_ball_point": [_c_int] * 3 + [_c_float, _c_int, _vp, _vp, _vp, _vp, _vp],
+    "sa_query_ball_point_dilated": [_c_int] * 3 + [_c_float, _c_float, _c_int, _vp, _vp, _vp, _vp, _vp],
+    "sa_group_point": [_c_int] * 5 + [_vp, _vp, _vp, _vp],
+    "sa_calc_square_dist": [_c_int] * 4 + [_vp, _vp, _vp, _vp],
+    "sa_fps_ex": [_c_int] * 4 + [_vp, _vp, _vp, _c_int, _c_int, _vp],
+    "sa_fps_with_distance_ex": [_c_int] * 3 + [_vp, _vp, _vp, _c_int, _c_int, _vp],
+    "sa_fps_generic": [_c_int] * 4 + [_vp, _vp, _vp, _c_int, _vp],
+    "sa_calc_square_dist_split": [_c_int] * 5 + [_vp, _vp, _vp, _vp, _vp, _vp],
+    "sa_query_ball_point_multi": [_c_int] * 4 + [_vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _vp],
+    "sa_group_mlp_max": [_c_int] * 5 + [_vp] * 5 + [_c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp],
+    "sa_dense": [_c_long, _c_int, _c_int, _vp, _vp, _vp, _c_int, _vp, _vp],
+    "sa_vote_translate": [_c_long, _vp, _vp, _c_float, _c_float, _c_float, _vp, _vp],
+}
+
+_ERRORS = {-1: "invalid argument", -2: "kernel launch failed (hipGetLastError)", -3: "unsupported size"}
+_LIB = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load lib3dssd_sa.so once; raise if it (or any declared symbol) is missing."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryError(
+                "HIP extension not built: %s is missing. Run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        h = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(h, name)  # AttributeError if the symbol is not exported
+            fn.argtypes = argtypes
+            fn.restype = _c_int
+        _LIB = h
+    return _LIB
+
+
+def check(status, what):
+    if status != 0:
+        msg = "%s: %s (status %d)" % (what, _ERRORS.get(status, "error"), status)
+        if status == -1:
+            raise ValueError(msg)
+        raise RuntimeError(msg)
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,182 @@
+"""SA-layer functions with the reference's signatures (lib/utils/layers_util.py): vote_layer (:12-24)
+and pointnet_sa_module_msg (:59-189), inference mode, on torch-ROCm tensors.
+
+The control flow (range slicing, FS = [F-FPS idx | D-FPS idx], index offsets, scale loop, aggregation)
+follows the reference line by line; what differs is what runs underneath:
+  * the radius bands of a layer go through ONE fused ball-query pass (csrc/ballquery.hip);
+  * group_point x2 + concat + conv2d x3 + reduce_max + mask is ONE fused MFMA kernel per scale
+    (csrc/mlp.hip) that writes straight into the concatenated [B,m,sum C] tensor;
+  * the F-FPS matrix is built from (xyz, features) without materialising their concat.
+Weights come from a VariableStore (utils/weights.py), the stand-in for TF variable scopes.
+Arguments that only matter for training (is_training, bn_decay) are accepted and ignored; BatchNorm is
+always the inference form.  use_attention (query_ball_point_withidx) is not on the 3DSSD path and is
+rejected.
+"""
+import ctypes
+
+import torch
+
+from . import _native as N
+from . import weights as W
+from .tf_ops import _tensor as T
+from .tf_ops.sampling.tf_sampling import farthest_point_sample, farthest_point_sample_with_distance, gather_point  # noqa: F401
+from .tf_ops.grouping.tf_grouping import query_ball_point, query_ball_point_dilated, group_point  # noqa: F401
+
+# cfg.MODEL.NETWORK.AGGREGATION_SA_FEATURE and cfg.MODEL.MAX_TRANSLATE_RANGE of the reference's global
+# config (configs/kitti/3dssd/3dssd.yaml:39,44); set by the backbone driver.
+AGGREGATION_SA_FEATURE = True
+MAX_TRANSLATE_RANGE = (-3.0, -2.0, -3.0)
+
+
+def _dense(x, layer, relu):
+    """tf_util.conv1d 1x1 (+ folded BN) (+ ReLU) on [..., K] -> [..., N]."""
+    rows = x.numel() // layer.K
+    y = torch.empty(x.shape[:-1] + (layer.N,), dtype=torch.float32, device=x.device)
+    st = N.lib().sa_dense(rows, layer.K, layer.N, x.data_ptr(), layer.w.data_ptr(), layer.bias.data_ptr(),
+                          1 if relu else 0, y.data_ptr(), N.current_stream())
+    N.check(st, "dense")
+    return y
+
+
+def vote_layer(xyz, points, mlp_list, is_training, bn_decay, bn, scope, variables=None):
+    """layers_util.py:12-24.  Returns (xyz + clipped offsets, features, raw offsets)."""
+    vs = variables or W.default_variables()
+    xyz = T.f32_cuda(xyz, "xyz")
+    points = T.f32_cuda(points, "points")
+    for i, _channel in enumerate(mlp_list):
+        points = _dense(points, vs.layer("%s/vote_layer_%d" % (scope, i), bn), relu=True)
+    ctr_offsets = _dense(points, vs.layer(scope + "/vote_offsets", False), relu=False)
+    out = torch.empty_like(xyz)
+    lo = MAX_TRANSLATE_RANGE
+    st = N.lib().sa_vote_translate(xyz.numel() // 3, xyz.data_ptr(), ctr_offsets.data_ptr(), float(lo[0]),
+                                   float(lo[1]), float(lo[2]), out.data_ptr(), N.current_stream())
+    N.check(st, "vote_translate")
+    return out, points, ctr_offsets
+
+
+def _ffps_into(npoint, tmp_xyz, tmp_points, out, col, idx_off):
+    """F-FPS: calc_square_dist(concat([xyz, feat])) + farthest_point_sample_with_distance
+    (layers_util.py:94-96,102-104), written into out[:, col:col+npoint] with idx_off added."""
+    b, n, _ = tmp_xyz.shape
+    c1 = tmp_points.shape[2]
+    dist = torch.empty((b, n, n), dtype=torch.float32, device=tmp_xyz.device)
+    lib = N.lib()
+    st = lib.sa_calc_square_dist_split(b, n, n, 3, c1, tmp_xyz.data_ptr(), tmp_points.data_ptr(),
+                                       tmp_xyz.data_ptr(), tmp_points.data_ptr(), dist.data_ptr(),
+                                       N.current_stream())
+    N.check(st, "calc_square_dist")
+    temp = torch.empty((b, n), dtype=torch.float32, device=dist.device) if n > 16384 else None
+    st = lib.sa_fps_with_distance_ex(b, n, npoint, dist.data_ptr(),
+                                     temp.data_ptr() if temp is not None else None,
+                                     out.data_ptr() + 4 * col, out.shape[1], idx_off, N.current_stream())
+    N.check(st, "farthest_point_sample_with_distance")
+
+
+def _dfps_into(npoint, tmp_xyz, out, col, idx_off):
+    b, n, c = tmp_xyz.shape
+    temp = torch.empty((b, n), dtype=torch.float32, device=tmp_xyz.device) if (c != 3 or n > 16384) else None
+    st = N.lib().sa_fps_ex(b, n, c, npoint, tmp_xyz.data_ptr(), temp.data_ptr() if temp is not None else None,
+                           out.data_ptr() + 4 * col, out.shape[1], idx_off, N.current_stream())
+    N.check(st, "farthest_point_sample")
+
+
+def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_training, bn_decay, bn,
+                           fps_sample_range_list, fps_method_list, npoint_list, former_fps_idx,
+                           use_attention, scope, dilated_group, vote_ctr=None, aggregation_channel=None,
+                           debugging=False, epsilon=1e-5, variables=None):
+    """layers_util.py:59-189.  xyz (B,n,3), points (B,n,C) -> new_xyz (B,m,3), new_points (B,m,C'),
+    fps_idx (B,m) int32."""
+    T.require(not use_attention, "use_attention (query_ball_point_withidx) is outside the 3DSSD SA path")
+    vs = variables or W.default_variables()
+    xyz = T.f32_cuda(xyz, "xyz")
+    points = T.f32_cuda(points, "points")
+    bs, n_all, _ = xyz.shape
+    dev = xyz.device
+
+    # ---- sampling plan (layers_util.py:84-111): (kind, start, end, npoint) per non-empty range
+    plan, last, total = [], 0, 0
+    for fps_sample_range, fps_method, npoint in zip(fps_sample_range_list, fps_method_list, npoint_list):
+        end = n_all if fps_sample_range == -1 else last + fps_sample_range   # tf.slice size -1
+        if npoint == 0:                                                      # :87-89
+            last += fps_sample_range
+            continue
+        rng_n = end - last
+        if vote_ctr is not None:                                             # :90-92
+            kind, cnt = "identity", vote_ctr.shape[1]
+        elif fps_method == "FS":                                             # :93-98
+            kind, cnt = "FS", 2 * npoint
+        elif npoint == rng_n:                                                # :99-100
+            kind, cnt = "identity", npoint
+        elif fps_method == "F-FPS":                                          # :101-104
+            kind, cnt = "F-FPS", npoint
+        else:                                                                # :105-106
+            kind, cnt = "D-FPS", npoint
+        plan.append((kind, last, end, cnt))
+        total += cnt
+        last += fps_sample_range
+    former_n = former_fps_idx.shape[1] if former_fps_idx is not None else 0
+    fps_idx = torch.empty((bs, total + former_n), dtype=torch.int32, device=dev)
+    col = 0
+    for kind, start, end, cnt in plan:
+        if kind == "identity":
+            fps_idx[:, col:col + cnt] = torch.arange(start, start + cnt, dtype=torch.int32, device=dev)[None]
+        else:
+            whole = (start == 0 and end == n_all)
+            tmp_xyz = xyz if whole else xyz[:, start:end].contiguous()
+            if kind in ("FS", "F-FPS"):
+                tmp_points = points if whole else points[:, start:end].contiguous()
+                npt = cnt // 2 if kind == "FS" else cnt
+                _ffps_into(npt, tmp_xyz, tmp_points, fps_idx, col, start)   # F-FPS indices first
+                if kind == "FS":
+                    _dfps_into(npt, tmp_xyz, fps_idx, col + npt, start)
+            else:
+                _dfps_into(cnt, tmp_xyz, fps_idx, col, start)
+        col += cnt
+    if former_fps_idx is not None:                                          # :112-113
+        fps_idx[:, col:] = T.i32_cuda(former_fps_idx, "former_fps_idx")
+
+    ctr_src = T.f32_cuda(vote_ctr, "vote_ctr") if vote_ctr is not None else xyz
+    new_xyz = gather_point(ctr_src, fps_idx)                                # :116-119
+    m = new_xyz.shape[1]
+    lib = N.lib()
+    stream = N.current_stream()
+
+    nscale = len(radius_list)
+    if nscale > 0:
+        # ---- all bands of the layer in one ball-query pass (:134-147)
+        idx_list = [torch.empty((bs, m, int(ns)), dtype=torch.int32, device=dev) for ns in nsample_list]
+        cnt_list = [torch.empty((bs, m), dtype=torch.int32, device=dev) for _ in nsample_list]
+        rmax = (ctypes.c_float * nscale)(*[float(r) for r in radius_list])
+        rmin = (ctypes.c_float * nscale)(*[0.0 if i == 0 else float(radius_list[i - 1]) for i in range(nscale)])
+        nsa = (ctypes.c_int * nscale)(*[int(v) for v in nsample_list])
+        idxp = (ctypes.c_void_p * nscale)(*[t.data_ptr() for t in idx_list])
+        cntp = (ctypes.c_void_p * nscale)(*[t.data_ptr() for t in cnt_list])
+        st = lib.sa_query_ball_point_multi(bs, n_all, m, nscale, rmin, rmax, nsa, 1 if dilated_group else 0,
+                                           xyz.data_ptr(), new_xyz.data_ptr(), idxp, cntp, stream)
+        N.check(st, "query_ball_point")
+        # ---- per scale: fused mask/group/concat/MLP/max/mask (:157-181) into the concat buffer (:183)
+        layers = [[vs.layer("%s/conv%d_%d" % (scope, i, j), bn) for j in range(len(mlp_list[i]))]
+                  for i in range(nscale)]
+        ctot = sum(ls[-1].N for ls in layers)
+        new_points_concat = torch.empty((bs, m, ctot), dtype=torch.float32, device=dev)
+        c_feat = points.shape[2]
+        off = 0
+        for i in range(nscale):
+            ls = layers[i]
+            nl = len(ls)
+            dims = (ctypes.c_int * (nl + 1))(*([c_feat + 3] + [l.N for l in ls]))
+            wp = (ctypes.c_void_p * nl)(*[l.w.data_ptr() for l in ls])
+            bp = (ctypes.c_void_p * nl)(*[l.bias.data_ptr() for l in ls])
+            st = lib.sa_group_mlp_max(bs, n_all, m, int(nsample_list[i]), c_feat, xyz.data_ptr(),
+                                      points.data_ptr(), new_xyz.data_ptr(), idx_list[i].data_ptr(),
+                                      cnt_list[i].data_ptr(), nl, dims, wp, bp,
+                                      new_points_concat.data_ptr(), ctot, off, stream)
+            N.check(st, "group_mlp_max")
+            off += ls[-1].N
+        if AGGREGATION_SA_FEATURE:                                          # :184-185
+            agg = vs.layer(scope + "/ensemble", bn)
+            T.require(agg.N == aggregation_channel, "aggregation_channel does not match the ensemble weights")
+            new_points_concat = _dense(new_points_concat, agg, relu=True)
+    else:
+        new_points_concat = gather_point(points, fps_idx)                   # :186-187
+    return new_xyz, new_points_concat, fps_idx

@@ -1,0 +1,25 @@
+"""calc_square_dist of the reference's lib/utils/model_util.py:144-160 on torch-ROCm tensors (the only
+function of that module on the SA hot path: it builds the F-FPS distance matrix,
+lib/utils/layers_util.py:95,103)."""
+import torch
+
+from .tf_ops import _tensor as T
+from . import _native as N
+
+
+def calc_square_dist(a, b, norm=False):
+    """a: [bs, npoint, c], b: [bs, ndataset, c] -> [bs, npoint, ndataset] = |a|^2 + |b|^2 - 2 a.b
+    (channel sums as ascending fmaf chains; see csrc/sqdist.hip).  norm=True (sqrt / c, never used on
+    the SA path) is not provided."""
+    T.require(not norm, "calc_square_dist: only norm=False is implemented (the SA path never uses norm=True)")
+    a = T.f32_cuda(a, "a")
+    b = T.f32_cuda(b, "b")
+    T.require(a.dim() == 3 and b.dim() == 3 and a.shape[0] == b.shape[0] and a.shape[2] == b.shape[2],
+              "calc_square_dist expects a [bs,npoint,c] and b [bs,ndataset,c]")
+    bs, n, c = a.shape
+    m = b.shape[1]
+    out = torch.empty((bs, n, m), dtype=torch.float32, device=a.device)
+    st = N.lib().sa_calc_square_dist(bs, n, m, c, a.data_ptr(), b.data_ptr(), out.data_ptr(),
+                                     N.current_stream())
+    N.check(st, "calc_square_dist")
+    return out

@@ -1,0 +1,61 @@
+"""Sampling operators with the reference's Python API (lib/utils/tf_ops/sampling/tf_sampling.py),
+on torch-ROCm tensors instead of tf.Tensor, backed by the gfx950 kernels in csrc/fps.hip and
+csrc/gather.hip through the C ABI of include/sa_ops.h.
+
+Same names, positional order (scalars first), return dtypes/shapes.  Forward only: the reference
+registers FPS as NoGradient (tf_sampling.py:52,63); GatherPoint's gradient (tf_sampling.py:38-42) is
+out of scope.  Argument errors are raised as ValueError with the reference's OP_REQUIRES messages
+(lib/utils/tf_ops/sampling/tf_sampling.cpp:136,142,169,175,241,246).
+"""
+import torch
+
+from .. import _tensor as T
+from ... import _native as N
+
+
+def farthest_point_sample(npoint, inp):
+    """inp: (batch, ndataset, c) float32 -> (batch, npoint) int32.   tf_sampling.py:43-51"""
+    T.require(int(npoint) > 0, "FarthestPointSample expects positive npoint")
+    inp = T.f32_cuda(inp, "inp")
+    T.require(inp.dim() == 3, "FarthestPointSample expects (batch_size,num_points,c) inp shape")
+    b, n, c = inp.shape
+    out = torch.empty((b, int(npoint)), dtype=torch.int32, device=inp.device)
+    # allocate_temp [b,n] of tf_sampling.cpp:153; only read by the global-scratch kernel
+    temp = torch.empty((b, n), dtype=torch.float32, device=inp.device) if (c != 3 or n > 16384) else None
+    st = N.lib().sa_farthest_point_sample(b, n, c, int(npoint), inp.data_ptr(),
+                                          temp.data_ptr() if temp is not None else None,
+                                          out.data_ptr(), N.current_stream())
+    N.check(st, "farthest_point_sample")
+    return out
+
+
+def farthest_point_sample_with_distance(npoint, dist):
+    """dist: (batch, ndataset, ndataset) float32 -> (batch, npoint) int32.   tf_sampling.py:54-62"""
+    T.require(int(npoint) > 0, "FarthestPointSampleWithDistance expects positive npoint")
+    dist = T.f32_cuda(dist, "dist")
+    T.require(dist.dim() == 3 and dist.shape[1] == dist.shape[2],
+              "FarthestPointSampleWithDistance expects (batch_size,num_points,num_points) inp shape")
+    b, n, _ = dist.shape
+    out = torch.empty((b, int(npoint)), dtype=torch.int32, device=dist.device)
+    temp = torch.empty((b, n), dtype=torch.float32, device=dist.device) if n > 16384 else None
+    st = N.lib().sa_farthest_point_sample_with_distance(b, n, int(npoint), dist.data_ptr(),
+                                                        temp.data_ptr() if temp is not None else None,
+                                                        out.data_ptr(), N.current_stream())
+    N.check(st, "farthest_point_sample_with_distance")
+    return out
+
+
+def gather_point(inp, idx):
+    """inp: (batch, ndataset, c) float32, idx: (batch, npoints) int32 -> (batch, npoints, c).
+    tf_sampling.py:24-32"""
+    inp = T.f32_cuda(inp, "inp")
+    idx = T.i32_cuda(idx, "idx")
+    T.require(inp.dim() == 3, "GatherPoint expects (batch_size,num_points,c) inp shape")
+    b, n, c = inp.shape
+    T.require(idx.dim() == 2 and idx.shape[0] == b, "GatherPoint expects (batch_size,num_result) idx shape")
+    m = idx.shape[1]
+    out = torch.empty((b, m, c), dtype=torch.float32, device=inp.device)
+    st = N.lib().sa_gather_point(b, n, m, c, inp.data_ptr(), idx.data_ptr(), out.data_ptr(),
+                                 N.current_stream())
+    N.check(st, "gather_point")
+    return out

@@ -1,0 +1,108 @@
+/*
+ * sa_ops.h -- C ABI of lib3dssd_sa.so, the gfx950 (MI355X) implementation of the 3DSSD
+ * set-abstraction hot path.
+ *
+ * Drop-in boundary.  The reference binds its CUDA kernels through plain C++ launcher functions that
+ * the TensorFlow OpKernels call with raw device pointers (declared in tf_sampling.cpp /
+ * tf_grouping.cpp, defined in the *_g.cu files).  Every entry below that cites a reference launcher
+ * takes the same scalars and device pointers in the same order, plus an explicit hipStream_t (the
+ * reference launches on the legacy default stream, e.g. tf_sampling_g.cu:393) and returns a status
+ * instead of void (the reference never checks cudaGetLastError).
+ *
+ * Conventions: all tensors are dense, row-major, channel-last, device resident; float = fp32,
+ * int = int32.  The library never allocates and keeps no state; outputs and scratch are owned by
+ * the caller (TF allocate_output / allocate_temp analogue, tf_sampling.cpp:149-155).  Functions are
+ * re-entrant.  Return: 0 ok, -1 invalid argument (the reference's OP_REQUIRES conditions), -2 launch
+ * failure (hipGetLastError), -3 unsupported size.  hipStream_t is passed as void*.
+ */
+#ifndef SA_OPS_H
+#define SA_OPS_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *sa_stream_t; /* hipStream_t */
+
+/* ---- sampling: lib/utils/tf_ops/sampling ------------------------------------------------ */
+
+/* farthestpointsamplingLauncher(b,n,c,m,inp,temp,out)   tf_sampling.cpp:131, tf_sampling_g.cu:123-178,392-394
+ * inp [b,n,c], temp [b,n] scratch (only touched when c != 3 or n > 16384), out [b,m] int32. */
+int sa_farthest_point_sample(int b, int n, int c, int m, const float *inp, float *temp, int *out,
+                             sa_stream_t stream);
+
+/* farthestpointsamplingwithdistLauncher(b,n,m,inp,temp,out)   tf_sampling.cpp:164, tf_sampling_g.cu:180-230,396-398
+ * dist [b,n,n], temp [b,n] scratch (only touched when n > 16384), out [b,m] int32. */
+int sa_farthest_point_sample_with_distance(int b, int n, int m, const float *dist, float *temp,
+                                           int *out, sa_stream_t stream);
+
+/* gatherpointLauncher(b,n,m,c,inp,idx,out)   tf_sampling.cpp:235, tf_sampling_g.cu:320-331,403-407 */
+int sa_gather_point(int b, int n, int m, int c, const float *inp, const int *idx, float *out,
+                    sa_stream_t stream);
+
+/* ---- grouping: lib/utils/tf_ops/grouping ------------------------------------------------ */
+
+/* queryBallPointLauncher(b,n,m,radius,nsample,xyz1,xyz2,idx,pts_cnt)   tf_grouping.cpp:270, tf_grouping_g.cu:215-255,461-464
+ * xyz1 [b,n,3], xyz2 [b,m,3], idx [b,m,nsample], pts_cnt [b,m].  Rows of empty balls are zero-filled
+ * (the reference leaves them unwritten). */
+int sa_query_ball_point(int b, int n, int m, float radius, int nsample, const float *xyz1,
+                        const float *xyz2, int *idx, int *pts_cnt, sa_stream_t stream);
+
+/* queryBallPointDilatedLauncher(b,n,m,min_radius,max_radius,nsample,...)   tf_grouping.cpp:363, tf_grouping_g.cu:308-357,465-468 */
+int sa_query_ball_point_dilated(int b, int n, int m, float min_radius, float max_radius, int nsample,
+                                const float *xyz1, const float *xyz2, int *idx, int *pts_cnt,
+                                sa_stream_t stream);
+
+/* groupPointLauncher(b,n,c,m,nsample,points,idx,out)   tf_grouping.cpp:446, tf_grouping_g.cu:362-379,476-479 */
+int sa_group_point(int b, int n, int c, int m, int nsample, const float *points, const int *idx,
+                   float *out, sa_stream_t stream);
+
+/* ---- F-FPS distance matrix: lib/utils/model_util.py:144-160 (calc_square_dist, norm=False) ----
+ * In the reference this is TensorFlow graph code (tf.matmul); a [bs,n,c], bb [bs,m,c] -> out [bs,n,m]. */
+int sa_calc_square_dist(int b, int n, int m, int c, const float *a, const float *bb, float *out,
+                        sa_stream_t stream);
+
+/* ======== additional entry points (no counterpart in the reference API) ==================== */
+
+/* Same kernels with an output row stride and an index offset, so the F-FPS and D-FPS halves of an
+ * 'FS' layer land in one [b, npoint_total] tensor (layers_util.py:96-98,108). */
+int sa_fps_ex(int b, int n, int c, int m, const float *inp, float *temp, int *out, int out_stride,
+              int idx_off, sa_stream_t stream);
+int sa_fps_with_distance_ex(int b, int n, int m, const float *dist, float *temp, int *out,
+                            int out_stride, int idx_off, sa_stream_t stream);
+/* Forces the global-scratch kernels (mode 0: points [b,n,c], mode 1: matrix [b,n,n]); test hook. */
+int sa_fps_generic(int b, int n, int c, int m, const float *inp, float *temp, int *out, int mode,
+                   sa_stream_t stream);
+
+/* calc_square_dist on rows given as two pieces [a0 | a1] (concat([xyz, feat]) never materialised,
+ * layers_util.py:94,102). */
+int sa_calc_square_dist_split(int b, int n, int m, int c0, int c1, const float *a0, const float *a1,
+                              const float *b0, const float *b1, float *out, sa_stream_t stream);
+
+/* All radius bands of one SA layer in one pass (layers_util.py:134-147).  rmin/rmax/ns: host arrays of
+ * nbands entries; idx/cnt: host arrays of nbands device pointers.  dilated=0 ignores rmin. */
+int sa_query_ball_point_multi(int b, int n, int m, int nbands, const float *rmin, const float *rmax,
+                              const int *ns, int dilated, const float *xyz1, const float *xyz2,
+                              int *const *idx, int *const *cnt, sa_stream_t stream);
+
+/* One scale of pointnet_sa_module_msg fused: mask, group, concat [features, rel-xyz], nl x
+ * (conv1x1 + folded BN + ReLU), max over nsample, empty-ball mask (layers_util.py:157-181).
+ * dims[0] = c+3, dims[l+1] = output channels of layer l; wpack[l]/bias[l] device pointers in the
+ * layouts documented in 3dssd_amd/csrc/mlp.hip; out[(b*m+j)*out_stride + out_off + ch]. */
+int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float *xyz, const float *feat,
+                     const float *new_xyz, const int *idx, const int *cnt, int nl, const int *dims,
+                     const void *const *wpack, const float *const *bias, float *out, int out_stride,
+                     int out_off, sa_stream_t stream);
+
+/* y[rows,N] = act(x[rows,K] W + b): tf_util.conv1d 1x1 + folded BN (tf_util.py:51-124). */
+int sa_dense(long rows, int K, int N, const float *x, const void *wpack, const float *bias, int relu,
+             float *y, sa_stream_t stream);
+
+/* vote_layer tail (layers_util.py:21-23): out = xyz + clip(off, lo, -lo), lo = MAX_TRANSLATE_RANGE. */
+int sa_vote_translate(long npoints, const float *xyz, const float *off, float lo_x, float lo_y,
+                      float lo_z, float *out, sa_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SA_OPS_H */

@@ -1,0 +1,314 @@
+/*
+ * sa_oracle.c -- CPU restatement of the 3DSSD set-abstraction hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under 3dssd_amd/ (the product) may import,
+ * link or execute this file.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py use it, as the checker / the timed CPU baseline.
+ *
+ * PARITY UNPINNED: the reference ships no CPU implementation of these ops, no
+ * golden vectors and no known-answer tests for them, and it
+ * cannot be built here (TensorFlow 1.4 headers + nvcc absent).  This file restates
+ * the semantics of the reference CUDA kernels; the hand-derived known-answer tests in
+ * tests/test_oracle_kat.py are what pins it.
+ *
+ * Arithmetic decisions (recorded once, used by oracle and HIP kernels alike):
+ *  A. FPS distance (lib/utils/tf_ops/sampling/tf_sampling_g.cu:144-150) is the loop
+ *     `d += (p2-p1)*(p2-p1)` over channels.  compile_all.sh:22 builds with plain
+ *     `nvcc -O2`, i.e. the default -fmad=true, so every step is one fused
+ *     multiply-add: d = fmaf(diff, diff, d), channels ascending, d starting at 0.
+ *  B. Ball-query distance (lib/utils/tf_ops/grouping/tf_grouping_g.cu:243,336) is the
+ *     single expression dx*dx + dy*dy + dz*dz.  Under -fmad=true the LLVM/NVVM
+ *     contraction of ((dx*dx + dy*dy) + dz*dz) is fma(dz,dz, fma(dx,dx, dy*dy))
+ *     (the left product of each add is the fused one, the remaining product is a
+ *     plain multiply).  nvcc is not available to confirm the PTX; this is the pinned
+ *     definition.  The comparison is on the correctly rounded sqrtf of that value.
+ *  C. FPS tie-break is the reference's (k mod 1024, k) order: thread t of the
+ *     1024-thread block keeps its first strict maximum over k = t, t+1024, ... and the
+ *     shared-memory tree keeps the left entry on ties (tf_sampling_g.cu:154-171).
+ *  D. Empty balls leave idx unwritten in the reference (tf_grouping_g.cu:236-253);
+ *     here the row is zero-filled.
+ *  E. calc_square_dist (lib/utils/model_util.py:144-160, norm=False) is
+ *     (|a|^2 + |b|^2) - 2*(a.b) with |.|^2 and a.b as fmaf chains over channels
+ *     ascending from 0.  TensorFlow's own order (cuBLAS) is unpinnable.
+ *  F. Grouped MLP (lib/utils/tf_util.py:127-201,424-444 via
+ *     lib/utils/layers_util.py:167-181): conv1x1 + bias + inference BN folded into
+ *     (W', b'); y = relu(chain + b') with chain = fmaf over input channels ascending
+ *     from 0; then max over nsample and the pts_cnt>0 mask.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define FPS_BLOCK 1024 /* blockDim of the reference launch, tf_sampling_g.cu:392-398 */
+
+/* ---- A.1 farthest_point_sample: tf_sampling_g.cu:123-178 ---------------------- */
+void orc_farthest_point_sample(int b, int n, int c, int m, const float *inp, float *temp,
+                               int *out) {
+    if (m <= 0) return; /* :125-126 */
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int i = 0; i < b; ++i) {
+        const float *p = inp + (size_t)i * n * c;
+        float *td = temp + (size_t)i * n;
+        int *o = out + (size_t)i * m;
+        float best[FPS_BLOCK];
+        int besti[FPS_BLOCK];
+        int old = 0;
+        o[0] = 0;                                   /* :131-133 */
+        for (int k = 0; k < n; ++k) td[k] = 1e38f;  /* :135-137 */
+        for (int j = 1; j < m; ++j) {
+            for (int t = 0; t < FPS_BLOCK; ++t) { best[t] = -1.0f; besti[t] = 0; } /* :140-141 */
+            const float *po = p + (size_t)old * c;
+            for (int k = 0; k < n; ++k) { /* k ascending visits each thread's points ascending */
+                const float *pk = p + (size_t)k * c;
+                float d = 0.0f;
+                for (int l = 0; l < c; ++l) {
+                    float diff = pk[l] - po[l];       /* p2 - p1, :147-149 */
+                    d = fmaf(diff, diff, d);          /* decision A */
+                }
+                float d2 = fminf(d, td[k]);           /* :151 */
+                td[k] = d2;
+                int t = k & (FPS_BLOCK - 1);
+                if (d2 > best[t]) { best[t] = d2; besti[t] = k; } /* :154-157 */
+            }
+            /* left-wins-ties tree (:161-171) == first maximum over t ascending */
+            float gb = best[0];
+            int gi = besti[0];
+            for (int t = 1; t < FPS_BLOCK; ++t)
+                if (gb < best[t]) { gb = best[t]; gi = besti[t]; }
+            old = gi;
+            o[j] = old;                               /* :173-175 */
+        }
+    }
+}
+
+/* ---- A.2 farthest_point_sample_with_distance: tf_sampling_g.cu:180-230 -------- */
+void orc_farthest_point_sample_with_distance(int b, int n, int m, const float *dist,
+                                             float *temp, int *out) {
+    if (m <= 0) return;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int i = 0; i < b; ++i) {
+        const float *D = dist + (size_t)i * n * n;
+        float *td = temp + (size_t)i * n;
+        int *o = out + (size_t)i * m;
+        float best[FPS_BLOCK];
+        int besti[FPS_BLOCK];
+        int old = 0;
+        o[0] = 0;
+        for (int k = 0; k < n; ++k) td[k] = 1e38f;
+        for (int j = 1; j < m; ++j) {
+            for (int t = 0; t < FPS_BLOCK; ++t) { best[t] = -1.0f; besti[t] = 0; }
+            const float *row = D + (size_t)old * n;  /* :202 */
+            for (int k = 0; k < n; ++k) {
+                float d2 = fminf(row[k], td[k]);
+                td[k] = d2;
+                int t = k & (FPS_BLOCK - 1);
+                if (d2 > best[t]) { best[t] = d2; besti[t] = k; }
+            }
+            float gb = best[0];
+            int gi = besti[0];
+            for (int t = 1; t < FPS_BLOCK; ++t)
+                if (gb < best[t]) { gb = best[t]; gi = besti[t]; }
+            old = gi;
+            o[j] = old;
+        }
+    }
+}
+
+/* ---- A.3 calc_square_dist: model_util.py:144-160 (norm=False), decision E ----- */
+void orc_calc_square_dist(int b, int n, int m, int c, const float *a, const float *bb,
+                          float *out) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < b; ++i) {
+        const float *A = a + (size_t)i * n * c;
+        const float *B = bb + (size_t)i * m * c;
+        float *O = out + (size_t)i * n * m;
+        float *bsq = (float *)malloc(sizeof(float) * (size_t)m);
+        for (int q = 0; q < m; ++q) {
+            float s = 0.0f;
+            for (int l = 0; l < c; ++l) s = fmaf(B[(size_t)q * c + l], B[(size_t)q * c + l], s);
+            bsq[q] = s;
+        }
+        for (int p = 0; p < n; ++p) {
+            const float *ap = A + (size_t)p * c;
+            float asq = 0.0f;
+            for (int l = 0; l < c; ++l) asq = fmaf(ap[l], ap[l], asq);
+            for (int q = 0; q < m; ++q) {
+                const float *bq = B + (size_t)q * c;
+                float dot = 0.0f;
+                for (int l = 0; l < c; ++l) dot = fmaf(ap[l], bq[l], dot);
+                O[(size_t)p * m + q] = (asq + bsq[q]) - 2.0f * dot;
+            }
+        }
+        free(bsq);
+    }
+}
+
+/* ---- A.4 gather_point: tf_sampling_g.cu:320-331 -------------------------------- */
+void orc_gather_point(int b, int n, int m, int c, const float *inp, const int *idx,
+                      float *out) {
+    for (int i = 0; i < b; ++i)
+        for (int j = 0; j < m; ++j) {
+            int a = idx[(size_t)i * m + j];
+            memcpy(out + ((size_t)i * m + j) * c, inp + ((size_t)i * n + a) * c,
+                   sizeof(float) * (size_t)c);
+        }
+}
+
+static inline float ball_d2(float x1, float y1, float z1, float x2, float y2, float z2) {
+    float dx = x2 - x1, dy = y2 - y1, dz = z2 - z1;
+    return fmaf(dz, dz, fmaf(dx, dx, dy * dy)); /* decision B */
+}
+
+/* ---- A.5 query_ball_point: tf_grouping_g.cu:215-255 ---------------------------- */
+void orc_query_ball_point(int b, int n, int m, float radius, int nsample, const float *xyz1,
+                          const float *xyz2, int *idx, int *pts_cnt) {
+#pragma omp parallel for schedule(static)
+    for (long q = 0; q < (long)b * m; ++q) {
+        int bi = (int)(q / m);
+        const float *P = xyz1 + (size_t)bi * n * 3;
+        const float *c2 = xyz2 + (size_t)q * 3;
+        int *ci = idx + (size_t)q * nsample;
+        for (int l = 0; l < nsample; ++l) ci[l] = 0; /* decision D */
+        float x2 = c2[0], y2 = c2[1], z2 = c2[2];
+        int cnt = 0;
+        for (int k = 0; k < n; ++k) {
+            if (cnt == nsample) break;                             /* :237-239 */
+            float d = fmaxf(sqrtf(ball_d2(P[k * 3], P[k * 3 + 1], P[k * 3 + 2], x2, y2, z2)),
+                            1e-20f);                               /* :243 */
+            if (d < radius) {                                      /* :244 */
+                if (cnt == 0)
+                    for (int l = 0; l < nsample; ++l) ci[l] = k;   /* :245-248 */
+                ci[cnt] = k;
+                cnt += 1;
+            }
+        }
+        pts_cnt[q] = cnt;                                          /* :253 */
+    }
+}
+
+/* ---- A.6 query_ball_point_dilated: tf_grouping_g.cu:308-357 -------------------- */
+void orc_query_ball_point_dilated(int b, int n, int m, float min_radius, float max_radius,
+                                  int nsample, const float *xyz1, const float *xyz2, int *idx,
+                                  int *pts_cnt) {
+#pragma omp parallel for schedule(static)
+    for (long q = 0; q < (long)b * m; ++q) {
+        int bi = (int)(q / m);
+        const float *P = xyz1 + (size_t)bi * n * 3;
+        const float *c2 = xyz2 + (size_t)q * 3;
+        int *ci = idx + (size_t)q * nsample;
+        for (int l = 0; l < nsample; ++l) ci[l] = 0;
+        float x2 = c2[0], y2 = c2[1], z2 = c2[2];
+        int cnt = 0;
+        for (int k = 0; k < n; ++k) {
+            if (cnt == nsample) break;
+            float d = sqrtf(ball_d2(P[k * 3], P[k * 3 + 1], P[k * 3 + 2], x2, y2, z2)); /* :336 */
+            if (d == 0.0f || (d >= min_radius && d < max_radius)) { /* :337,346 */
+                if (cnt == 0)
+                    for (int l = 0; l < nsample; ++l) ci[l] = k;
+                ci[cnt] = k;
+                cnt += 1;
+            }
+        }
+        pts_cnt[q] = cnt;
+    }
+}
+
+/* ---- A.7 group_point: tf_grouping_g.cu:362-379 --------------------------------- */
+void orc_group_point(int b, int n, int c, int m, int nsample, const float *points,
+                     const int *idx, float *out) {
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < (long)b * m * nsample; ++r) {
+        int bi = (int)(r / ((long)m * nsample));
+        int a = idx[r];
+        float *o = out + (size_t)r * c;
+        if (a == -1) {                                             /* :373-375 */
+            for (int l = 0; l < c; ++l) o[l] = 0.0f;
+        } else {
+            memcpy(o, points + ((size_t)bi * n + a) * c, sizeof(float) * (size_t)c);
+        }
+    }
+}
+
+/* ---- dense layer: tf_util.conv1d/conv2d 1x1 with folded BN, decision F --------- */
+/* x[rows,cin] row-major, w[cin,cout] row-major, y[rows,cout]. */
+static void dense_rows(int rows, int cin, int cout, const float *x, const float *w,
+                       const float *bias, int relu, float *y) {
+    for (int r = 0; r < rows; ++r) {
+        const float *xr = x + (size_t)r * cin;
+        float *yr = y + (size_t)r * cout;
+        for (int o = 0; o < cout; ++o) yr[o] = 0.0f;
+        for (int k = 0; k < cin; ++k) {
+            float xv = xr[k];
+            const float *wk = w + (size_t)k * cout;
+            for (int o = 0; o < cout; ++o) yr[o] = fmaf(xv, wk[o], yr[o]);
+        }
+        if (bias)
+            for (int o = 0; o < cout; ++o) yr[o] = yr[o] + bias[o];
+        if (relu)
+            for (int o = 0; o < cout; ++o) yr[o] = yr[o] > 0.0f ? yr[o] : 0.0f;
+    }
+}
+
+void orc_dense(int rows, int cin, int cout, const float *x, const float *w, const float *bias,
+               int relu, float *y) {
+    const int chunk = 256;
+#pragma omp parallel for schedule(static)
+    for (int r0 = 0; r0 < rows; r0 += chunk) {
+        int nr = rows - r0 < chunk ? rows - r0 : chunk;
+        dense_rows(nr, cin, cout, x + (size_t)r0 * cin, w, bias, relu, y + (size_t)r0 * cout);
+    }
+}
+
+/* ---- one scale of pointnet_sa_module_msg: layers_util.py:157-181 ---------------
+ * idx*=mask -> group(xyz)-new_xyz, group(points) -> concat [feat, rel_xyz] ->
+ * conv/BN/ReLU stack -> max over nsample -> *mask.
+ * xyz[b,n,3], points[b,n,c] (c may be 0 -> points ignored), new_xyz[b,m,3],
+ * idx[b,m,ns], cnt[b,m]; dims[0] must equal c+3; W[l] is [dims[l], dims[l+1]].
+ * out[b,m,dims[nl]].  */
+void orc_group_mlp_max(int b, int n, int m, int ns, int c, const float *xyz, const float *points,
+                       const float *new_xyz, const int *idx, const int *cnt, int nl,
+                       const int *dims, const float *const *W, const float *const *B,
+                       float *out) {
+    int maxd = 0;
+    for (int l = 0; l <= nl; ++l) if (dims[l] > maxd) maxd = dims[l];
+    const int cout = dims[nl];
+#pragma omp parallel
+    {
+        float *buf0 = (float *)malloc(sizeof(float) * (size_t)ns * maxd);
+        float *buf1 = (float *)malloc(sizeof(float) * (size_t)ns * maxd);
+#pragma omp for schedule(static)
+        for (long q = 0; q < (long)b * m; ++q) {
+            int bi = (int)(q / m);
+            const float *X = xyz + (size_t)bi * n * 3;
+            const float *F = points ? points + (size_t)bi * n * c : 0;
+            const float *ctr = new_xyz + (size_t)q * 3;
+            int nonempty = cnt[q] > 0;
+            const int cin = c + 3;
+            for (int s = 0; s < ns; ++s) {
+                int a = nonempty ? idx[(size_t)q * ns + s] : 0; /* layers_util.py:157-159 */
+                float *row = buf0 + (size_t)s * cin;
+                for (int l = 0; l < c; ++l) row[l] = F[(size_t)a * c + l]; /* features first, :165 */
+                row[c + 0] = X[(size_t)a * 3 + 0] - ctr[0];                 /* :161-163 */
+                row[c + 1] = X[(size_t)a * 3 + 1] - ctr[1];
+                row[c + 2] = X[(size_t)a * 3 + 2] - ctr[2];
+            }
+            float *cur = buf0, *nxt = buf1;
+            for (int l = 0; l < nl; ++l) {
+                dense_rows(ns, dims[l], dims[l + 1], cur, W[l], B[l], 1, nxt);
+                float *t = cur; cur = nxt; nxt = t;
+            }
+            float *o = out + (size_t)q * cout;
+            for (int ch = 0; ch < cout; ++ch) {
+                float mx = cur[ch];
+                for (int s = 1; s < ns; ++s) {
+                    float v = cur[(size_t)s * cout + ch];
+                    if (v > mx) mx = v;                                      /* :178 */
+                }
+                o[ch] = nonempty ? mx : 0.0f;                                /* :180 */
+            }
+        }
+        free(buf0);
+        free(buf1);
+    }
+}
