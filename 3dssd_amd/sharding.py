@@ -1,0 +1,61 @@
+"""Frame sharding across the GPUs of one node.
+
+Every op of the SA path indexes its own batch item only and inference BatchNorm uses frozen statistics,
+so frames are independent units: frame f goes to rank f mod world_size, weights are replicated, and
+there is NO collective on the data path.  torch.distributed (backend "nccl" = RCCL over xGMI on the
+GPU box, "gloo" in the CPU tests) is used only to agree on the wall time (max over ranks), to add up the
+frame counts, and optionally to gather the small backbone outputs on rank 0.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    """(rank, local_rank, world_size) from the torchrun environment (1 process per GPU)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init(backend=None):
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def frames_of_rank(first_frame, n_frames, rank, world):
+    """Global frame ids handled by `rank`: f with f mod world == rank (round-robin)."""
+    return [f for f in range(first_frame, first_frame + n_frames) if f % world == rank]
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def reduce_timing(elapsed_s, frames_done, device="cpu"):
+    """(max elapsed over ranks, total frames over ranks)."""
+    if not dist.is_initialized():
+        return float(elapsed_s), int(frames_done)
+    t = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=device)
+    c = torch.tensor([float(frames_done)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(c, op=dist.ReduceOp.SUM)
+    return float(t.item()), int(round(c.item()))
+
+
+def gather_outputs(xyz, feat):
+    """all_gather of the per-rank backbone outputs ([B_local,256,3], [B_local,256,512]) -> lists ordered
+    by rank.  ~0.53 MB per frame; not part of the timed path."""
+    if not dist.is_initialized():
+        return [xyz], [feat]
+    world = dist.get_world_size()
+    xs = [torch.empty_like(xyz) for _ in range(world)]
+    fs = [torch.empty_like(feat) for _ in range(world)]
+    dist.all_gather(xs, xyz.contiguous())
+    dist.all_gather(fs, feat.contiguous())
+    return xs, fs

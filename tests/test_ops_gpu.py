@@ -1,0 +1,313 @@
+"""Parity of every HIP operator against the CPU oracle on identical seeded inputs (run with -m gpu).
+Bar (BASELINE.json): bit-exact FPS indices and ball-query neighbour sets/counts, bit-exact copies and
+distance matrices, grouped-MLP outputs within 1e-3 relative (max|d| / max|ref|) of the fp32 oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+
+pytestmark = pytest.mark.gpu
+MLP_TOL = 1e-3
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _cloud(rng, b, n, scale=10.0, dup=0):
+    p = rng.uniform(-scale, scale, (b, n, 3)).astype(np.float32)
+    if dup:
+        src = rng.integers(0, n - dup, (b, dup))
+        for i in range(b):
+            p[i, n - dup:] = p[i, src[i]]
+    return p
+
+
+# ----------------------------------------------------------------------------------- FPS
+@pytest.mark.parametrize("b,n,m,dup", [(1, 5, 3, 0), (2, 64, 64, 0), (3, 1000, 100, 0), (2, 1024, 256, 100),
+                                       (2, 2048, 512, 400), (2, 4096, 512, 0), (1, 5000, 300, 500),
+                                       (2, 16384, 1024, 1600), (1, 777, 777, 0)])
+def test_fps_matches_oracle(gpu, oracle, b, n, m, dup):
+    S = pkg("utils.tf_ops.sampling.tf_sampling")
+    rng = np.random.default_rng(n * 7 + m)
+    p = _cloud(rng, b, n, dup=dup)
+    got = S.farthest_point_sample(m, _t(p, gpu)).cpu().numpy()
+    ref = oracle.farthest_point_sample(m, p)
+    assert got.dtype == np.int32 and got.shape == (b, m)
+    assert np.array_equal(got, ref)
+
+
+def test_fps_all_points_identical(gpu, oracle):
+    # every distance is 0: ties everywhere, the (k mod 1024, k) rule decides every pick
+    S = pkg("utils.tf_ops.sampling.tf_sampling")
+    p = np.ones((2, 3000, 3), np.float32)
+    got = S.farthest_point_sample(50, _t(p, gpu)).cpu().numpy()
+    assert np.array_equal(got, oracle.farthest_point_sample(50, p))
+    assert (got == 0).all()
+
+
+def test_fps_tiebreak_and_fma_kats(gpu):
+    S = pkg("utils.tf_ops.sampling.tf_sampling")
+    n = 2048
+    p = np.zeros((1, n, 3), np.float32)
+    p[0, 7, 0] = 3.0
+    p[0, 1030, 0] = -3.0
+    assert S.farthest_point_sample(2, _t(p, gpu)).cpu().tolist() == [[0, 1030]]
+    o = [-0.6892402172088623, -0.11729754507541656, -0.16030718386173248]
+    a = [0.6565782427787781, 0.3208279013633728, -0.18391664326190948]
+    bb = [-0.25111478567123413, -0.14090700447559357, 1.1855113506317139]
+    p = np.array([[o, a, bb]], np.float32)
+    assert S.farthest_point_sample(2, _t(p, gpu)).cpu().tolist() == [[0, 2]]   # fused chain, see KAT
+
+
+@pytest.mark.parametrize("b,n,c,m", [(2, 300, 5, 40), (1, 2048, 67, 128), (2, 512, 131, 64), (1, 20000, 3, 64)])
+def test_fps_generic_channels_and_large_n(gpu, oracle, b, n, c, m):
+    S = pkg("utils.tf_ops.sampling.tf_sampling")
+    rng = np.random.default_rng(c + n)
+    p = rng.normal(0, 1, (b, n, c)).astype(np.float32)
+    got = S.farthest_point_sample(m, _t(p, gpu)).cpu().numpy()
+    assert np.array_equal(got, oracle.farthest_point_sample(m, p))
+
+
+def test_fps_forced_generic_kernel_equals_register_kernel(gpu, oracle):
+    N = pkg("utils._native")
+    rng = np.random.default_rng(5)
+    p = _cloud(rng, 2, 3000, dup=300)
+    t = _t(p, gpu)
+    out = torch.empty((2, 200), dtype=torch.int32, device=gpu)
+    temp = torch.empty((2, 3000), dtype=torch.float32, device=gpu)
+    st = N.lib().sa_fps_generic(2, 3000, 3, 200, t.data_ptr(), temp.data_ptr(), out.data_ptr(), 0,
+                                N.current_stream())
+    assert st == 0
+    assert np.array_equal(out.cpu().numpy(), oracle.farthest_point_sample(200, p))
+
+
+@pytest.mark.parametrize("b,n,m", [(1, 4, 4), (2, 100, 30), (2, 512, 256), (1, 1500, 200), (2, 4096, 512)])
+def test_fps_with_distance(gpu, oracle, b, n, m):
+    S = pkg("utils.tf_ops.sampling.tf_sampling")
+    rng = np.random.default_rng(n + m)
+    f = rng.normal(0, 1, (b, n, 9)).astype(np.float32)
+    d = oracle.calc_square_dist(f, f)
+    got = S.farthest_point_sample_with_distance(m, _t(d, gpu)).cpu().numpy()
+    assert np.array_equal(got, oracle.farthest_point_sample_with_distance(m, d))
+
+
+def test_fps_with_distance_negative_rows(gpu, oracle):
+    S = pkg("utils.tf_ops.sampling.tf_sampling")
+    d = np.full((1, 3, 3), -2.0, np.float32)
+    assert S.farthest_point_sample_with_distance(3, _t(d, gpu)).cpu().tolist() == [[0, 0, 0]]
+    rng = np.random.default_rng(0)
+    d = rng.normal(-0.5, 1.0, (2, 700, 700)).astype(np.float32)
+    got = S.farthest_point_sample_with_distance(100, _t(d, gpu)).cpu().numpy()
+    assert np.array_equal(got, oracle.farthest_point_sample_with_distance(100, d))
+
+
+# ----------------------------------------------------------------------------------- gathers
+@pytest.mark.parametrize("c", [1, 3, 4, 64, 67, 256])
+def test_gather_and_group_point(gpu, oracle, c):
+    S = pkg("utils.tf_ops.sampling.tf_sampling")
+    G = pkg("utils.tf_ops.grouping.tf_grouping")
+    rng = np.random.default_rng(c)
+    b, n, m, ns = 2, 500, 37, 16
+    pts = rng.normal(0, 1, (b, n, c)).astype(np.float32)
+    idx = rng.integers(0, n, (b, m)).astype(np.int32)
+    assert np.array_equal(S.gather_point(_t(pts, gpu), _t(idx, gpu)).cpu().numpy(), oracle.gather_point(pts, idx))
+    gidx = rng.integers(-1, n, (b, m, ns)).astype(np.int32)      # includes -1 -> zero rows
+    got = G.group_point(_t(pts, gpu), _t(gidx, gpu)).cpu().numpy()
+    assert np.array_equal(got, oracle.group_point(pts, gidx))
+
+
+# ----------------------------------------------------------------------------------- ball query
+def _check_ball(got_idx, got_cnt, ref_idx, ref_cnt):
+    assert np.array_equal(got_cnt, ref_cnt)
+    assert np.array_equal(got_idx, ref_idx)          # includes padding and zero-filled empty rows
+
+
+@pytest.mark.parametrize("b,n,m,r,ns", [(1, 6, 1, 0.5, 5), (2, 1000, 100, 1.5, 32), (2, 4096, 512, 2.0, 64),
+                                        (1, 3000, 77, 0.3, 16), (2, 513, 9, 50.0, 8), (1, 2000, 50, 3.0, 100)])
+def test_query_ball_point(gpu, oracle, b, n, m, r, ns):
+    G = pkg("utils.tf_ops.grouping.tf_grouping")
+    rng = np.random.default_rng(n + ns)
+    xyz1 = _cloud(rng, b, n, scale=8.0, dup=n // 10)
+    xyz2 = np.concatenate([xyz1[:, :m // 2], _cloud(rng, b, m - m // 2, scale=12.0)], 1)   # some empty balls
+    idx, cnt = G.query_ball_point(r, ns, _t(xyz1, gpu), _t(xyz2, gpu))
+    ridx, rcnt = oracle.query_ball_point(r, ns, xyz1, xyz2)
+    _check_ball(idx.cpu().numpy(), cnt.cpu().numpy(), ridx, rcnt)
+
+
+@pytest.mark.parametrize("rmin,rmax,ns", [(0.0, 0.8, 32), (0.8, 1.6, 32), (1.6, 3.2, 64), (0.5, 0.5000001, 4)])
+def test_query_ball_point_dilated(gpu, oracle, rmin, rmax, ns):
+    G = pkg("utils.tf_ops.grouping.tf_grouping")
+    rng = np.random.default_rng(int(rmax * 100))
+    b, n, m = 2, 3000, 300
+    xyz1 = _cloud(rng, b, n, scale=6.0, dup=300)
+    xyz2 = np.concatenate([xyz1[:, :200], _cloud(rng, b, 100, scale=9.0)], 1)
+    idx, cnt = G.query_ball_point_dilated(rmin, rmax, ns, _t(xyz1, gpu), _t(xyz2, gpu))
+    ridx, rcnt = oracle.query_ball_point_dilated(rmin, rmax, ns, xyz1, xyz2)
+    _check_ball(idx.cpu().numpy(), cnt.cpu().numpy(), ridx, rcnt)
+
+
+def test_ball_query_boundary_kats(gpu):
+    G = pkg("utils.tf_ops.grouping.tf_grouping")
+    def line(xs):
+        p = np.zeros((1, len(xs), 3), np.float32)
+        p[0, :, 0] = xs
+        return p
+    xyz1, xyz2 = line([0, .25, .5, .75, 1, 1.25]), line([0.5])
+    idx, cnt = G.query_ball_point(0.5, 5, _t(xyz1, gpu), _t(xyz2, gpu))
+    assert cnt.cpu().tolist() == [[3]] and idx.cpu().tolist() == [[[1, 2, 3, 1, 1]]]
+    r32 = np.float32(0.2)
+    xyz1 = line([r32, np.nextafter(r32, np.float32(0))])
+    idx, cnt = G.query_ball_point(0.2, 2, _t(xyz1, gpu), _t(line([0]), gpu))
+    assert cnt.cpu().tolist() == [[1]] and idx.cpu().tolist() == [[[1, 1]]]
+    xyz1 = line([0, .25, .5, .75, 1, 1.25, .5])
+    idx, cnt = G.query_ball_point_dilated(0.5, 0.8, 8, _t(xyz1, gpu), _t(line([0.5]), gpu))
+    assert cnt.cpu().tolist() == [[5]] and idx.cpu()[0, 0].tolist() == [0, 2, 4, 5, 6, 0, 0, 0]
+
+
+def test_ball_query_multi_band_equals_single_band(gpu, oracle):
+    import ctypes
+    N = pkg("utils._native")
+    rng = np.random.default_rng(11)
+    b, n, m = 2, 5000, 640
+    xyz1 = _cloud(rng, b, n, scale=5.0, dup=500)
+    xyz2 = xyz1[:, rng.permutation(n)[:m]].copy()
+    radii, nss = [0.4, 0.8, 1.6], [32, 32, 64]
+    t1, t2 = _t(xyz1, gpu), _t(xyz2, gpu)
+    idx = [torch.empty((b, m, s), dtype=torch.int32, device=gpu) for s in nss]
+    cnt = [torch.empty((b, m), dtype=torch.int32, device=gpu) for _ in nss]
+    st = N.lib().sa_query_ball_point_multi(
+        b, n, m, 3, (ctypes.c_float * 3)(0.0, 0.4, 0.8), (ctypes.c_float * 3)(*radii), (ctypes.c_int * 3)(*nss), 1,
+        t1.data_ptr(), t2.data_ptr(), (ctypes.c_void_p * 3)(*[t.data_ptr() for t in idx]),
+        (ctypes.c_void_p * 3)(*[t.data_ptr() for t in cnt]), N.current_stream())
+    assert st == 0
+    for i in range(3):
+        ridx, rcnt = oracle.query_ball_point_dilated(0.0 if i == 0 else radii[i - 1], radii[i], nss[i], xyz1, xyz2)
+        _check_ball(idx[i].cpu().numpy(), cnt[i].cpu().numpy(), ridx, rcnt)
+
+
+# ----------------------------------------------------------------------------------- sqdist
+@pytest.mark.parametrize("n,m,c", [(5, 7, 3), (64, 64, 67), (300, 200, 131), (512, 512, 16)])
+def test_calc_square_dist_bit_exact(gpu, oracle, n, m, c):
+    M = pkg("utils.model_util")
+    rng = np.random.default_rng(n + c)
+    a = rng.normal(0, 2, (2, n, c)).astype(np.float32)
+    bb = rng.normal(0, 2, (2, m, c)).astype(np.float32)
+    got = M.calc_square_dist(_t(a, gpu), _t(bb, gpu)).cpu().numpy()
+    assert np.array_equal(got, oracle.calc_square_dist(a, bb))
+
+
+# ----------------------------------------------------------------------------------- fused MLP
+def _rand_layers(rng, dims):
+    ws = [rng.normal(0, 1.0 / np.sqrt(dims[i]), (dims[i], dims[i + 1])).astype(np.float32) for i in range(len(dims) - 1)]
+    bs = [rng.normal(0, 0.1, dims[i + 1]).astype(np.float32) for i in range(len(dims) - 1)]
+    return ws, bs
+
+
+def _run_group_mlp(gpu, xyz, feat, new_xyz, idx, cnt, ws, bs):
+    import ctypes
+    N = pkg("utils._native")
+    Wt = pkg("utils.weights")
+    b, n, _ = xyz.shape
+    _, m, ns = idx.shape
+    c = 0 if feat is None else feat.shape[2]
+    layers = [Wt.PackedLayer(w, bb, gpu) for w, bb in zip(ws, bs)]
+    nl = len(layers)
+    out = torch.full((b, m, layers[-1].N + 5), -7.0, dtype=torch.float32, device=gpu)   # strided output
+    dims = (ctypes.c_int * (nl + 1))(*([c + 3] + [l.N for l in layers]))
+    tx, tn, ti, tc = _t(xyz, gpu), _t(new_xyz, gpu), _t(idx, gpu), _t(cnt, gpu)
+    tf = _t(feat, gpu) if feat is not None else None
+    st = N.lib().sa_group_mlp_max(b, n, m, ns, c, tx.data_ptr(), tf.data_ptr() if tf is not None else None,
+                                  tn.data_ptr(), ti.data_ptr(), tc.data_ptr(), nl, dims,
+                                  (ctypes.c_void_p * nl)(*[l.w.data_ptr() for l in layers]),
+                                  (ctypes.c_void_p * nl)(*[l.bias.data_ptr() for l in layers]),
+                                  out.data_ptr(), layers[-1].N + 5, 2, N.current_stream())
+    assert st == 0
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    assert (o[:, :, :2] == -7.0).all() and (o[:, :, 2 + layers[-1].N:] == -7.0).all()   # untouched margins
+    return o[:, :, 2:2 + layers[-1].N]
+
+
+@pytest.mark.parametrize("c,ns,dims", [(1, 32, [16, 16, 32]), (1, 64, [32, 32, 64]), (64, 32, [64, 64, 128]),
+                                       (64, 64, [64, 96, 128]), (128, 32, [128, 192, 256]),
+                                       (256, 16, [256, 256, 512]), (256, 32, [256, 512, 1024]),
+                                       (5, 8, [24]), (3, 20, [40, 72]), (0, 48, [16, 32, 48])])
+def test_group_mlp_max(gpu, oracle, c, ns, dims):
+    rng = np.random.default_rng(c * 100 + ns)
+    b, n, m = 2, 600, 45
+    xyz = _cloud(rng, b, n, scale=4.0)
+    feat = rng.normal(0, 1, (b, n, c)).astype(np.float32) if c > 0 else None
+    new_xyz = xyz[:, :m] + rng.normal(0, 0.1, (b, m, 3)).astype(np.float32)
+    idx = rng.integers(0, n, (b, m, ns)).astype(np.int32)
+    cnt = rng.integers(0, ns + 1, (b, m)).astype(np.int32)
+    cnt[:, ::7] = 0                                           # empty balls -> zero output
+    ws, bs = _rand_layers(rng, [c + 3] + dims)
+    got = _run_group_mlp(gpu, xyz, feat, new_xyz, idx, cnt, ws, bs)
+    ref = oracle.group_mlp_max(xyz, feat, new_xyz, idx, cnt, ws, bs)
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    assert err < MLP_TOL, "relative error %g" % err
+    assert (got[cnt == 0] == 0).all()
+
+
+def test_group_mlp_max_identity_layout_probe(gpu):
+    # asymmetric probe of the MFMA operand/accumulator mapping: one layer whose weight matrix selects
+    # and scales single input channels, so any row/column/transposition mix-up shows up exactly
+    rng = np.random.default_rng(3)
+    b, n, m, ns, c = 1, 64, 4, 32, 13
+    xyz = np.zeros((b, n, 3), np.float32)
+    feat = rng.integers(1, 50, (b, n, c)).astype(np.float32)
+    new_xyz = np.zeros((b, m, 3), np.float32)
+    idx = rng.integers(0, n, (b, m, ns)).astype(np.int32)
+    cnt = np.full((b, m), ns, np.int32)
+    W = np.zeros((c + 3, 40), np.float32)
+    for o in range(40):
+        W[(o * 5 + 2) % c, o] = float(o + 1)
+    got = _run_group_mlp(gpu, xyz, feat, new_xyz, idx, cnt, [W], [np.zeros(40, np.float32)])
+    g = np.take_along_axis(feat[:, None].repeat(m, 1), idx[..., None].repeat(c, -1), 2)   # [b,m,ns,c]
+    ref = np.stack([g[..., (o * 5 + 2) % c].max(-1) * (o + 1) for o in range(40)], -1)
+    assert np.array_equal(got, ref)        # small integers: exact in split-bf16
+
+
+@pytest.mark.parametrize("rows,K,N,relu", [(100, 128, 64, True), (77, 384, 128, True), (300, 1536, 512, True),
+                                           (64, 256, 128, True), (50, 128, 3, False), (33, 7, 5, False)])
+def test_dense(gpu, oracle, rows, K, N, relu):
+    N_ = pkg("utils._native")
+    Wt = pkg("utils.weights")
+    rng = np.random.default_rng(K + N)
+    x = rng.normal(0, 1, (rows, K)).astype(np.float32)
+    w = rng.normal(0, 1 / np.sqrt(K), (K, N)).astype(np.float32)
+    bias = rng.normal(0, 0.2, N).astype(np.float32)
+    L = Wt.PackedLayer(w, bias, gpu)
+    tx = _t(x, gpu)
+    y = torch.empty((rows, N), dtype=torch.float32, device=gpu)
+    st = N_.lib().sa_dense(rows, K, N, tx.data_ptr(), L.w.data_ptr(), L.bias.data_ptr(), int(relu), y.data_ptr(),
+                           N_.current_stream())
+    assert st == 0
+    ref = oracle.dense(x, w, bias, relu)
+    err = np.abs(y.cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert err < MLP_TOL, "relative error %g" % err
+
+
+# ----------------------------------------------------------------------------------- API behaviour
+def test_argument_errors_match_reference_conditions(gpu):
+    S = pkg("utils.tf_ops.sampling.tf_sampling")
+    G = pkg("utils.tf_ops.grouping.tf_grouping")
+    x = torch.zeros((1, 8, 3), device=gpu)
+    with pytest.raises(ValueError, match="positive npoint"):
+        S.farthest_point_sample(0, x)
+    with pytest.raises(ValueError, match="inp shape"):
+        S.farthest_point_sample(2, x[0])
+    with pytest.raises(ValueError, match="num_points,num_points"):
+        S.farthest_point_sample_with_distance(2, torch.zeros((1, 4, 5), device=gpu))
+    with pytest.raises(ValueError, match="positive radius"):
+        G.query_ball_point(0.0, 4, x, x)
+    with pytest.raises(ValueError, match="positive nsample"):
+        G.query_ball_point(1.0, 0, x, x)
+    with pytest.raises(ValueError, match="xyz1 shape"):
+        G.query_ball_point(1.0, 4, torch.zeros((1, 8, 4), device=gpu), x)
+    with pytest.raises(ValueError, match="min_radius"):
+        G.query_ball_point_dilated(-1.0, 1.0, 4, x, x)
+    with pytest.raises(ValueError, match="idx shape"):
+        G.group_point(x, torch.zeros((2, 3, 4), dtype=torch.int32, device=gpu))
