@@ -39,7 +39,6 @@ struct Bands {
 __global__ __launch_bounds__(kWavesPerWG * 64) void ball_query_kernel(
     int n, int m, const float *__restrict__ xyz1, const float *__restrict__ xyz2, Bands B) {
     __shared__ int s_rows[kWavesPerWG][kQW][kMaxBands][kRow];
-    __shared__ int s_cnt[kWavesPerWG][kQW][kMaxBands];
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int q0 = (blockIdx.x * kWavesPerWG + w) * kQW;   // first query of this wave
@@ -51,7 +50,8 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void ball_query_kernel(
     // lane q < nq holds centre q
     float cx = 0.f, cy = 0.f, cz = 0.f;
     if (lane < nq) { cx = C[lane * 3 + 0]; cy = C[lane * 3 + 1]; cz = C[lane * 3 + 2]; }
-    if (lane < kQW * kMaxBands) (&s_cnt[w][0][0])[lane] = 0;
+    int cntv = 0;   // lane q*kMaxBands+i holds the hit count of (query q, band i): read/written with
+                    // v_readlane / a lane select, no LDS round trip on the scan path
     unsigned active = (1u << nq) - 1u;                     // queries with at least one band not full
 
     for (int base = 0; base < n && active != 0u; base += 64 * kCH) {
@@ -67,29 +67,38 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void ball_query_kernel(
             const float x2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cx), q));
             const float y2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cy), q));
             const float z2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cz), q));
+            // distances of this query to the whole register chunk; one wave-wide test decides whether any
+            // of the 512 points can be a hit at all (d2 == 0 < thi_max is covered by the same test)
+            float d2[kCH];
+            float dmin = 3.0e38f;
+#pragma unroll
+            for (int s = 0; s < kCH; ++s) {
+                const float dx = x2 - x1[s], dy = y2 - y1[s], dz = z2 - z1[s];
+                d2[s] = __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));
+                dmin = sa::fmin_nn(dmin, d2[s]);
+            }
+            if (__ballot(dmin < B.thi_max) == 0ull) continue;
 #pragma unroll
             for (int s = 0; s < kCH; ++s) {
                 const int k = base + s * 64 + lane;
-                const float dx = x2 - x1[s], dy = y2 - y1[s], dz = z2 - z1[s];
-                const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));
                 const bool valid = k < n;
-                const bool near = valid && (d2 < B.thi_max || (B.dilated && d2 == 0.0f));
+                const bool near = valid && (d2[s] < B.thi_max);
                 if (__ballot(near) == 0ull) continue;
                 bool all_full = true;
 #pragma unroll
                 for (int i = 0; i < kMaxBands; ++i) {
                     if (i >= B.nbands) break;
-                    int c = __builtin_amdgcn_readfirstlane(s_cnt[w][q][i]);
+                    int c = __builtin_amdgcn_readlane(cntv, q * kMaxBands + i);
                     const int nsi = B.ns[i];
                     if (c >= nsi) continue;
-                    bool hit = valid && (B.dilated ? (d2 == 0.0f || (d2 >= B.tlo[i] && d2 < B.thi[i]))
-                                                   : (d2 < B.thi[i]));
+                    bool hit = valid && (B.dilated ? (d2[s] == 0.0f || (d2[s] >= B.tlo[i] && d2[s] < B.thi[i]))
+                                                   : (d2[s] < B.thi[i]));
                     unsigned long long hm = __ballot(hit);
                     if (hm != 0ull) {
                         int pos = c + __popcll(hm & ((1ull << lane) - 1ull));
                         if (hit && pos < nsi) s_rows[w][q][i][pos] = k;
                         c = min(nsi, c + (int)__popcll(hm));
-                        if (lane == 0) s_cnt[w][q][i] = c;
+                        cntv = (lane == q * kMaxBands + i) ? c : cntv;
                     }
                     all_full = all_full && (c >= nsi);
                 }
@@ -103,7 +112,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void ball_query_kernel(
 #pragma unroll
         for (int i = 0; i < kMaxBands; ++i) {
             if (i >= B.nbands) break;
-            const int c = __builtin_amdgcn_readfirstlane(s_cnt[w][q][i]);
+            const int c = __builtin_amdgcn_readlane(cntv, q * kMaxBands + i);
             const int nsi = B.ns[i];
             const size_t qi = (size_t)b * m + q0 + q;
             if (lane < nsi) {

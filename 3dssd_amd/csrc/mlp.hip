@@ -26,6 +26,8 @@
 // Weights are pre-packed on the host in fragment order: uint4 index ((ct*KS + ks)*2 + plane)*64 + lane
 // holds W[k = 16*ks + 8*(lane>>5) + e][cout = 32*ct + (lane&31)], so every weight load is one
 // contiguous 1 KiB wave access (they stream from L2; they are never staged through LDS).
+#include <stdlib.h>
+
 #include "sa_common.h"
 
 namespace {
@@ -73,13 +75,84 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4 &hi, uint4 &lo
     lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
 }
 
+
+// acc[tt] += sum_ks (hi*hi + lo*hi + hi*lo) for the TG output tiles starting at gb.  WFIRST: weights are the
+// MFMA A operand (D^T form) else the activations are (D form).  Weight fragments (global, L2-resident) and
+// activation fragments (LDS) of k-step ks+1 are requested before the MFMAs of k-step ks are issued, so the
+// matrix pipe works under the load latency instead of behind it.
+#ifndef SA_MLP_PREFETCH
+#define SA_MLP_PREFETCH 1
+#endif
+template <int TG, bool WFIRST>
+__device__ __forceinline__ void mma_k_loop(f32x16 (&acc)[TG], const unsigned char *arow, const LayerDesc &L,
+                                           int gb, int lane) {
+    const uint4 *wbase[TG];
+#pragma unroll
+    for (int tt = 0; tt < TG; ++tt)
+        wbase[tt] = L.w + ((size_t)(min(gb + tt, L.NT - 1) * L.KS) * 2) * 64 + lane;
+#if SA_MLP_PREFETCH
+    uint4 wh[TG], wl[TG];
+#pragma unroll
+    for (int tt = 0; tt < TG; ++tt) { wh[tt] = wbase[tt][0]; wl[tt] = wbase[tt][64]; }
+    uint4 ah = *(const uint4 *)(arow), al = *(const uint4 *)(arow + 16);
+    for (int ks = 0; ks < L.KS; ++ks) {
+        uint4 nwh[TG], nwl[TG], nah = ah, nal = al;
+        const int kn = ks + 1 < L.KS ? ks + 1 : ks;
+#pragma unroll
+        for (int tt = 0; tt < TG; ++tt) { nwh[tt] = wbase[tt][kn * 128]; nwl[tt] = wbase[tt][kn * 128 + 64]; }
+        nah = *(const uint4 *)(arow + kn * 64);
+        nal = *(const uint4 *)(arow + kn * 64 + 16);
+#pragma unroll
+        for (int tt = 0; tt < TG; ++tt) {
+            if (gb + tt < L.NT) {
+                if (WFIRST) {
+                    acc[tt] = mfma_bf16(wh[tt], ah, acc[tt]);
+                    acc[tt] = mfma_bf16(wl[tt], ah, acc[tt]);
+                    acc[tt] = mfma_bf16(wh[tt], al, acc[tt]);
+                } else {
+                    acc[tt] = mfma_bf16(ah, wh[tt], acc[tt]);
+                    acc[tt] = mfma_bf16(ah, wl[tt], acc[tt]);
+                    acc[tt] = mfma_bf16(al, wh[tt], acc[tt]);
+                }
+            }
+        }
+#pragma unroll
+        for (int tt = 0; tt < TG; ++tt) { wh[tt] = nwh[tt]; wl[tt] = nwl[tt]; }
+        ah = nah; al = nal;
+    }
+#else
+#ifdef SA_MLP_KUNROLL
+#pragma unroll SA_MLP_KUNROLL
+#endif
+    for (int ks = 0; ks < L.KS; ++ks) {
+        const uint4 ah = *(const uint4 *)(arow + ks * 64);
+        const uint4 al = *(const uint4 *)(arow + ks * 64 + 16);
+#pragma unroll
+        for (int tt = 0; tt < TG; ++tt) {
+            if (gb + tt < L.NT) {
+                const uint4 wh = wbase[tt][ks * 128], wl = wbase[tt][ks * 128 + 64];
+                if (WFIRST) {
+                    acc[tt] = mfma_bf16(wh, ah, acc[tt]);
+                    acc[tt] = mfma_bf16(wl, ah, acc[tt]);
+                    acc[tt] = mfma_bf16(wh, al, acc[tt]);
+                } else {
+                    acc[tt] = mfma_bf16(ah, wh, acc[tt]);
+                    acc[tt] = mfma_bf16(ah, wl, acc[tt]);
+                    acc[tt] = mfma_bf16(al, wh, acc[tt]);
+                }
+            }
+        }
+    }
+#endif
+}
+
 // ---- hidden layer, D^T form: out[row][cout] = relu(bias + sum_k W[k][cout] * in[row][k]) ----------
-template <int TG>
+template <int TG, int NW>
 __device__ __forceinline__ void layer_hidden(const unsigned char *in, int strideIn, unsigned char *outb,
                                              int strideOut, const LayerDesc &L, int lane, int w) {
     const int half = lane >> 5, col = lane & 31;
     const unsigned char *arow = in + col * strideIn + half * 32;
-    for (int gb = w * TG; gb < L.NT; gb += kNW * TG) {
+    for (int gb = w * TG; gb < L.NT; gb += NW * TG) {
         f32x16 acc[TG];
 #pragma unroll
         for (int tt = 0; tt < TG; ++tt) {
@@ -91,20 +164,7 @@ __device__ __forceinline__ void layer_hidden(const unsigned char *in, int stride
                 acc[tt][4 * q + 2] = bv.z; acc[tt][4 * q + 3] = bv.w;
             }
         }
-        for (int ks = 0; ks < L.KS; ++ks) {
-            const uint4 ah = *(const uint4 *)(arow + ks * 64);
-            const uint4 al = *(const uint4 *)(arow + ks * 64 + 16);
-#pragma unroll
-            for (int tt = 0; tt < TG; ++tt) {
-                if (gb + tt < L.NT) {
-                    const uint4 *wp = L.w + ((size_t)((gb + tt) * L.KS + ks) * 2) * 64 + lane;
-                    const uint4 wh = wp[0], wl = wp[64];
-                    acc[tt] = mfma_bf16(wh, ah, acc[tt]);
-                    acc[tt] = mfma_bf16(wl, ah, acc[tt]);
-                    acc[tt] = mfma_bf16(wh, al, acc[tt]);
-                }
-            }
-        }
+        mma_k_loop<TG, true>(acc, arow, L, gb, lane);
 #pragma unroll
         for (int tt = 0; tt < TG; ++tt) {
             if (gb + tt < L.NT) {
@@ -127,32 +187,19 @@ __device__ __forceinline__ void layer_hidden(const unsigned char *in, int stride
 }
 
 // ---- last layer, D form + max over the rows of each ball; bias/ReLU/mask are applied at write-out ---
-template <int TG>
+template <int TG, int NW>
 __device__ __forceinline__ void layer_last(const unsigned char *in, int strideIn, const LayerDesc &L,
                                            float *pooled, int pooled_ld, bool first, int rp, int lane,
                                            int w) {
     const int half = lane >> 5, col = lane & 31;
     const unsigned char *arow = in + col * strideIn + half * 32;
-    for (int gb = w * TG; gb < L.NT; gb += kNW * TG) {
+    for (int gb = w * TG; gb < L.NT; gb += NW * TG) {
         f32x16 acc[TG];
 #pragma unroll
         for (int tt = 0; tt < TG; ++tt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tt][r] = 0.0f;
-        for (int ks = 0; ks < L.KS; ++ks) {
-            const uint4 ah = *(const uint4 *)(arow + ks * 64);
-            const uint4 al = *(const uint4 *)(arow + ks * 64 + 16);
-#pragma unroll
-            for (int tt = 0; tt < TG; ++tt) {
-                if (gb + tt < L.NT) {
-                    const uint4 *wp = L.w + ((size_t)((gb + tt) * L.KS + ks) * 2) * 64 + lane;
-                    const uint4 wh = wp[0], wl = wp[64];
-                    acc[tt] = mfma_bf16(ah, wh, acc[tt]);
-                    acc[tt] = mfma_bf16(ah, wl, acc[tt]);
-                    acc[tt] = mfma_bf16(al, wh, acc[tt]);
-                }
-            }
-        }
+        mma_k_loop<TG, false>(acc, arow, L, gb, lane);
 #pragma unroll
         for (int tt = 0; tt < TG; ++tt) {
             if (gb + tt < L.NT) {
@@ -187,9 +234,26 @@ __device__ __forceinline__ void layer_last(const unsigned char *in, int strideIn
     }
 }
 
-__device__ __forceinline__ int pick_tg(int NT) { return NT >= 4 * kNW ? 4 : (NT >= 2 * kNW ? 2 : 1); }
+#ifndef SA_MLP_MAXTG
+#define SA_MLP_MAXTG 2
+#endif
+#ifndef SA_MLP_WPE8
+#define SA_MLP_WPE8 4      // min waves per SIMD the 8-wave kernel is compiled for (4 -> 128 VGPRs, 2 -> 256)
+#endif
+template <int NW>
+__device__ __forceinline__ int pick_tg(int NT) {
+    // the one-wave kernel keeps TG <= 2 under register prefetch (4 tiles x double-buffered fragments spill)
+    constexpr int cap = (NW == 1 && SA_MLP_PREFETCH) ? 2 : SA_MLP_MAXTG;
+    return (cap >= 4 && NT >= 4 * NW) ? 4 : (NT >= 2 * NW ? 2 : 1);
+}
 
-__global__ __launch_bounds__(kThreads, 4) void group_mlp_max_kernel(MlpParams P) {
+// NW = waves cooperating on one 32-row item.  NW = 8: the wide layers (weights split across waves,
+// one 512-thread workgroup per item).  NW = 1: narrow layers (layer1/layer2 of 3dssd.yaml) where one
+// wave runs the whole stack on its own item -- no cross-wave barrier, 8x more items in flight per CU to
+// hide the idx -> point gather latency.
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? SA_MLP_WPE8 : 4) void group_mlp_max_kernel(MlpParams P) {
+    constexpr int kThr = NW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *bufA = smem;
     unsigned char *bufB = smem + kRows * P.strideA;
@@ -208,14 +272,15 @@ __global__ __launch_bounds__(kThreads, 4) void group_mlp_max_kernel(MlpParams P)
         for (int ch = 0; ch < chunks; ++ch) {
             // ---- gather the [32 rows x cin] input tile (features first, then relative xyz:
             //      layers_util.py:160-165) into bufA as hi/lo bf16
-            for (int it = tid; it < kRows * G0; it += kThreads) {
+            for (int it = tid; it < kRows * G0; it += kThr) {
                 const int row = it / G0, g = it - row * G0;
                 int bl, s;
                 if (P.rp <= 32) { bl = row / P.rp; s = row - bl * P.rp; } else { bl = 0; s = ch * 32 + row; }
                 long ball = ball0 + bl;
                 if (ball >= P.nballs) ball = P.nballs - 1;
                 if (s >= P.ns) s = 0;                               // padded rows repeat sample 0
-                const int a = P.cnt[ball] > 0 ? P.idx[ball * P.ns + s] : 0;   // layers_util.py:157-159
+                const int a_raw = P.idx[ball * P.ns + s];               // both loads issue together
+                const int a = P.cnt[ball] > 0 ? a_raw : 0;              // layers_util.py:157-159
                 const long bi = ball / P.m;
                 const long pt = bi * P.n + a;
                 float v[8];
@@ -247,10 +312,12 @@ __global__ __launch_bounds__(kThreads, 4) void group_mlp_max_kernel(MlpParams P)
                 const unsigned char *in = (l & 1) ? bufB : bufA;
                 unsigned char *ob = (l & 1) ? bufA : bufB;
                 const int si = (l & 1) ? P.strideB : P.strideA, so = (l & 1) ? P.strideA : P.strideB;
-                switch (pick_tg(P.L[l].NT)) {
-                    case 4: layer_hidden<4>(in, si, ob, so, P.L[l], lane, w); break;
-                    case 2: layer_hidden<2>(in, si, ob, so, P.L[l], lane, w); break;
-                    default: layer_hidden<1>(in, si, ob, so, P.L[l], lane, w); break;
+                switch (pick_tg<NW>(P.L[l].NT)) {
+#if SA_MLP_MAXTG >= 4
+                    case 4: layer_hidden<4, NW>(in, si, ob, so, P.L[l], lane, w); break;
+#endif
+                    case 2: layer_hidden<2, NW>(in, si, ob, so, P.L[l], lane, w); break;
+                    default: layer_hidden<1, NW>(in, si, ob, so, P.L[l], lane, w); break;
                 }
                 __syncthreads();
             }
@@ -259,16 +326,18 @@ __global__ __launch_bounds__(kThreads, 4) void group_mlp_max_kernel(MlpParams P)
                 const int l = P.nl - 1;
                 const unsigned char *in = (l & 1) ? bufB : bufA;
                 const int si = (l & 1) ? P.strideB : P.strideA;
-                switch (pick_tg(LL.NT)) {
-                    case 4: layer_last<4>(in, si, LL, pooled, N3p, ch == 0, P.rp, lane, w); break;
-                    case 2: layer_last<2>(in, si, LL, pooled, N3p, ch == 0, P.rp, lane, w); break;
-                    default: layer_last<1>(in, si, LL, pooled, N3p, ch == 0, P.rp, lane, w); break;
+                switch (pick_tg<NW>(LL.NT)) {
+#if SA_MLP_MAXTG >= 4
+                    case 4: layer_last<4, NW>(in, si, LL, pooled, N3p, ch == 0, P.rp, lane, w); break;
+#endif
+                    case 2: layer_last<2, NW>(in, si, LL, pooled, N3p, ch == 0, P.rp, lane, w); break;
+                    default: layer_last<1, NW>(in, si, LL, pooled, N3p, ch == 0, P.rp, lane, w); break;
                 }
             }
             __syncthreads();
         }
         // ---- write out: relu(max + bias), zero for empty balls (layers_util.py:178-181)
-        for (int e = tid; e < bpi * LL.N; e += kThreads) {
+        for (int e = tid; e < bpi * LL.N; e += kThr) {
             const int g = e / LL.N, c = e - g * LL.N;
             const long ball = ball0 + g;
             if (ball < P.nballs) {
@@ -292,16 +361,23 @@ struct DenseParams {
     LayerDesc L;
     int stride;   // LDS row stride in bytes for a KC-wide chunk
     int KC;       // channels staged per chunk (multiple of 16)
+    int tg;       // output tiles per wave (1, 2 or 4)
 };
 
+constexpr int kDW = 4;               // waves per dense workgroup
+constexpr int kDThreads = kDW * 64;
+
+// One workgroup: 32 rows x (kDW*TG output tiles starting at tile blockIdx.y*kDW*TG).  Splitting the output
+// channels over blockIdx.y keeps >= 256 workgroups in flight for the short, wide aggregation layers
+// (2048 rows x 1536 -> 512 is only 64 row tiles).
 template <int TG>
 __device__ __forceinline__ void dense_body(const DenseParams &P, unsigned char *buf, int lane, int w,
                                            int tid) {
     const int half = lane >> 5, col = lane & 31;
     const LayerDesc &L = P.L;
     const int Kp = L.KS * 16;
+    const int gb = (blockIdx.y * kDW + w) * TG;
     for (long r0 = (long)blockIdx.x * kRows; r0 < P.rows; r0 += (long)gridDim.x * kRows) {
-        const int gb = w * TG;
         f32x16 acc[TG];
 #pragma unroll
         for (int tt = 0; tt < TG; ++tt) {
@@ -316,7 +392,7 @@ __device__ __forceinline__ void dense_body(const DenseParams &P, unsigned char *
         for (int k0 = 0; k0 < Kp; k0 += P.KC) {
             const int kc = min(P.KC, Kp - k0);
             const int G = kc / 8;
-            for (int it = tid; it < kRows * G; it += kThreads) {
+            for (int it = tid; it < kRows * G; it += kDThreads) {
                 const int row = it / G, g = it - row * G;
                 long r = r0 + row;
                 if (r >= P.rows) r = P.rows - 1;
@@ -338,19 +414,21 @@ __device__ __forceinline__ void dense_body(const DenseParams &P, unsigned char *
                 *(uint4 *)(dst + 16) = lo;
             }
             __syncthreads();
-            const unsigned char *arow = buf + col * P.stride + half * 32;
-            const int ks0 = k0 / 16;
-            for (int ks = 0; ks < kc / 16; ++ks) {
-                const uint4 ah = *(const uint4 *)(arow + ks * 64);
-                const uint4 al = *(const uint4 *)(arow + ks * 64 + 16);
+            if (gb < L.NT) {
+                const unsigned char *arow = buf + col * P.stride + half * 32;
+                const int ks0 = k0 / 16;
+                for (int ks = 0; ks < kc / 16; ++ks) {
+                    const uint4 ah = *(const uint4 *)(arow + ks * 64);
+                    const uint4 al = *(const uint4 *)(arow + ks * 64 + 16);
 #pragma unroll
-                for (int tt = 0; tt < TG; ++tt) {
-                    if (gb + tt < L.NT) {
-                        const uint4 *wp = L.w + ((size_t)((gb + tt) * L.KS + ks0 + ks) * 2) * 64 + lane;
-                        const uint4 wh = wp[0], wl = wp[64];
-                        acc[tt] = mfma_bf16(wh, ah, acc[tt]);
-                        acc[tt] = mfma_bf16(wl, ah, acc[tt]);
-                        acc[tt] = mfma_bf16(wh, al, acc[tt]);
+                    for (int tt = 0; tt < TG; ++tt) {
+                        if (gb + tt < L.NT) {
+                            const uint4 *wp = L.w + ((size_t)((gb + tt) * L.KS + ks0 + ks) * 2) * 64 + lane;
+                            const uint4 wh = wp[0], wl = wp[64];
+                            acc[tt] = mfma_bf16(wh, ah, acc[tt]);
+                            acc[tt] = mfma_bf16(wl, ah, acc[tt]);
+                            acc[tt] = mfma_bf16(wh, al, acc[tt]);
+                        }
                     }
                 }
             }
@@ -385,12 +463,12 @@ __device__ __forceinline__ void dense_body(const DenseParams &P, unsigned char *
     }
 }
 
-__global__ __launch_bounds__(kThreads) void dense_kernel(DenseParams P) {
+// TG (tiles per wave) is chosen on the host and passed in P.tg
+__global__ __launch_bounds__(kDThreads) void dense_kernel(DenseParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int tpw = (P.L.NT + kNW - 1) / kNW;
-    if (tpw <= 1) dense_body<1>(P, smem, lane, w, tid);
-    else if (tpw <= 2) dense_body<2>(P, smem, lane, w, tid);
+    if (P.tg == 1) dense_body<1>(P, smem, lane, w, tid);
+    else if (P.tg == 2) dense_body<2>(P, smem, lane, w, tid);
     else dense_body<4>(P, smem, lane, w, tid);
 }
 
@@ -450,13 +528,22 @@ extern "C" int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float 
     const size_t lds = (size_t)P.pool_off + (size_t)bpi * P.L[nl - 1].NT * 32 * sizeof(float);
     if (lds > 160 * 1024) return SA_ERR_UNSUPPORTED;
     if (lds > 48 * 1024) {   // opt in to large dynamic LDS; a refusal surfaces at the launch check below
-        (void)hipFuncSetAttribute((const void *)group_mlp_max_kernel,
+        (void)hipFuncSetAttribute((const void *)group_mlp_max_kernel<kNW>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipGetLastError();
     }
     const long nitems = (P.nballs + bpi - 1) / bpi;
-    const int grid = (int)(nitems < 16384 ? nitems : 16384);
-    hipLaunchKernelGGL(group_mlp_max_kernel, dim3(grid), dim3(kThreads), lds, stream, P);
+    int max_nt = 0;
+    for (int l = 0; l < nl; ++l) if (P.L[l].NT > max_nt) max_nt = P.L[l].NT;
+    static const int narrow_nt = getenv("SA_MLP_NARROW_NT") ? atoi(getenv("SA_MLP_NARROW_NT")) : 4;  // tuning knob
+    const bool narrow = max_nt <= narrow_nt && lds <= 40 * 1024;   // default: <= 128 output channels everywhere
+    if (narrow) {
+        const int grid = (int)(nitems < 65536 ? nitems : 65536);
+        hipLaunchKernelGGL(group_mlp_max_kernel<1>, dim3(grid), dim3(64), lds, stream, P);
+    } else {
+        const int grid = (int)(nitems < 16384 ? nitems : 16384);
+        hipLaunchKernelGGL(group_mlp_max_kernel<kNW>, dim3(grid), dim3(kThreads), lds, stream, P);
+    }
     SA_CHECK_LAUNCH();
     return SA_OK;
 }
@@ -470,13 +557,16 @@ extern "C" int sa_dense(long rows, int K, int N, const float *x, const void *wpa
     P.L.w = (const uint4 *)wpack; P.L.bias = bias; P.L.K = K; P.L.N = N;
     P.L.KS = roundup(K, 16) / 16;
     P.L.NT = roundup(N, 32) / 32;
-    if (P.L.NT > 4 * kNW) return SA_ERR_UNSUPPORTED;       // N <= 1024
     P.KC = P.L.KS * 16 < 256 ? P.L.KS * 16 : 256;
     P.stride = P.KC * 4 + 16;
     const size_t lds = (size_t)kRows * P.stride;
     const long tiles = (rows + kRows - 1) / kRows;
-    const int grid = (int)(tiles < 8192 ? tiles : 8192);
-    hipLaunchKernelGGL(dense_kernel, dim3(grid), dim3(kThreads), lds, stream, P);
+    // tiles per wave: as few as keeps >= ~512 workgroups in flight, at most 4
+    P.tg = 4;
+    while (P.tg > 1 && tiles * ((P.L.NT + kDW * P.tg - 1) / (kDW * P.tg)) < 512) P.tg >>= 1;
+    const int ysplit = (P.L.NT + kDW * P.tg - 1) / (kDW * P.tg);
+    const int gx = (int)(tiles < 8192 ? tiles : 8192);
+    hipLaunchKernelGGL(dense_kernel, dim3(gx, ysplit), dim3(kDThreads), lds, stream, P);
     SA_CHECK_LAUNCH();
     return SA_OK;
 }

@@ -7,9 +7,14 @@
 // Row vectors may be given in two pieces [x0 | x1] (c0 + c1 channels) so that the SA layer's
 // concat([xyz, features]) (layers_util.py:94,102) never has to be materialised.
 //
-// v1: fp32 VALU, 64x64 output tile per 256-thread workgroup, 4x4 outputs per thread, operands
-// staged k-major through LDS.  Every output's chain runs over channels in ascending order, so the
-// result is bit-identical to the oracle.
+// Main kernel: fp32-input MFMA (v_mfma_f32_32x32x2_f32).  On gfx950 that instruction is bitwise a
+// k-ordered fp32 fmaf chain (one rounding per product, no wider accumulation; cdna_hip_programming.md
+// section 3), so the matrix-core result is bit-identical to the oracle's scalar chain while running
+// at the matrix pipe's fp32 rate.  128x128 output tile per 256-thread workgroup, 2x2 MFMA tiles per
+// wave, operands staged k-major through LDS.  A plain VALU kernel (64x64 tile, 4x4 outputs per thread)
+// is kept as the cross-check (SA_SQDIST_VALU=1); tests require the two to agree bit for bit.
+#include <stdlib.h>
+
 #include "sa_common.h"
 
 namespace {
@@ -87,6 +92,88 @@ __global__ __launch_bounds__(256) void sqdist_kernel(int n, int m, RowSrc A, Row
     }
 }
 
+// ---- fp32 MFMA kernel ---------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kMT = 128;   // tile edge
+constexpr int kMK = 16;    // channels per LDS stage
+constexpr int kMLd = 132;  // padded leading dimension
+
+__global__ __launch_bounds__(256) void sqdist_mfma_kernel(int n, int m, RowSrc A, RowSrc Bm,
+                                                          float *__restrict__ out) {
+    __shared__ float As[kMK][kMLd];
+    __shared__ float Bs[kMK][kMLd];
+    __shared__ float sA[kMT], sB[kMT];
+    const int b = blockIdx.z;
+    const int i0 = blockIdx.y * kMT, j0 = blockIdx.x * kMT;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    const int half = lane >> 5, col = lane & 31;
+    const int c = A.c0 + A.c1;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.0f;
+    float nrm = 0.0f;   // |a_i|^2 (threads 0..127) or |b_j|^2 (threads 128..255), channel-ascending chain
+
+    const int lrow = tid >> 1, lk = (tid & 1) * 8;
+    const long ga = (long)b * n + min(i0 + lrow, n - 1);
+    const long gb = (long)b * m + min(j0 + lrow, m - 1);
+    for (int k0 = 0; k0 < c; k0 += kMK) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            As[lk + e][lrow] = load_ch(A, ga, k0 + lk + e);    // channels >= c read as 0
+            Bs[lk + e][lrow] = load_ch(Bm, gb, k0 + lk + e);
+        }
+        __syncthreads();
+        const int kend = min(kMK, c - k0);
+        {
+            const float(*S)[kMLd] = tid < kMT ? As : Bs;
+            const int t = tid & (kMT - 1);
+            for (int kk = 0; kk < kend; ++kk) nrm = __builtin_fmaf(S[kk][t], S[kk][t], nrm);
+        }
+#pragma unroll
+        for (int ks = 0; ks < kMK / 2; ++ks) {
+            if (ks * 2 < kend) {
+                const int kk = ks * 2 + half;
+                float a[2], bb[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    a[t] = As[kk][wr * 64 + t * 32 + col];
+                    bb[t] = Bs[kk][wc * 64 + t * 32 + col];
+                }
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < 2; ++tj)
+                        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ti], bb[tj], acc[ti][tj], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < kMT) sA[tid] = nrm; else sB[tid - kMT] = nrm;
+    __syncthreads();
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            const int jl = wc * 64 + tj * 32 + col;
+            const int j = j0 + jl;
+            const float sb = sB[jl];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int il = wr * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int i = i0 + il;
+                if (i < n && j < m)
+                    out[((size_t)b * n + i) * m + j] = (sA[il] + sb) - 2.0f * acc[ti][tj][r];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // a = [a0 | a1] rows [b,n,c0+c1], bb = [b0 | b1] rows [b,m,c0+c1]; out [b,n,m].
@@ -96,8 +183,14 @@ extern "C" int sa_calc_square_dist_split(int b, int n, int m, int c0, int c1, co
     if (b <= 0 || n <= 0 || m <= 0 || c0 <= 0 || c1 < 0 || !a0 || !b0 || !out) return SA_ERR_INVALID;
     if (c1 > 0 && (!a1 || !b1)) return SA_ERR_INVALID;
     RowSrc A{a0, c0, a1, c1}, Bm{b0, c0, b1, c1};
-    dim3 grid((m + kT - 1) / kT, (n + kT - 1) / kT, b);
-    hipLaunchKernelGGL(sqdist_kernel, grid, dim3(256), 0, stream, n, m, A, Bm, out);
+    static const bool use_valu = getenv("SA_SQDIST_VALU") && atoi(getenv("SA_SQDIST_VALU")) != 0;
+    if (use_valu) {
+        dim3 grid((m + kT - 1) / kT, (n + kT - 1) / kT, b);
+        hipLaunchKernelGGL(sqdist_kernel, grid, dim3(256), 0, stream, n, m, A, Bm, out);
+    } else {
+        dim3 grid((m + kMT - 1) / kMT, (n + kMT - 1) / kMT, b);
+        hipLaunchKernelGGL(sqdist_mfma_kernel, grid, dim3(256), 0, stream, n, m, A, Bm, out);
+    }
     SA_CHECK_LAUNCH();
     return SA_OK;
 }

@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "lib3dssd_sa.so")
+# SA3D_LIB selects another build of the same library (kernel A/B experiments); default: the in-tree one
+LIB_PATH = os.environ.get("SA3D_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "lib3dssd_sa.so")
 
 _c_int, _c_long, _c_float, _vp = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p
 

@@ -72,6 +72,19 @@ def _ffps_into(npoint, tmp_xyz, tmp_points, out, col, idx_off):
     N.check(st, "farthest_point_sample_with_distance")
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(main):
+    """One helper stream per issuing stream: D-FPS runs there while the F-FPS chain (distance matrix +
+    FPS on it) runs on the issuing stream -- the two halves of 'FS' / of a two-range layer are
+    independent (layers_util.py:93-106)."""
+    key = (main.device, main.cuda_stream)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=main.device)
+    return _SIDE_STREAMS[key]
+
+
 def _dfps_into(npoint, tmp_xyz, out, col, idx_off):
     b, n, c = tmp_xyz.shape
     temp = torch.empty((b, n), dtype=torch.float32, device=tmp_xyz.device) if (c != 3 or n > 16384) else None
@@ -117,21 +130,41 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
     former_n = former_fps_idx.shape[1] if former_fps_idx is not None else 0
     fps_idx = torch.empty((bs, total + former_n), dtype=torch.int32, device=dev)
     col = 0
+    has_f = any(k in ("FS", "F-FPS") for k, _s, _e, _c in plan)
+    has_d = any(k in ("FS", "D-FPS") for k, _s, _e, _c in plan)
+    main = torch.cuda.current_stream()
+    side = _side_stream(main) if (has_f and has_d) else None
+    keep = []
     for kind, start, end, cnt in plan:
         if kind == "identity":
             fps_idx[:, col:col + cnt] = torch.arange(start, start + cnt, dtype=torch.int32, device=dev)[None]
         else:
             whole = (start == 0 and end == n_all)
             tmp_xyz = xyz if whole else xyz[:, start:end].contiguous()
+            keep.append(tmp_xyz)
+            d_col, d_n = None, 0
             if kind in ("FS", "F-FPS"):
                 tmp_points = points if whole else points[:, start:end].contiguous()
                 npt = cnt // 2 if kind == "FS" else cnt
                 _ffps_into(npt, tmp_xyz, tmp_points, fps_idx, col, start)   # F-FPS indices first
                 if kind == "FS":
-                    _dfps_into(npt, tmp_xyz, fps_idx, col + npt, start)
+                    d_col, d_n = col + npt, npt
             else:
-                _dfps_into(cnt, tmp_xyz, fps_idx, col, start)
+                d_col, d_n = col, cnt
+            if d_col is not None:
+                if side is not None:
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    side.wait_event(ev)
+                    with torch.cuda.stream(side):
+                        _dfps_into(d_n, tmp_xyz, fps_idx, d_col, start)
+                else:
+                    _dfps_into(d_n, tmp_xyz, fps_idx, d_col, start)
         col += cnt
+    if side is not None:
+        ev = torch.cuda.Event()
+        ev.record(side)
+        main.wait_event(ev)
     if former_fps_idx is not None:                                          # :112-113
         fps_idx[:, col:] = T.i32_cuda(former_fps_idx, "former_fps_idx")
 

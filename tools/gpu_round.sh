@@ -13,7 +13,7 @@ echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 
 echo "== pytest gpu"; timeout 1500 python -m pytest tests -m gpu -q --maxfail=200 -p no:cacheprovider -rf > $OUT/pytest_gpu.log 2>&1; tail -40 $OUT/pytest_gpu.log
 echo "== bench"; timeout 600 python bench.py --steps 24 --warmup 6 > $OUT/bench.json 2> $OUT/bench.err; tail -c 3000 $OUT/bench.json; tail -5 $OUT/bench.err
 echo "== bench 1 stream"; timeout 300 python bench.py --steps 8 --warmup 2 --streams 1 --no-cpu-baseline > $OUT/bench_s1.json 2> $OUT/bench_s1.err; tail -c 600 $OUT/bench_s1.json
-echo "== rocprof"; cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --streams 1 --no-cpu-baseline --profile-iters 1 > $GRAFT_REPO_ROOT/$OUT/rocprof.log 2>&1; cd $GRAFT_REPO_ROOT
+echo "== rocprof"; cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --streams 1 --no-cpu-baseline --profile-iters 1 > $GRAFT_REPO_ROOT/$OUT/rocprof.log 2>&1; cd $GRAFT_REPO_ROOT
 find $OUT/prof -name "*stats*" | head; for f in $(find $OUT/prof -name "*kernel_stats.csv" | head -1); do head -30 $f; done
 # keep only the summaries (traces can be large)
 find $OUT/prof -name "*kernel_trace.csv" -size +20M -delete
