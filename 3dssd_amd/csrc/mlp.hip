@@ -91,6 +91,8 @@ __device__ __forceinline__ void mma_k_loop(f32x16 (&acc)[TG], const unsigned cha
     for (int tt = 0; tt < TG; ++tt)
         wbase[tt] = L.w + ((size_t)(min(gb + tt, L.NT - 1) * L.KS) * 2) * 64 + lane;
 #if SA_MLP_PREFETCH
+    // one-k-step-ahead register prefetch.  (A deeper register ring was tried: hipcc either waits vmcnt(0)
+    // at every ring step or spills; the measured gain of distance 1 over none is 10-20%.)
     uint4 wh[TG], wl[TG];
 #pragma unroll
     for (int tt = 0; tt < TG; ++tt) { wh[tt] = wbase[tt][0]; wl[tt] = wbase[tt][64]; }
@@ -144,6 +146,34 @@ __device__ __forceinline__ void mma_k_loop(f32x16 (&acc)[TG], const unsigned cha
         }
     }
 #endif
+}
+
+
+// 8 consecutive channels [c0, c0+8) of the grouped row (features first, then xyz - centre, then zero
+// padding).  The mixed / unaligned case issues every load unconditionally at a clamped address and
+// selects afterwards: one round trip, no per-element branch + wait.
+__device__ __forceinline__ void gather8(const MlpParams &P, long pt, long ball, int c0, float (&v)[8]) {
+    if ((P.C & 3) == 0 && c0 + 8 <= P.C) {
+        const float4 f0 = *(const float4 *)(P.feat + pt * P.C + c0);
+        const float4 f1 = *(const float4 *)(P.feat + pt * P.C + c0 + 4);
+        v[0] = f0.x; v[1] = f0.y; v[2] = f0.z; v[3] = f0.w;
+        v[4] = f1.x; v[5] = f1.y; v[6] = f1.z; v[7] = f1.w;
+        return;
+    }
+    const float px = P.xyz[pt * 3 + 0] - P.new_xyz[ball * 3 + 0];
+    const float py = P.xyz[pt * 3 + 1] - P.new_xyz[ball * 3 + 1];
+    const float pz = P.xyz[pt * 3 + 2] - P.new_xyz[ball * 3 + 2];
+    float fv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = c0 + e;
+        fv[e] = P.C > 0 ? P.feat[pt * P.C + (c < P.C ? c : P.C - 1)] : 0.0f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int x = c0 + e - P.C;
+        v[e] = x < 0 ? fv[e] : (x == 0 ? px : (x == 1 ? py : (x == 2 ? pz : 0.0f)));
+    }
 }
 
 // ---- hidden layer, D^T form: out[row][cout] = relu(bias + sum_k W[k][cout] * in[row][k]) ----------
@@ -265,7 +295,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? SA_MLP_WPE8 : 4) void group_mlp_
     const LayerDesc &LL = P.L[P.nl - 1];
     const int N3p = LL.NT * 32;
     const int G0 = P.L[0].KS * 2;                     // 8-channel groups of the input tile
-    const int cin = P.C + 3;
 
     for (long item = blockIdx.x; item < nitems; item += gridDim.x) {
         const long ball0 = item * bpi;
@@ -284,22 +313,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? SA_MLP_WPE8 : 4) void group_mlp_
                 const long bi = ball / P.m;
                 const long pt = bi * P.n + a;
                 float v[8];
-                const int c0 = g * 8;
-                if ((P.C & 3) == 0 && c0 + 8 <= P.C) {
-                    const float4 f0 = *(const float4 *)(P.feat + pt * P.C + c0);
-                    const float4 f1 = *(const float4 *)(P.feat + pt * P.C + c0 + 4);
-                    v[0] = f0.x; v[1] = f0.y; v[2] = f0.z; v[3] = f0.w;
-                    v[4] = f1.x; v[5] = f1.y; v[6] = f1.z; v[7] = f1.w;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int c = c0 + e;
-                        float x = 0.0f;
-                        if (c < P.C) x = P.feat[pt * P.C + c];
-                        else if (c < cin) x = P.xyz[pt * 3 + (c - P.C)] - P.new_xyz[ball * 3 + (c - P.C)];
-                        v[e] = x;
-                    }
-                }
+                gather8(P, pt, ball, g * 8, v);
                 uint4 hi, lo;
                 split8(v, hi, lo);
                 unsigned char *dst = bufA + row * P.strideA + g * 32;
@@ -338,6 +352,309 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? SA_MLP_WPE8 : 4) void group_mlp_
         }
         // ---- write out: relu(max + bias), zero for empty balls (layers_util.py:178-181)
         for (int e = tid; e < bpi * LL.N; e += kThr) {
+            const int g = e / LL.N, c = e - g * LL.N;
+            const long ball = ball0 + g;
+            if (ball < P.nballs) {
+                float v = pooled[g * N3p + c] + LL.bias[c];
+                v = v > 0.0f ? v : 0.0f;
+                if (P.cnt[ball] <= 0) v = 0.0f;
+                P.out[ball * P.out_stride + P.out_off + c] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+
+// =====================================================================================================
+// Wide-layer kernel: 64 rows per item.  Every weight fragment fetched from L2 feeds TWO 32-row tiles
+// (6 MFMA passes per 2 KiB of weights instead of 3), which halves the L2 weight traffic that bounds the
+// 32-row kernel on the 256..1024-channel layers.  The last layer's accumulators (all of a wave's output
+// tiles x 2 row tiles) stay in registers while the last HIDDEN layer is produced in column chunks, so its
+// full-width output never has to sit in LDS (512 channels x 64 rows x hi/lo would not fit next to the
+// 256-channel buffer): chunk c of layer nl-2 is written, consumed as k-range c of layer nl-1, overwritten.
+// =====================================================================================================
+constexpr int kWRows = 64;
+
+struct WideParams {
+    MlpParams M;          // strideA/strideB/pool_off are for 64-row buffers here
+    int tiles_per_chunk;  // output tiles of the last hidden layer per chunk (all of them when nl == 1)
+    int nchunks;
+};
+
+// hidden layer (D^T form) for output tiles [tile_lo, tile_hi), written at column (tile - tile_lo) * 32
+template <int TG>
+__device__ __forceinline__ void wide_hidden(const unsigned char *in, int strideIn, unsigned char *outb,
+                                            int strideOut, const LayerDesc &L, int tile_lo, int tile_hi,
+                                            int lane, int w) {
+    const int half = lane >> 5, col = lane & 31;
+    const unsigned char *arow0 = in + col * strideIn + half * 32;
+    const unsigned char *arow1 = arow0 + 32 * strideIn;
+    for (int gb = tile_lo + w * TG; gb < tile_hi; gb += kNW * TG) {
+        f32x16 acc[TG][2];
+        const uint4 *wbase[TG];
+#pragma unroll
+        for (int tt = 0; tt < TG; ++tt) {
+            const int ct = min(gb + tt, tile_hi - 1);
+            wbase[tt] = L.w + ((size_t)(ct * L.KS) * 2) * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bv = *(const float4 *)(L.bias + ct * 32 + 8 * q + 4 * half);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[tt][j][4 * q + 0] = bv.x; acc[tt][j][4 * q + 1] = bv.y;
+                    acc[tt][j][4 * q + 2] = bv.z; acc[tt][j][4 * q + 3] = bv.w;
+                }
+            }
+        }
+        constexpr int D = TG == 2 ? 2 : 4;
+        uint4 wq[D][TG][2];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int kd = d < L.KS ? d : L.KS - 1;
+#pragma unroll
+            for (int tt = 0; tt < TG; ++tt) { wq[d][tt][0] = wbase[tt][kd * 128]; wq[d][tt][1] = wbase[tt][kd * 128 + 64]; }
+        }
+        uint4 ah0 = *(const uint4 *)(arow0), al0 = *(const uint4 *)(arow0 + 16);
+        uint4 ah1 = *(const uint4 *)(arow1), al1 = *(const uint4 *)(arow1 + 16);
+        for (int ks0 = 0; ks0 < L.KS; ks0 += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int ks = ks0 + d;
+                if (ks < L.KS) {
+                    uint4 wh[TG], wl[TG];
+#pragma unroll
+                    for (int tt = 0; tt < TG; ++tt) { wh[tt] = wq[d][tt][0]; wl[tt] = wq[d][tt][1]; }
+                    const int kw = ks + D < L.KS ? ks + D : L.KS - 1;
+#pragma unroll
+                    for (int tt = 0; tt < TG; ++tt) { wq[d][tt][0] = wbase[tt][kw * 128]; wq[d][tt][1] = wbase[tt][kw * 128 + 64]; }
+                    const int kn = ks + 1 < L.KS ? ks + 1 : ks;
+                    const uint4 nah0 = *(const uint4 *)(arow0 + kn * 64), nal0 = *(const uint4 *)(arow0 + kn * 64 + 16);
+                    const uint4 nah1 = *(const uint4 *)(arow1 + kn * 64), nal1 = *(const uint4 *)(arow1 + kn * 64 + 16);
+#pragma unroll
+                    for (int tt = 0; tt < TG; ++tt) {
+                        if (gb + tt < tile_hi) {
+                            acc[tt][0] = mfma_bf16(wh[tt], ah0, acc[tt][0]);
+                            acc[tt][1] = mfma_bf16(wh[tt], ah1, acc[tt][1]);
+                            acc[tt][0] = mfma_bf16(wl[tt], ah0, acc[tt][0]);
+                            acc[tt][1] = mfma_bf16(wl[tt], ah1, acc[tt][1]);
+                            acc[tt][0] = mfma_bf16(wh[tt], al0, acc[tt][0]);
+                            acc[tt][1] = mfma_bf16(wh[tt], al1, acc[tt][1]);
+                        }
+                    }
+                    ah0 = nah0; al0 = nal0; ah1 = nah1; al1 = nal1;
+                }
+            }
+        }
+#pragma unroll
+        for (int tt = 0; tt < TG; ++tt) {
+            if (gb + tt < tile_hi) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    unsigned char *orow = outb + (j * 32 + col) * strideOut + (gb + tt - tile_lo) * 128 + 8 * half;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        unsigned h[4], l[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = acc[tt][j][4 * q + e];
+                            v = v > 0.0f ? v : 0.0f;
+                            sa::bf16_split(v, h[e], l[e]);
+                        }
+                        *(uint2 *)(orow + q * 32) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                        *(uint2 *)(orow + q * 32 + 16) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+                    }
+                }
+            }
+        }
+    }
+}
+
+// last layer (D form), k-steps [ks_lo, ks_hi) of the input whose columns start at k-step ks_lo in `in`;
+// wave w owns output tiles w, w+8, ... (TGL of them), accumulators persist across calls
+template <int TGL>
+__device__ __forceinline__ void wide_last_partial(f32x16 (&acc)[TGL][2], const unsigned char *in, int strideIn,
+                                                  const LayerDesc &L, int ks_lo, int ks_hi, int lane, int w) {
+    const int half = lane >> 5, col = lane & 31;
+    const unsigned char *arow0 = in + col * strideIn + half * 32;
+    const unsigned char *arow1 = arow0 + 32 * strideIn;
+    const uint4 *wbase[TGL];
+#pragma unroll
+    for (int tt = 0; tt < TGL; ++tt)
+        wbase[tt] = L.w + ((size_t)(min(w + kNW * tt, L.NT - 1) * L.KS) * 2) * 64 + lane;
+    constexpr int D = TGL >= 4 ? 1 : (TGL == 2 ? 2 : 4);
+    uint4 wq[D][TGL][2];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const int kd = ks_lo + d < ks_hi ? ks_lo + d : ks_hi - 1;
+#pragma unroll
+        for (int tt = 0; tt < TGL; ++tt) { wq[d][tt][0] = wbase[tt][kd * 128]; wq[d][tt][1] = wbase[tt][kd * 128 + 64]; }
+    }
+    uint4 ah0 = *(const uint4 *)(arow0), al0 = *(const uint4 *)(arow0 + 16);
+    uint4 ah1 = *(const uint4 *)(arow1), al1 = *(const uint4 *)(arow1 + 16);
+    for (int ks0 = ks_lo; ks0 < ks_hi; ks0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int ks = ks0 + d;
+            if (ks < ks_hi) {
+                uint4 wh[TGL], wl[TGL];
+#pragma unroll
+                for (int tt = 0; tt < TGL; ++tt) { wh[tt] = wq[d][tt][0]; wl[tt] = wq[d][tt][1]; }
+                const int kw = ks + D < ks_hi ? ks + D : ks_hi - 1;
+#pragma unroll
+                for (int tt = 0; tt < TGL; ++tt) { wq[d][tt][0] = wbase[tt][kw * 128]; wq[d][tt][1] = wbase[tt][kw * 128 + 64]; }
+                const int kn = (ks + 1 < ks_hi ? ks + 1 : ks) - ks_lo;
+                const uint4 nah0 = *(const uint4 *)(arow0 + kn * 64), nal0 = *(const uint4 *)(arow0 + kn * 64 + 16);
+                const uint4 nah1 = *(const uint4 *)(arow1 + kn * 64), nal1 = *(const uint4 *)(arow1 + kn * 64 + 16);
+#pragma unroll
+                for (int tt = 0; tt < TGL; ++tt) {
+                    if (w + kNW * tt < L.NT) {
+                        acc[tt][0] = mfma_bf16(ah0, wh[tt], acc[tt][0]);
+                        acc[tt][1] = mfma_bf16(ah1, wh[tt], acc[tt][1]);
+                        acc[tt][0] = mfma_bf16(ah0, wl[tt], acc[tt][0]);
+                        acc[tt][1] = mfma_bf16(ah1, wl[tt], acc[tt][1]);
+                        acc[tt][0] = mfma_bf16(al0, wh[tt], acc[tt][0]);
+                        acc[tt][1] = mfma_bf16(al1, wh[tt], acc[tt][1]);
+                    }
+                }
+                ah0 = nah0; al0 = nal0; ah1 = nah1; al1 = nal1;
+            }
+        }
+    }
+}
+
+// max over the rows of each ball for one 32-row tile: bm[g], g < nb = 32/min(rp,32)
+__device__ __forceinline__ int tile_ball_max(const f32x16 &a, int rp, float (&bm)[4]) {
+    float qm[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float a0 = sa::fmax_nn(a[4 * q], a[4 * q + 1]);
+        float a1 = sa::fmax_nn(a[4 * q + 2], a[4 * q + 3]);
+        float x = sa::fmax_nn(a0, a1);
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+        qm[q] = sa::fmax_nn(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    if (rp == 8) { bm[0] = qm[0]; bm[1] = qm[1]; bm[2] = qm[2]; bm[3] = qm[3]; return 4; }
+    if (rp == 16) { bm[0] = sa::fmax_nn(qm[0], qm[1]); bm[1] = sa::fmax_nn(qm[2], qm[3]); bm[2] = bm[3] = 0.f; return 2; }
+    bm[0] = sa::fmax_nn(sa::fmax_nn(qm[0], qm[1]), sa::fmax_nn(qm[2], qm[3]));
+    bm[1] = bm[2] = bm[3] = 0.f;
+    return 1;
+}
+
+template <int TGL>
+__device__ __forceinline__ void wide_item_layers(const WideParams &WP, unsigned char *bufA, unsigned char *bufB,
+                                                 float *pooled, int N3p, bool first_pass, int lane, int w) {
+    const MlpParams &P = WP.M;
+    const int nl = P.nl;
+    const LayerDesc &LL = P.L[nl - 1];
+    // hidden layers that are stored whole
+    for (int l = 0; l + 2 < nl; ++l) {
+        const unsigned char *in = (l & 1) ? bufB : bufA;
+        unsigned char *ob = (l & 1) ? bufA : bufB;
+        const int si = (l & 1) ? P.strideB : P.strideA, so = (l & 1) ? P.strideA : P.strideB;
+        if (P.L[l].NT >= 2 * kNW) wide_hidden<2>(in, si, ob, so, P.L[l], 0, P.L[l].NT, lane, w);
+        else wide_hidden<1>(in, si, ob, so, P.L[l], 0, P.L[l].NT, lane, w);
+        __syncthreads();
+    }
+    f32x16 acc[TGL][2];
+#pragma unroll
+    for (int tt = 0; tt < TGL; ++tt)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tt][j][r] = 0.0f;
+    if (nl == 1) {
+        wide_last_partial<TGL>(acc, bufA, P.strideA, LL, 0, LL.KS, lane, w);
+    } else {
+        const int l = nl - 2;                         // last hidden layer, produced in column chunks
+        const unsigned char *in = (l & 1) ? bufB : bufA;
+        unsigned char *ob = (l & 1) ? bufA : bufB;
+        const int si = (l & 1) ? P.strideB : P.strideA, so = (l & 1) ? P.strideA : P.strideB;
+        for (int c = 0; c < WP.nchunks; ++c) {
+            const int t_lo = c * WP.tiles_per_chunk;
+            const int t_hi = min(P.L[l].NT, t_lo + WP.tiles_per_chunk);
+            if (c > 0) __syncthreads();               // previous chunk fully consumed before it is overwritten
+            // with 128 accumulator registers live (TGL == 4) only the one-tile form fits the register file
+            if (TGL < 4 && t_hi - t_lo >= 2 * kNW) wide_hidden<2>(in, si, ob, so, P.L[l], t_lo, t_hi, lane, w);
+            else wide_hidden<1>(in, si, ob, so, P.L[l], t_lo, t_hi, lane, w);
+            __syncthreads();
+            const int ks_lo = t_lo * 2, ks_hi = min(LL.KS, t_hi * 2);
+            if (ks_lo < ks_hi) wide_last_partial<TGL>(acc, ob, so, LL, ks_lo, ks_hi, lane, w);
+        }
+    }
+    // pooling: row tile j covers rows 32j..32j+31 of the item
+    const int col = lane & 31;
+#pragma unroll
+    for (int tt = 0; tt < TGL; ++tt) {
+        const int ct = w + kNW * tt;
+        if (ct < LL.NT) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float bm[4];
+                const int nb = tile_ball_max(acc[tt][j], P.rp, bm);
+                if (lane < 32) {
+                    // ball slot inside the item: rp <= 32 -> j*nb + g ; rp >= 64 -> 0 for both tiles
+                    const int base = P.rp <= 32 ? j * nb : 0;
+                    const bool fresh = first_pass && (P.rp <= 32 || j == 0);
+                    float *pp = pooled + ct * 32 + col;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        if (g < nb) {
+                            float v = bm[g];
+                            if (!fresh) v = sa::fmax_nn(v, pp[(base + g) * N3p]);
+                            pp[(base + g) * N3p] = v;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads, 2) void group_mlp_wide_kernel(WideParams WP) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const MlpParams &P = WP.M;
+    unsigned char *bufA = smem;
+    unsigned char *bufB = smem + kWRows * P.strideA;
+    float *pooled = (float *)(smem + P.pool_off);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int bpi = P.rp <= 64 ? 64 / P.rp : 1;        // balls per item
+    const int passes = P.rp <= 64 ? 1 : P.rp / 64;     // 64-row passes per item
+    const long nitems = (P.nballs + bpi - 1) / bpi;
+    const LayerDesc &LL = P.L[P.nl - 1];
+    const int N3p = LL.NT * 32;
+    const int G0 = P.L[0].KS * 2;
+    const int tgl = (LL.NT + kNW - 1) / kNW;
+
+    for (long item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const long ball0 = item * bpi;
+        for (int ps = 0; ps < passes; ++ps) {
+            for (int it = tid; it < kWRows * G0; it += kThreads) {
+                const int row = it / G0, g = it - row * G0;
+                int bl, s;
+                if (P.rp <= 64) { bl = row / P.rp; s = row - bl * P.rp; } else { bl = 0; s = ps * 64 + row; }
+                long ball = ball0 + bl;
+                if (ball >= P.nballs) ball = P.nballs - 1;
+                if (s >= P.ns) s = 0;
+                const int a_raw = P.idx[ball * P.ns + s];
+                const int a = P.cnt[ball] > 0 ? a_raw : 0;
+                const long bi = ball / P.m;
+                const long pt = bi * P.n + a;
+                float v[8];
+                gather8(P, pt, ball, g * 8, v);
+                uint4 hi, lo;
+                split8(v, hi, lo);
+                unsigned char *dst = bufA + row * P.strideA + g * 32;
+                *(uint4 *)dst = hi;
+                *(uint4 *)(dst + 16) = lo;
+            }
+            __syncthreads();
+            if (tgl <= 1) wide_item_layers<1>(WP, bufA, bufB, pooled, N3p, ps == 0, lane, w);
+            else if (tgl <= 2) wide_item_layers<2>(WP, bufA, bufB, pooled, N3p, ps == 0, lane, w);
+            else wide_item_layers<4>(WP, bufA, bufB, pooled, N3p, ps == 0, lane, w);
+            __syncthreads();
+        }
+        for (int e = tid; e < bpi * LL.N; e += kThreads) {
             const int g = e / LL.N, c = e - g * LL.N;
             const long ball = ball0 + g;
             if (ball < P.nballs) {
@@ -405,7 +722,10 @@ __device__ __forceinline__ void dense_body(const DenseParams &P, unsigned char *
                     v[4] = f1.x; v[5] = f1.y; v[6] = f1.z; v[7] = f1.w;
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (c0 + e < L.K) ? P.x[r * L.K + c0 + e] : 0.0f;
+                    for (int e = 0; e < 8; ++e) {
+                        const float x = P.x[r * L.K + (c0 + e < L.K ? c0 + e : L.K - 1)];
+                        v[e] = c0 + e < L.K ? x : 0.0f;
+                    }
                 }
                 uint4 hi, lo;
                 split8(v, hi, lo);
@@ -540,7 +860,44 @@ extern "C" int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float 
     if (narrow) {
         const int grid = (int)(nitems < 65536 ? nitems : 65536);
         hipLaunchKernelGGL(group_mlp_max_kernel<1>, dim3(grid), dim3(64), lds, stream, P);
-    } else {
+        SA_CHECK_LAUNCH();
+        return SA_OK;
+    }
+    // ---- wide path: 64-row items, last hidden layer chunked until the buffers fit
+    static const bool use_wide = getenv("SA_MLP_WIDE") && atoi(getenv("SA_MLP_WIDE")) != 0;   // experiment switch
+    if (use_wide && P.L[nl - 1].NT <= 4 * kNW) {
+        WideParams WP{};
+        WP.M = P;
+        WP.M.rp = ns <= 8 ? 8 : (ns <= 16 ? 16 : (ns <= 32 ? 32 : roundup(ns, 64)));
+        const int wbpi = WP.M.rp <= 64 ? 64 / WP.M.rp : 1;
+        const int nt_h = nl >= 2 ? P.L[nl - 2].NT : 0;            // tiles of the last hidden layer
+        for (int nch = 1; nch <= (nt_h > 0 ? nt_h : 1); nch *= 2) {
+            const int tpc = nt_h > 0 ? (nt_h + nch - 1) / nch : 0;
+            int wwA = roundup(dims[0], 16), wwB = 0;
+            for (int l = 0; l + 1 < nl; ++l) {                    // act_{l+1}: l even -> B, l odd -> A
+                const int wd = (l == nl - 2 ? tpc : P.L[l].NT) * 32;
+                if (l & 1) { if (wd > wwA) wwA = wd; } else { if (wd > wwB) wwB = wd; }
+            }
+            WP.M.strideA = wwA * 4 + 16;
+            WP.M.strideB = wwB * 4 + 16;
+            WP.M.pool_off = kWRows * (WP.M.strideA + WP.M.strideB);
+            const size_t wlds = (size_t)WP.M.pool_off + (size_t)wbpi * P.L[nl - 1].NT * 32 * sizeof(float);
+            if (wlds <= 156 * 1024) {
+                WP.tiles_per_chunk = tpc;
+                WP.nchunks = nt_h > 0 ? (nt_h + tpc - 1) / tpc : 1;
+                (void)hipFuncSetAttribute((const void *)group_mlp_wide_kernel,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);
+                (void)hipGetLastError();
+                const long witems = (WP.M.nballs + wbpi - 1) / wbpi;
+                const int grid = (int)(witems < 16384 ? witems : 16384);
+                hipLaunchKernelGGL(group_mlp_wide_kernel, dim3(grid), dim3(kThreads), wlds, stream, WP);
+                SA_CHECK_LAUNCH();
+                return SA_OK;
+            }
+            if (nt_h == 0) break;
+        }
+    }
+    {
         const int grid = (int)(nitems < 16384 ? nitems : 16384);
         hipLaunchKernelGGL(group_mlp_max_kernel<kNW>, dim3(grid), dim3(kThreads), lds, stream, P);
     }

@@ -1,0 +1,25 @@
+"""Summarise rocprofv3 output: per-kernel average duration (kernel trace) and per-kernel PMC sums."""
+import csv, glob, os, sys, collections
+root = sys.argv[1]
+def short(n):
+    for p in ("void (anonymous namespace)::", "(anonymous namespace)::", "void "):
+        n = n.replace(p, "")
+    n = n.split("(")[0]
+    return n[:70]
+for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    print("== kernel stats", os.path.relpath(f, root))
+    rows = list(csv.DictReader(open(f)))
+    for r in rows[:25]:
+        print("  %-70s calls %6s  avg %10.1f us  total %10.1f us  %5s%%" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e3, r["Percentage"]))
+for f in sorted(glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
+    print("== pmc", os.path.relpath(f, root))
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+    seen = set()
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        key = (k, r["Dispatch_Id"])
+        if key not in seen:
+            seen.add(key); cnt[k] += 1
+    for k in sorted(agg, key=lambda k: -cnt[k])[:40]:
+        print("  %-60s n=%4d " % (k, cnt[k]) + " ".join("%s=%.4g" % (c, v / cnt[k]) for c, v in sorted(agg[k].items())))
