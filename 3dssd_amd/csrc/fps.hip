@@ -12,6 +12,8 @@
 // the lowest lane wins, among equal workgroup maxima the lowest wave wins.
 // Distance arithmetic: d = fmaf(diff, diff, d) over channels ascending (nvcc -fmad=true form of
 // tf_sampling_g.cu:146-150); built with -ffp-contract=off so only the explicit fmaf fuses.
+#include <stdlib.h>
+
 #include "sa_common.h"
 
 namespace {
@@ -208,9 +210,19 @@ int ppt_for(int n) {
 
 // Internal launchers with an output row stride / index offset so that an SA layer can write the
 // F-FPS and D-FPS halves straight into one [b, npoint_total] index tensor (layers_util.py:96-108).
+extern "C" int sa_fps_bucket_ex(int b, int n, int m, const float *inp, int *out, int out_stride, int idx_off,
+                                hipStream_t stream);
+
 extern "C" int sa_fps_ex(int b, int n, int c, int m, const float *inp, float *temp, int *out,
                          int out_stride, int idx_off, hipStream_t stream) {
     if (b <= 0 || n <= 0 || c <= 0 || m <= 0 || !inp || !out || out_stride < m) return SA_ERR_INVALID;
+    // Experimental: the bucket-culled kernel (fps_bucket.hip), bit-identical output.  It skips ~99% of the
+    // distance evaluations but measured no faster than the plain kernel on MI355X (the iteration is bound by
+    // the serial reduce/exchange chain of the one wave that still has work, not by VALU throughput), so it
+    // is off by default.  SA_FPS_BUCKET_MIN_N = smallest n it is used for (0 = never).
+    static const int bucket_min_n = getenv("SA_FPS_BUCKET_MIN_N") ? atoi(getenv("SA_FPS_BUCKET_MIN_N")) : 0;
+    if (c == 3 && bucket_min_n > 0 && n >= bucket_min_n && n <= 16384 && m >= 64)
+        return sa_fps_bucket_ex(b, n, m, inp, out, out_stride, idx_off, stream);
     const int ppt = ppt_for(n);
     if (c == 3 && ppt <= 16) {
         switch (ppt) {

@@ -70,6 +70,10 @@ int sa_fps_ex(int b, int n, int c, int m, const float *inp, float *temp, int *ou
               int idx_off, sa_stream_t stream);
 int sa_fps_with_distance_ex(int b, int n, int m, const float *dist, float *temp, int *out,
                             int out_stride, int idx_off, sa_stream_t stream);
+/* D-FPS (c == 3, n <= 16384) with Morton-bucket culling: same output as sa_fps_ex, which dispatches to it
+ * for large frames (3dssd_amd/csrc/fps_bucket.hip). */
+int sa_fps_bucket_ex(int b, int n, int m, const float *inp, int *out, int out_stride, int idx_off,
+                     sa_stream_t stream);
 /* Forces the global-scratch kernels (mode 0: points [b,n,c], mode 1: matrix [b,n,n]); test hook. */
 int sa_fps_generic(int b, int n, int c, int m, const float *inp, float *temp, int *out, int mode,
                    sa_stream_t stream);

@@ -311,3 +311,34 @@ def test_argument_errors_match_reference_conditions(gpu):
         G.query_ball_point_dilated(-1.0, 1.0, 4, x, x)
     with pytest.raises(ValueError, match="idx shape"):
         G.group_point(x, torch.zeros((2, 3, 4), dtype=torch.int32, device=gpu))
+
+
+@pytest.mark.parametrize("b,n,m,dup,scale", [(2, 16384, 4096, 0, 30.0), (1, 16384, 700, 3000, 5.0), (2, 9000, 512, 100, 50.0),
+                                             (1, 4100, 4100, 0, 1.0), (1, 16384, 64, 16000, 2.0)])
+def test_fps_bucket_kernel_matches_oracle(gpu, oracle, b, n, m, dup, scale):
+    # the culled kernel directly (also reached through farthest_point_sample for n > 4096): clustered,
+    # heavily duplicated and fully-sampled clouds
+    N = pkg("utils._native")
+    rng = np.random.default_rng(n + m + dup)
+    p = _cloud(rng, b, n, scale=scale, dup=dup)
+    p[:, :, 1] *= 0.05                                    # flat in y like a LiDAR frame
+    t = _t(p, gpu)
+    out = torch.empty((b, m), dtype=torch.int32, device=gpu)
+    st = N.lib().sa_fps_bucket_ex(b, n, m, t.data_ptr(), out.data_ptr(), m, 0, N.current_stream())
+    assert st == 0
+    assert np.array_equal(out.cpu().numpy(), oracle.farthest_point_sample(m, p))
+
+
+def test_fps_bucket_all_identical_and_kitti_frame(gpu, oracle):
+    N = pkg("utils._native")
+    syn = pkg("synthetic")
+    p = np.full((1, 8192, 3), 2.5, np.float32)
+    t = _t(p, gpu)
+    out = torch.empty((1, 100), dtype=torch.int32, device=gpu)
+    assert N.lib().sa_fps_bucket_ex(1, 8192, 100, t.data_ptr(), out.data_ptr(), 100, 0, N.current_stream()) == 0
+    assert (out.cpu().numpy() == 0).all()
+    pts = np.ascontiguousarray(syn.kitti_like_batch(2, first_frame=55, dup_fraction=0.1)[:, :, :3])
+    t = _t(pts, gpu)
+    out = torch.empty((2, 4096), dtype=torch.int32, device=gpu)
+    assert N.lib().sa_fps_bucket_ex(2, 16384, 4096, t.data_ptr(), out.data_ptr(), 4096, 0, N.current_stream()) == 0
+    assert np.array_equal(out.cpu().numpy(), oracle.farthest_point_sample(4096, pts))
