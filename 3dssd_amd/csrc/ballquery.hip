@@ -54,13 +54,24 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void ball_query_kernel(
                     // v_readlane / a lane select, no LDS round trip on the scan path
     unsigned active = (1u << nq) - 1u;                     // queries with at least one band not full
 
-    for (int base = 0; base < n && active != 0u; base += 64 * kCH) {
-        float x1[kCH], y1[kCH], z1[kCH];
+    // register chunk of 64*kCH points, double buffered: chunk c+1 is requested before chunk c is scanned
+    float x1[kCH], y1[kCH], z1[kCH], xn[kCH], yn[kCH], zn[kCH];
 #pragma unroll
-        for (int s = 0; s < kCH; ++s) {
-            int k = base + s * 64 + lane;
-            int kk = k < n ? k : n - 1;
-            x1[s] = P[kk * 3 + 0]; y1[s] = P[kk * 3 + 1]; z1[s] = P[kk * 3 + 2];
+    for (int s = 0; s < kCH; ++s) {
+        const int k = s * 64 + lane;
+        const int kk = k < n ? k : n - 1;
+        xn[s] = P[kk * 3 + 0]; yn[s] = P[kk * 3 + 1]; zn[s] = P[kk * 3 + 2];
+    }
+    for (int base = 0; base < n && active != 0u; base += 64 * kCH) {
+#pragma unroll
+        for (int s = 0; s < kCH; ++s) { x1[s] = xn[s]; y1[s] = yn[s]; z1[s] = zn[s]; }
+        if (base + 64 * kCH < n) {
+#pragma unroll
+            for (int s = 0; s < kCH; ++s) {
+                const int k = base + 64 * kCH + s * 64 + lane;
+                const int kk = k < n ? k : n - 1;
+                xn[s] = P[kk * 3 + 0]; yn[s] = P[kk * 3 + 1]; zn[s] = P[kk * 3 + 2];
+            }
         }
         for (int q = 0; q < nq; ++q) {
             if (!((active >> q) & 1u)) continue;

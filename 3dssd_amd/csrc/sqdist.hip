@@ -98,13 +98,27 @@ constexpr int kMT = 128;   // tile edge
 constexpr int kMK = 16;    // channels per LDS stage
 constexpr int kMLd = 132;  // padded leading dimension
 
+// SYM: a == b (the F-FPS case).  Only tiles with bj >= bi are computed; an off-diagonal tile is also
+// written transposed (through a per-wave LDS patch, so both copies are coalesced).  The matrix is bitwise
+// symmetric by construction: dot(i,j) and dot(j,i) are the same products in the same channel order, and
+// the norm sum is a commutative fp32 add.
+template <bool SYM>
 __global__ __launch_bounds__(256) void sqdist_mfma_kernel(int n, int m, RowSrc A, RowSrc Bm,
                                                           float *__restrict__ out) {
     __shared__ float As[kMK][kMLd];
     __shared__ float Bs[kMK][kMLd];
     __shared__ float sA[kMT], sB[kMT];
+    __shared__ float sT[SYM ? 4 : 1][SYM ? 64 : 1][SYM ? 33 : 1];   // per-wave transpose patch: 64 cols x 32 rows
     const int b = blockIdx.z;
-    const int i0 = blockIdx.y * kMT, j0 = blockIdx.x * kMT;
+    int bi = blockIdx.y, bj = blockIdx.x;
+    if (SYM) {                                    // linear id over the upper triangle (row-major)
+        const int T = (n + kMT - 1) / kMT;
+        int rem = blockIdx.x;
+        bi = 0;
+        while (rem >= T - bi) { rem -= T - bi; ++bi; }
+        bj = bi + rem;
+    }
+    const int i0 = bi * kMT, j0 = bj * kMT;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w >> 1, wc = w & 1;
     const int half = lane >> 5, col = lane & 31;
@@ -122,13 +136,20 @@ __global__ __launch_bounds__(256) void sqdist_mfma_kernel(int n, int m, RowSrc A
     const int lrow = tid >> 1, lk = (tid & 1) * 8;
     const long ga = (long)b * n + min(i0 + lrow, n - 1);
     const long gb = (long)b * m + min(j0 + lrow, m - 1);
+    float pa[8], pb[8];                            // next stage, fetched while the current one is multiplied
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { pa[e] = load_ch(A, ga, lk + e); pb[e] = load_ch(Bm, gb, lk + e); }
     for (int k0 = 0; k0 < c; k0 += kMK) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            As[lk + e][lrow] = load_ch(A, ga, k0 + lk + e);    // channels >= c read as 0
-            Bs[lk + e][lrow] = load_ch(Bm, gb, k0 + lk + e);
-        }
+        for (int e = 0; e < 8; ++e) { As[lk + e][lrow] = pa[e]; Bs[lk + e][lrow] = pb[e]; }
         __syncthreads();
+        if (k0 + kMK < c) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                pa[e] = load_ch(A, ga, k0 + kMK + lk + e);     // channels >= c read as 0
+                pb[e] = load_ch(Bm, gb, k0 + kMK + lk + e);
+            }
+        }
         const int kend = min(kMK, c - k0);
         {
             const float(*S)[kMLd] = tid < kMT ? As : Bs;
@@ -156,6 +177,7 @@ __global__ __launch_bounds__(256) void sqdist_mfma_kernel(int n, int m, RowSrc A
     }
     if (tid < kMT) sA[tid] = nrm; else sB[tid - kMT] = nrm;
     __syncthreads();
+    const bool mirror = SYM && bi != bj;
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti) {
 #pragma unroll
@@ -165,10 +187,19 @@ __global__ __launch_bounds__(256) void sqdist_mfma_kernel(int n, int m, RowSrc A
             const float sb = sB[jl];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int il = wr * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int ir = (r & 3) + 8 * (r >> 2) + 4 * half;        // row inside the 32-row tile
+                const int il = wr * 64 + ti * 32 + ir;
                 const int i = i0 + il;
-                if (i < n && j < m)
-                    out[((size_t)b * n + i) * m + j] = (sA[il] + sb) - 2.0f * acc[ti][tj][r];
+                const float v = (sA[il] + sb) - 2.0f * acc[ti][tj][r];
+                if (i < n && j < m) out[((size_t)b * n + i) * m + j] = v;
+                if (SYM) sT[w][tj * 32 + col][ir] = v;
+            }
+        }
+        if (mirror) {                              // out[j][i] for rows j of this wave's patch, 32 columns i
+            for (int r2 = 0; r2 < 32; ++r2) {
+                const int r = r2 * 2 + half;       // two patch rows per step, 32 lanes (128 B) each
+                const int j = j0 + wc * 64 + r, i = i0 + wr * 64 + ti * 32 + col;
+                if (j < n && i < n) out[((size_t)b * n + j) * n + i] = sT[w][r][col];
             }
         }
     }
@@ -187,9 +218,13 @@ extern "C" int sa_calc_square_dist_split(int b, int n, int m, int c0, int c1, co
     if (use_valu) {
         dim3 grid((m + kT - 1) / kT, (n + kT - 1) / kT, b);
         hipLaunchKernelGGL(sqdist_kernel, grid, dim3(256), 0, stream, n, m, A, Bm, out);
+    } else if (n == m && a0 == b0 && a1 == b1) {   // the F-FPS case: symmetric, upper triangle only
+        const int T = (n + kMT - 1) / kMT;
+        dim3 grid(T * (T + 1) / 2, 1, b);
+        hipLaunchKernelGGL(sqdist_mfma_kernel<true>, grid, dim3(256), 0, stream, n, m, A, Bm, out);
     } else {
         dim3 grid((m + kMT - 1) / kMT, (n + kMT - 1) / kMT, b);
-        hipLaunchKernelGGL(sqdist_mfma_kernel, grid, dim3(256), 0, stream, n, m, A, Bm, out);
+        hipLaunchKernelGGL(sqdist_mfma_kernel<false>, grid, dim3(256), 0, stream, n, m, A, Bm, out);
     }
     SA_CHECK_LAUNCH();
     return SA_OK;

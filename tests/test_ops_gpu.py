@@ -342,3 +342,15 @@ def test_fps_bucket_all_identical_and_kitti_frame(gpu, oracle):
     out = torch.empty((2, 4096), dtype=torch.int32, device=gpu)
     assert N.lib().sa_fps_bucket_ex(2, 16384, 4096, t.data_ptr(), out.data_ptr(), 4096, 0, N.current_stream()) == 0
     assert np.array_equal(out.cpu().numpy(), oracle.farthest_point_sample(4096, pts))
+
+
+@pytest.mark.parametrize("n,c", [(300, 7), (512, 131), (1000, 67), (4096, 35)])
+def test_calc_square_dist_symmetric_path(gpu, oracle, n, c):
+    # a is b (the F-FPS call): upper-triangle kernel with mirrored tiles, still bit-exact and bitwise symmetric
+    M = pkg("utils.model_util")
+    rng = np.random.default_rng(n + c)
+    a = rng.normal(0, 1.5, (2, n, c)).astype(np.float32)
+    ta = _t(a, gpu)
+    got = M.calc_square_dist(ta, ta).cpu().numpy()
+    assert np.array_equal(got, oracle.calc_square_dist(a, a))
+    assert np.array_equal(got, got.transpose(0, 2, 1))
