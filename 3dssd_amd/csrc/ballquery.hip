@@ -20,9 +20,18 @@
 namespace {
 
 constexpr int kMaxBands = 4;
-constexpr int kQW = 8;        // queries per wave
+#ifndef SA_BQ_QW
+#define SA_BQ_QW 8
+#endif
+#ifndef SA_BQ_CH
+#define SA_BQ_CH 8
+#endif
+#ifndef SA_BQ_PREFETCH
+#define SA_BQ_PREFETCH 1
+#endif
+constexpr int kQW = SA_BQ_QW;        // queries per wave
 constexpr int kWavesPerWG = 4;
-constexpr int kCH = 8;        // 64-point steps held in registers per chunk
+constexpr int kCH = SA_BQ_CH;        // 64-point steps held in registers per chunk
 constexpr int kRow = 64;      // max nsample of the fused kernel
 
 struct Bands {
@@ -54,6 +63,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void ball_query_kernel(
                     // v_readlane / a lane select, no LDS round trip on the scan path
     unsigned active = (1u << nq) - 1u;                     // queries with at least one band not full
 
+#if SA_BQ_PREFETCH
     // register chunk of 64*kCH points, double buffered: chunk c+1 is requested before chunk c is scanned
     float x1[kCH], y1[kCH], z1[kCH], xn[kCH], yn[kCH], zn[kCH];
 #pragma unroll
@@ -73,6 +83,16 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void ball_query_kernel(
                 xn[s] = P[kk * 3 + 0]; yn[s] = P[kk * 3 + 1]; zn[s] = P[kk * 3 + 2];
             }
         }
+#else
+    float x1[kCH], y1[kCH], z1[kCH];
+    for (int base = 0; base < n && active != 0u; base += 64 * kCH) {
+#pragma unroll
+        for (int s = 0; s < kCH; ++s) {
+            const int k = base + s * 64 + lane;
+            const int kk = k < n ? k : n - 1;
+            x1[s] = P[kk * 3 + 0]; y1[s] = P[kk * 3 + 1]; z1[s] = P[kk * 3 + 2];
+        }
+#endif
         for (int q = 0; q < nq; ++q) {
             if (!((active >> q) & 1u)) continue;
             const float x2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cx), q));

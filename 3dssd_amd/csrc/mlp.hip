@@ -61,6 +61,21 @@ struct MlpParams {
     int strideA, strideB, pool_off;   // bytes
 };
 
+#ifdef SA_MLP_TIMING
+// phase clocks (s_memtime) summed over workgroups: 0 gather, 1 hidden layers, 2 last layer + pooling,
+// 3 write-out, 4 items, 5 passes.  Debug builds only (tools/mlp_phase_prof.py).
+__device__ unsigned long long g_mlp_prof[65536 * 8];   // one row per workgroup, summed on the host
+#define SA_T0() unsigned long long t__ = __builtin_readcyclecounter(); unsigned long long acc__[4] = {0, 0, 0, 0}; unsigned long long cnt__[2] = {0, 0}
+#define SA_TICK(i) { unsigned long long n__ = __builtin_readcyclecounter(); acc__[i] += n__ - t__; t__ = n__; }
+#define SA_COUNT(i) cnt__[i]++
+#define SA_TFLUSH(cond) if (cond) { unsigned long long *r__ = g_mlp_prof + (size_t)(blockIdx.x & 65535) * 8; for (int i__ = 0; i__ < 4; ++i__) r__[i__] += acc__[i__]; r__[4] += cnt__[0]; r__[5] += cnt__[1]; }
+#else
+#define SA_T0()
+#define SA_TICK(i)
+#define SA_COUNT(i)
+#define SA_TFLUSH(cond)
+#endif
+
 __device__ __forceinline__ f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
                                                    __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -173,6 +188,91 @@ __device__ __forceinline__ void gather8(const MlpParams &P, long pt, long ball, 
     for (int e = 0; e < 8; ++e) {
         const int x = c0 + e - P.C;
         v[e] = x < 0 ? fv[e] : (x == 0 ? px : (x == 1 ? py : (x == 2 ? pz : 0.0f)));
+    }
+}
+
+
+// Gather one 32/64-row input tile into `buf` (hi/lo bf16 planes), NTHR threads, no barrier inside.
+//  * every wave resolves (ball, source point) of each tile row once (lane r -> row r) and hands it to the
+//    slot that needs it with a wave shuffle -- idx/cnt are not re-read per 8-channel group;
+//  * the full 8-channel feature groups (two aligned float4 loads, identical for every lane: no divergence)
+//    are separated from the short tail (left-over feature channels + relative xyz + zero padding), which
+//    only 32..128 slots execute.
+template <int ROWS, int NTHR>
+__device__ __forceinline__ void gather_tile(const MlpParams &P, unsigned char *buf, int stride, long ball0,
+                                            int pass, int G0, int tid) {
+    const int lane = tid & 63;
+    // rows lane and lane+64 (ROWS == 64) / lane&31 (ROWS == 32) resolved by this lane
+    int r_pt[ROWS / 32 > 1 ? 1 : 1], r_ball[1];
+    {
+        const int row = ROWS == 64 ? lane : (lane & 31);
+        int bl, s;
+        if (P.rp <= ROWS) { bl = row / P.rp; s = row - bl * P.rp; } else { bl = 0; s = pass * ROWS + row; }
+        long ball = ball0 + bl;
+        if (ball >= P.nballs) ball = P.nballs - 1;
+        if (s >= P.ns) s = 0;                               // padded rows repeat sample 0
+        const int a_raw = P.idx[ball * P.ns + s];           // both loads issue together
+        const int a = P.cnt[ball] > 0 ? a_raw : 0;          // layers_util.py:157-159
+        r_ball[0] = (int)ball;
+        r_pt[0] = (int)((ball / P.m) * P.n + a);
+    }
+    const int GF = (P.C & 3) == 0 ? (P.C >> 3) : 0;         // full feature groups per row
+    const int totF = ROWS * GF;
+    // uniform trip counts: every lane stays active for the shuffles, out-of-range slots repeat the last one
+#pragma unroll 4
+    for (int it0 = 0; it0 < totF; it0 += NTHR) {
+        const bool live = it0 + tid < totF;
+        const int it = live ? it0 + tid : totF - 1;
+        const int row = it / GF, g = it - row * GF;
+        const long pt = __shfl(r_pt[0], row);
+        const float4 f0 = *(const float4 *)(P.feat + pt * P.C + g * 8);
+        const float4 f1 = *(const float4 *)(P.feat + pt * P.C + g * 8 + 4);
+        const float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+        uint4 hi, lo;
+        split8(v, hi, lo);
+        unsigned char *dst = buf + row * stride + g * 32;
+        if (live) {
+            *(uint4 *)dst = hi;
+            *(uint4 *)(dst + 16) = lo;
+        }
+    }
+    const int GT = G0 - GF;                                 // tail groups per row (1 or 2; all of them if C%4 != 0)
+    const int totT = ROWS * GT;
+    for (int it0 = 0; it0 < totT; it0 += NTHR) {
+        const bool live = it0 + tid < totT;
+        const int it = live ? it0 + tid : totT - 1;
+        const int row = it / GT, g = GF + (it - row * GT);
+        const long pt = __shfl(r_pt[0], row);
+        const long ball = __shfl(r_ball[0], row);
+        const float px = P.xyz[pt * 3 + 0] - P.new_xyz[ball * 3 + 0];
+        const float py = P.xyz[pt * 3 + 1] - P.new_xyz[ball * 3 + 1];
+        const float pz = P.xyz[pt * 3 + 2] - P.new_xyz[ball * 3 + 2];
+        // feature channels that did not fill a whole group (nleft of them after the GF full groups; wave-
+        // uniform): element e of a tail group can only be a feature if e < nleft, so the branch is uniform and
+        // the loads are independent; the address is clamped, the value selected per lane
+        const int nleft = P.C - GF * 8;
+        float fv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            fv[e] = 0.0f;
+            if (e < nleft) {
+                const int c = g * 8 + e;
+                fv[e] = P.feat[pt * P.C + (c < P.C ? c : P.C - 1)];
+            }
+        }
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int x = g * 8 + e - P.C;
+            v[e] = x < 0 ? fv[e] : (x == 0 ? px : (x == 1 ? py : (x == 2 ? pz : 0.0f)));
+        }
+        uint4 hi, lo;
+        split8(v, hi, lo);
+        unsigned char *dst = buf + row * stride + g * 32;
+        if (live) {
+            *(uint4 *)dst = hi;
+            *(uint4 *)(dst + 16) = lo;
+        }
     }
 }
 
@@ -295,32 +395,18 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? SA_MLP_WPE8 : 4) void group_mlp_
     const LayerDesc &LL = P.L[P.nl - 1];
     const int N3p = LL.NT * 32;
     const int G0 = P.L[0].KS * 2;                     // 8-channel groups of the input tile
+    SA_T0();
 
     for (long item = blockIdx.x; item < nitems; item += gridDim.x) {
         const long ball0 = item * bpi;
+        SA_COUNT(0);
         for (int ch = 0; ch < chunks; ++ch) {
+            SA_COUNT(1);
             // ---- gather the [32 rows x cin] input tile (features first, then relative xyz:
             //      layers_util.py:160-165) into bufA as hi/lo bf16
-            for (int it = tid; it < kRows * G0; it += kThr) {
-                const int row = it / G0, g = it - row * G0;
-                int bl, s;
-                if (P.rp <= 32) { bl = row / P.rp; s = row - bl * P.rp; } else { bl = 0; s = ch * 32 + row; }
-                long ball = ball0 + bl;
-                if (ball >= P.nballs) ball = P.nballs - 1;
-                if (s >= P.ns) s = 0;                               // padded rows repeat sample 0
-                const int a_raw = P.idx[ball * P.ns + s];               // both loads issue together
-                const int a = P.cnt[ball] > 0 ? a_raw : 0;              // layers_util.py:157-159
-                const long bi = ball / P.m;
-                const long pt = bi * P.n + a;
-                float v[8];
-                gather8(P, pt, ball, g * 8, v);
-                uint4 hi, lo;
-                split8(v, hi, lo);
-                unsigned char *dst = bufA + row * P.strideA + g * 32;
-                *(uint4 *)dst = hi;
-                *(uint4 *)(dst + 16) = lo;
-            }
+            gather_tile<kRows, kThr>(P, bufA, P.strideA, ball0, ch, G0, tid);
             __syncthreads();
+            SA_TICK(0)
             // ---- hidden layers (ping-pong A -> B -> A)
             for (int l = 0; l + 1 < P.nl; ++l) {
                 const unsigned char *in = (l & 1) ? bufB : bufA;
@@ -335,6 +421,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? SA_MLP_WPE8 : 4) void group_mlp_
                 }
                 __syncthreads();
             }
+            SA_TICK(1)
             // ---- last layer + pooling
             {
                 const int l = P.nl - 1;
@@ -349,6 +436,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? SA_MLP_WPE8 : 4) void group_mlp_
                 }
             }
             __syncthreads();
+            SA_TICK(2)
         }
         // ---- write out: relu(max + bias), zero for empty balls (layers_util.py:178-181)
         for (int e = tid; e < bpi * LL.N; e += kThr) {
@@ -362,7 +450,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? SA_MLP_WPE8 : 4) void group_mlp_
             }
         }
         __syncthreads();
+        SA_TICK(3)
     }
+    SA_TFLUSH(tid == 0)
 }
 
 
@@ -629,25 +719,7 @@ __global__ __launch_bounds__(kThreads, 2) void group_mlp_wide_kernel(WideParams 
     for (long item = blockIdx.x; item < nitems; item += gridDim.x) {
         const long ball0 = item * bpi;
         for (int ps = 0; ps < passes; ++ps) {
-            for (int it = tid; it < kWRows * G0; it += kThreads) {
-                const int row = it / G0, g = it - row * G0;
-                int bl, s;
-                if (P.rp <= 64) { bl = row / P.rp; s = row - bl * P.rp; } else { bl = 0; s = ps * 64 + row; }
-                long ball = ball0 + bl;
-                if (ball >= P.nballs) ball = P.nballs - 1;
-                if (s >= P.ns) s = 0;
-                const int a_raw = P.idx[ball * P.ns + s];
-                const int a = P.cnt[ball] > 0 ? a_raw : 0;
-                const long bi = ball / P.m;
-                const long pt = bi * P.n + a;
-                float v[8];
-                gather8(P, pt, ball, g * 8, v);
-                uint4 hi, lo;
-                split8(v, hi, lo);
-                unsigned char *dst = bufA + row * P.strideA + g * 32;
-                *(uint4 *)dst = hi;
-                *(uint4 *)(dst + 16) = lo;
-            }
+            gather_tile<kWRows, kThreads>(P, bufA, P.strideA, ball0, ps, G0, tid);
             __syncthreads();
             if (tgl <= 1) wide_item_layers<1>(WP, bufA, bufB, pooled, N3p, ps == 0, lane, w);
             else if (tgl <= 2) wide_item_layers<2>(WP, bufA, bufB, pooled, N3p, ps == 0, lane, w);
@@ -938,3 +1010,20 @@ extern "C" int sa_vote_translate(long npoints, const float *xyz, const float *of
     SA_CHECK_LAUNCH();
     return SA_OK;
 }
+
+#ifdef SA_MLP_TIMING
+extern "C" int sa_debug_mlp_prof(unsigned long long *host8, int reset) {
+    static unsigned long long *h = (unsigned long long *)calloc(65536 * 8, sizeof(unsigned long long));
+    if (host8) {
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_mlp_prof), 65536 * 8 * sizeof(unsigned long long)) != hipSuccess) return SA_ERR_LAUNCH;
+        for (int i = 0; i < 8; ++i) host8[i] = 0;
+        for (int r = 0; r < 65536; ++r) for (int i = 0; i < 8; ++i) host8[i] += h[r * 8 + i];
+    }
+    if (reset) {
+        void *d = nullptr;
+        if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_mlp_prof)) != hipSuccess) return SA_ERR_LAUNCH;
+        if (hipMemset(d, 0, 65536 * 8 * sizeof(unsigned long long)) != hipSuccess) return SA_ERR_LAUNCH;
+    }
+    return SA_OK;
+}
+#endif
