@@ -31,6 +31,7 @@ import torch
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E, MI355X_MICROARCH.md
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA
 VALU_F32_PEAK_TF = 157.3
+CUS_USED_FPS = 8            # FPS runs one workgroup per frame: batch 8 -> 8 of 256 CUs
 
 
 def pkg(name):
@@ -131,6 +132,35 @@ def profile_stages(net, pts, iters):
     return stages
 
 
+def _pmc_traffic(stage):
+    """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC pass
+    (profiles/r01_traffic.json, made by tools/gpu_prof.sh + tools/summarize_prof.py: FETCH_SIZE doubled per the
+    gfx950 note of MI355X_MICROARCH.md + WRITE_SIZE).  Only for kernels whose template instance is unique to
+    the stage; None otherwise or when the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if not os.path.exists(path):
+        return None
+    label = stage["label"]
+    name = None
+    if stage["kernel"] == "sa_fps_ex" and " c=3" in label:
+        n = int(label.split("n=")[1].split("->")[0])
+        ppt = 1
+        while ppt * 1024 < n:
+            ppt *= 2
+        name = "fps3_reg_kernel<%d>" % ppt
+    elif stage["kernel"] == "sa_fps_with_distance_ex":
+        n = int(label.split("n=")[1].split("->")[0])
+        ppt = 1
+        while ppt * 1024 < n:
+            ppt *= 2
+        name = "fpsdist_reg_kernel<%d>" % ppt
+    try:
+        d = json.load(open(path))
+        return int(d[name]["hbm_bytes_per_launch"]) if name in d else None
+    except Exception:
+        return None
+
+
 def roofline_of(stage):
     k = stage["kernel"]
     if k in ("sa_group_mlp_max", "sa_dense", "sa_calc_square_dist_split"):
@@ -140,13 +170,17 @@ def roofline_of(stage):
                     frac=round(a / peak, 5), traffic=None)
     a = stage.get("gbs", 0.0)
     r = dict(kernel=stage["label"], bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s",
-             frac=round(a / HBM_PEAK_GBS, 6), traffic=None)
+             frac=round(a / HBM_PEAK_GBS, 6), traffic=_pmc_traffic(stage),
+             algorithmic_bytes=int(stage["mbytes"] * 1e6))
     if k.startswith("sa_fps"):
         # FPS is a serial dependent chain on ONE CU per frame: neither HBM- nor MFMA-bound;
         # the fp32 VALU rate is the meaningful ceiling, quoted beside the (tiny) algorithmic HBM figure.
         r["note"] = "latency/VALU-bound serial chain; see valu_tflops"
         r["valu_tflops"] = stage.get("tflops", 0.0)
         r["valu_frac"] = round(stage.get("tflops", 0.0) / VALU_F32_PEAK_TF, 5)
+        # one workgroup (one CU) per frame by construction: fraction of the fp32 VALU peak of the CUs it can use
+        r["cus_used"] = CUS_USED_FPS
+        r["valu_frac_of_cus_used"] = round(stage.get("tflops", 0.0) / (VALU_F32_PEAK_TF * CUS_USED_FPS / 256.0), 4)
     return r
 
 
@@ -173,13 +207,13 @@ def cpu_baseline(arch, params, batch, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step (BASELINE.json configs[1])")
     ap.add_argument("--points", type=int, default=16384)
     ap.add_argument("--streams", type=int, default=16, help="HIP streams the steps are issued on")
     ap.add_argument("--profile-iters", type=int, default=3)
-    ap.add_argument("--graphs", type=int, default=0, help="1: capture one hipGraph per stream and replay it")
+    ap.add_argument("--graphs", type=int, default=1, help="1 (default): capture one hipGraph per stream and replay it; 0: eager launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -198,6 +232,8 @@ def main():
     frames = sh.frames_of_rank(0, args.batch * world, rank, world)
     pts = torch.from_numpy(np.stack([syn.kitti_like_frame(f, args.points) for f in frames])).to(dev)
 
+    global CUS_USED_FPS
+    CUS_USED_FPS = len(frames)          # one FPS workgroup (one CU) per frame
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
 
     graphs = None

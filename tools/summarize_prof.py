@@ -23,3 +23,24 @@ for f in sorted(glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection
             seen.add(key); cnt[k] += 1
     for k in sorted(agg, key=lambda k: -cnt[k])[:40]:
         print("  %-60s n=%4d " % (k, cnt[k]) + " ".join("%s=%.4g" % (c, v / cnt[k]) for c, v in sorted(agg[k].items())))
+
+# per-kernel HBM traffic per launch (bytes) for bench.py's roofline.traffic: FETCH_SIZE / WRITE_SIZE are in KiB;
+# on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM section), so reads are
+# doubled; WRITE_SIZE is taken as is (uncalibrated).
+import json
+tr = {}
+for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+    for f in glob.glob(os.path.join(root, "pmc_" + cname, "**", "*counter_collection.csv"), recursive=True):
+        agg = collections.defaultdict(float); cnt = collections.Counter(); seen = set()
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != cname:
+                continue
+            k = short(r["Kernel_Name"])
+            agg[k] += float(r["Counter_Value"])
+            if (k, r["Dispatch_Id"]) not in seen:
+                seen.add((k, r["Dispatch_Id"])); cnt[k] += 1
+        for k in agg:
+            tr.setdefault(k, {})[cname + "_KiB_per_launch"] = agg[k] / cnt[k]
+for k, d in tr.items():
+    d["hbm_bytes_per_launch"] = int(1024 * (2.0 * d.get("FETCH_SIZE_KiB_per_launch", 0.0) + d.get("WRITE_SIZE_KiB_per_launch", 0.0)))
+json.dump(tr, open(os.path.join(root, "traffic.json"), "w"), indent=1, sort_keys=True)
