@@ -46,3 +46,9 @@ CONFIG0_SINGLE_SA = [
      [-1], ["D-FPS"], [512],
      -1, False, "SA_Layer", "layer1", False, -1, -1],
 ]
+
+# MODEL.NETWORK.FIRST_STAGE.HEAD of 3dssd.yaml:68 and the post-processing constants (:38, :70-71)
+KITTI_3DSSD_HEAD = [[6], [6], "conv1d", [128], True, "Det", ""]
+KITTI_ANGLE_CLS_NUM = 12
+KITTI_MAX_OUTPUT_NUM = 100
+KITTI_NMS_THRESH = 0.1

@@ -104,3 +104,28 @@ def random_backbone_params(arch, in_feature_channels=1, seed=WEIGHT_SEED, aggreg
         else:
             raise NotImplementedError(layer_type)
     return p
+
+
+def random_head_params(in_channels=512, cls_channel=1, angle_cls_num=12, mlp_list=(128,), scope="", seed=WEIGHT_SEED + 1,
+                       params=None):
+    """Random-init 'Det' head (lib/modeling/head_builder.py:97-98, lib/utils/head_util.py:32-38): conv1d_<i>,
+    pred_cls_base, pred_cls, pred_reg_base, pred_reg under `scope` (empty for 3dssd.yaml:68)."""
+    rng = np.random.default_rng(seed)
+    p = {} if params is None else params
+    pre = scope + "/" if scope else ""
+
+    def conv(name, cin, cout, bn):
+        p[pre + name + "/weights"] = _xavier(rng, cin, cout).reshape(1, cin, cout)
+        p[pre + name + "/biases"] = rng.normal(0.0, 0.05, cout).astype(np.float32)
+        if bn:
+            _bn(rng, cout, p, pre + name)
+
+    cin = in_channels
+    for i, ch in enumerate(mlp_list):
+        conv("conv1d_%d" % i, cin, ch, True)
+        cin = ch
+    conv("pred_cls_base", cin, 128, True)
+    conv("pred_cls", 128, cls_channel, False)
+    conv("pred_reg_base", cin, 128, True)
+    conv("pred_reg", 128, 6 + 2 * angle_cls_num, False)
+    return p

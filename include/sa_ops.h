@@ -106,6 +106,19 @@ int sa_dense(long rows, int K, int N, const float *x, const void *wpack, const f
 int sa_vote_translate(long npoints, const float *xyz, const float *off, float lo_x, float lo_y,
                       float lo_z, float *out, sa_stream_t stream);
 
+/* ---- next row after the backbone: TF graph code in the reference ------------------- */
+
+/* decode_dist_anchor_free + decode_class2angle (lib/utils/anchor_decoder.py:6-14,86-112), sigmoid scores
+ * (lib/modeling/single_stage_detector.py:211-212) and the BEV box of every prediction (box_3d_utils.py:25-58,
+ * anchors_util.py:11-50).  reg [b,n,6+2A] = offsets | angle cls | angle res; boxes [b,n,7]; bev [b,n,4]. */
+int sa_decode_anchor_free(int b, int n, int A, int C, const float *xyz, const float *reg, const float *cls,
+                          float *boxes, float *scores, float *bev, sa_stream_t stream);
+int sa_boxes_to_bev(long nboxes, const float *boxes, float *bev, sa_stream_t stream);
+/* tf.image.non_max_suppression per frame and class (lib/builder/postprocessor.py:76-88): idx [b,C,max_out] kept
+ * candidate indices in selection order padded with -1, cnt [b,C].  Equal scores: lower index first. */
+int sa_nms_bev(int b, int n, int C, int max_out, float iou_threshold, const float *bev, const float *scores,
+               int *idx, int *cnt, sa_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

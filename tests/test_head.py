@@ -1,0 +1,167 @@
+"""Next row after the backbone: detection head, anchor-free decode, sigmoid, BEV NMS.
+CPU: hand-derived known-answer tests of the oracle (oracle/head_oracle.py).  GPU (-m gpu): HIP vs oracle --
+decode / BEV / NMS bit-exact on identical inputs, head convolutions within 1e-3, whole detector stage by stage."""
+import numpy as np
+import pytest
+
+from conftest import pkg
+
+f32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def H(oracle):
+    from oracle import head_oracle
+    return head_oracle
+
+
+# ------------------------------------------------------------------------------------------- CPU KATs
+def test_decode_class2angle_and_anchor_free_hand(H):
+    # anchor_decoder.py:6-14: angle = (bin + res[bin]) * 2pi/12 ; :86-112: centre = xyz + t (+ half_y on y),
+    # lhw = max(2*half, 0.1)
+    A = 12
+    xyz = np.array([[[1.0, 2.0, 3.0]]], f32)
+    dist6 = np.array([[[0.5, -0.25, 1.0, 2.0, 0.75, 0.01]]], f32)
+    acls = np.zeros((1, 1, A), f32); acls[0, 0, 3] = 5.0; acls[0, 0, 7] = 5.0      # tie: first maximum = bin 3
+    ares = np.zeros((1, 1, A), f32); ares[0, 0, 3] = 0.5; ares[0, 0, 7] = 0.9
+    box = H.decode_dist_anchor_free(xyz, dist6, acls, ares, A)[0, 0]
+    assert box[0] == f32(1.5) and box[2] == f32(4.0)
+    assert box[1] == f32(2.0 - 0.25 + 0.75)                  # bottom-centre convention
+    assert box[3] == f32(4.0) and box[4] == f32(1.5) and box[5] == f32(0.1)   # 2*0.01 < 0.1 -> clamped
+    assert box[6] == f32(f32(3.5) * f32(2 * np.pi / 12))
+
+
+def test_bev_box_axis_aligned_and_rotated(H):
+    # box_3d_utils.py:51-53: dimx = l|cos| + w|sin| ; ry = 0 -> (l, w) ; ry = pi/2 -> (w, l) up to cos(pi/2) ~ 6e-17
+    boxes = np.array([[10, 0, 20, 4, 1.5, 2, 0.0], [10, 0, 20, 4, 1.5, 2, np.pi / 2]], f32)
+    bev = H.box_3d_to_bev(boxes)
+    assert bev[0].tolist() == [8.0, 19.0, 12.0, 21.0]
+    assert np.allclose(bev[1], [9.0, 18.0, 11.0, 22.0], atol=1e-6)
+
+
+def test_nms_hand(H):
+    # tf.image.non_max_suppression: descending score, keep iff IoU <= thr with every kept box
+    boxes = np.array([[0, 0, 2, 2],      # A  score .9
+                      [1, 1, 3, 3],      # B  IoU(A,B) = 1/7 = .143
+                      [0, 0, 2, 2.2],    # C  IoU(A,C) = 4/4.4 = .909
+                      [5, 5, 6, 6],      # D  disjoint
+                      [2, 2, 1, 1]],     # E  flipped corners of a unit box inside B: IoU(B,E)=1/4, IoU(A,E)=1/4
+                     f32)
+    scores = np.array([0.9, 0.8, 0.85, 0.1, 0.5], f32)
+    assert H.non_max_suppression(boxes, scores, 10, 0.5).tolist() == [0, 1, 4, 3]     # C suppressed by A
+    assert H.non_max_suppression(boxes, scores, 10, 0.2).tolist() == [0, 1, 3]        # E: IoU .25 > .2
+    assert H.non_max_suppression(boxes, scores, 10, 0.1).tolist() == [0, 3]           # B: .143 > .1
+    assert H.non_max_suppression(boxes, scores, 2, 0.5).tolist() == [0, 1]            # max_output_size
+    # IoU exactly at the threshold is kept (suppression needs iou > thr): two unit squares sharing half: 1/3
+    b2 = np.array([[0, 0, 1, 1], [0, 0.5, 1, 1.5]], f32)
+    assert H.non_max_suppression(b2, np.array([1, .5], f32), 10, float(f32(f32(0.5) / f32(1.5)))).tolist() == [0, 1]
+    # zero-area boxes never suppress nor get suppressed (IoU := 0)
+    b3 = np.array([[0, 0, 1, 1], [0.5, 0.5, 0.5, 0.9], [0.2, 0.2, 0.8, 0.8]], f32)
+    assert H.non_max_suppression(b3, np.array([.9, .8, .7], f32), 10, 0.3).tolist() == [0, 1]
+    # equal scores: lower index first (pinned)
+    b4 = np.array([[0, 0, 1, 1], [0, 0, 1, 1]], f32)
+    assert H.non_max_suppression(b4, np.array([.5, .5], f32), 10, 0.5).tolist() == [0]
+
+
+def test_sigmoid_f32(H):
+    assert H.sigmoid_f32(np.array([0.0], f32))[0] == f32(0.5)
+    assert H.sigmoid_f32(np.array([40.0], f32))[0] == f32(1.0)
+
+
+# ------------------------------------------------------------------------------------------- GPU parity
+def _t(a, dev):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,n,C", [(2, 256, 1), (1, 300, 3), (3, 64, 2)])
+def test_decode_scores_bev_bit_exact(gpu, H, b, n, C):
+    D = pkg("utils.anchor_decoder")
+    rng = np.random.default_rng(n + C)
+    A = 12
+    xyz = rng.uniform(-30, 30, (b, n, 3)).astype(f32)
+    reg = rng.normal(0, 1, (b, n, 6 + 2 * A)).astype(f32)
+    reg[..., 3:6] = np.abs(reg[..., 3:6]) * 1.5
+    reg[:, ::5, 5] = 0.01                                         # clamp branch
+    cls = rng.normal(0, 4, (b, n, C)).astype(f32)
+    boxes, scores, bev = D.decode_scores_bev(_t(xyz, gpu), _t(reg, gpu), _t(cls, gpu), A)
+    rb = H.decode_dist_anchor_free(xyz, reg[..., :6], reg[..., 6:6 + A], reg[..., 6 + A:], A)
+    assert np.array_equal(boxes.cpu().numpy(), rb)
+    assert np.array_equal(scores.cpu().numpy(), H.sigmoid_f32(cls))
+    assert np.array_equal(bev.cpu().numpy(), H.box_3d_to_bev(rb))
+    b2 = D.decode_dist_anchor_free(_t(xyz, gpu), _t(reg[..., :6], gpu), _t(reg[..., 6:6 + A], gpu), _t(reg[..., 6 + A:], gpu))
+    assert np.array_equal(b2.cpu().numpy(), rb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,n,C,thr,K", [(2, 256, 1, 0.1, 100), (1, 256, 3, 0.5, 100), (2, 1000, 1, 0.3, 50), (1, 70, 2, 0.1, 100)])
+def test_nms_bev_matches_oracle(gpu, H, b, n, C, thr, K):
+    P = pkg("builder.postprocessor")
+    rng = np.random.default_rng(n + int(thr * 10))
+    ctr = rng.uniform(0, 30, (b, n, 2)).astype(f32)
+    half = rng.uniform(0.5, 3.0, (b, n, 2)).astype(f32)
+    bev = np.concatenate([ctr - half, ctr + half], -1).astype(f32)
+    bev[:, ::17, 2] = bev[:, ::17, 0]                             # zero-area boxes
+    scores = rng.uniform(0, 1, (b, n, C)).astype(f32)
+    scores[:, 5::9] = scores[:, 4::9][:, :scores[:, 5::9].shape[1]]   # equal scores -> index order
+    pp = P.PostProcessor(0, C, K, thr)
+    idx, cnt = pp.nms(_t(bev, gpu), _t(scores, gpu))
+    idx, cnt = idx.cpu().numpy(), cnt.cpu().numpy()
+    for bi in range(b):
+        for c in range(C):
+            ref = H.non_max_suppression(bev[bi], scores[bi, :, c], K, thr)
+            assert cnt[bi, c] == len(ref)
+            assert np.array_equal(idx[bi, c, :len(ref)], ref)
+            assert (idx[bi, c, len(ref):] == -1).all()
+
+
+@pytest.mark.gpu
+def test_nms_kat_on_gpu(gpu):
+    P = pkg("builder.postprocessor")
+    boxes = np.array([[[0, 0, 2, 2], [1, 1, 3, 3], [0, 0, 2, 2.2], [5, 5, 6, 6], [2, 2, 1, 1]]], f32)
+    scores = np.array([[[0.9], [0.8], [0.85], [0.1], [0.5]]], f32)
+    for thr, exp in ((0.5, [0, 1, 4, 3]), (0.2, [0, 1, 3]), (0.1, [0, 3])):
+        idx, cnt = P.PostProcessor(0, 1, 10, thr).nms(_t(boxes, gpu), _t(scores, gpu))
+        assert idx.cpu()[0, 0, :int(cnt[0, 0])].tolist() == exp
+
+
+@pytest.mark.gpu
+def test_detector_points_to_boxes_stage_by_stage(gpu, oracle, H):
+    import torch
+    cfgs, syn = pkg("configs"), pkg("synthetic")
+    M = pkg("modeling.single_stage_detector")
+    arch = cfgs.KITTI_3DSSD_ARCH
+    params = syn.random_backbone_params(arch)
+    syn.random_head_params(512, 1, cfgs.KITTI_ANGLE_CLS_NUM, params=params)
+    det = M.SingleStageDetector(arch, cfgs.KITTI_3DSSD_HEAD, params, gpu, cls_num=1,
+                                angle_cls_num=cfgs.KITTI_ANGLE_CLS_NUM,
+                                max_output_size=cfgs.KITTI_MAX_OUTPUT_NUM, nms_threshold=cfgs.KITTI_NMS_THRESH)
+    pts = syn.kitti_like_batch(2, first_frame=11)
+    out = det(torch.from_numpy(pts).to(gpu))
+    torch.cuda.synchronize()
+    xyz = out["key_output_xyz"][0].cpu().numpy()
+    # head convolutions from the GPU's own backbone features (teacher-forced), 1e-3
+    feat_in = det.backbone  # noqa: F841
+    xl, fl, _ = det.backbone(torch.from_numpy(pts).to(gpu))
+    pc, po, pac, par = H.box_regression_head(fl[-1].cpu().numpy(), params, 1, cfgs.KITTI_ANGLE_CLS_NUM)
+    rel = lambda a, r: float(np.abs(a - r).max() / max(np.abs(r).max(), 1e-30))
+    assert rel(out["pred_cls"][0].cpu().numpy(), pc) < 1e-3
+    assert rel(out["pred_reg_raw"][0].cpu().numpy(), np.concatenate([po, pac, par], -1)) < 1e-3
+    # decode / scores / BEV from the GPU's own head outputs: bit-exact
+    reg = out["pred_reg_raw"][0].cpu().numpy()
+    A = cfgs.KITTI_ANGLE_CLS_NUM
+    rb = H.decode_dist_anchor_free(xyz, reg[..., :6], reg[..., 6:6 + A], reg[..., 6 + A:], A)
+    assert np.array_equal(out["pred_anchors_3d"][0].cpu().numpy(), rb)
+    rs = H.sigmoid_f32(out["pred_cls"][0].cpu().numpy())
+    assert np.array_equal(out["pred_score"][0].cpu().numpy(), rs)
+    # NMS from the GPU's own boxes and scores: bit-exact, and the gathered detections are consistent
+    ridx, rcnt, _ = H.postprocess(rb, rs, cfgs.KITTI_MAX_OUTPUT_NUM, cfgs.KITTI_NMS_THRESH)
+    assert np.array_equal(out["nms_cnt"][0].cpu().numpy(), rcnt)
+    assert np.array_equal(out["nms_idx"][0].cpu().numpy(), ridx)
+    k = int(rcnt[0, 0])
+    assert k >= 1
+    got = out["pred_3d_bbox"][0].cpu().numpy()
+    assert np.array_equal(got[0, :k], rb[0][ridx[0, 0, :k]])
+    assert (got[0, k:] == 0).all()
+    assert np.array_equal(out["pred_3d_score"][0].cpu().numpy()[0, :k], rs[0, ridx[0, 0, :k], 0])
