@@ -106,36 +106,45 @@ __device__ __forceinline__ void mma_k_loop(f32x16 (&acc)[TG], const unsigned cha
     for (int tt = 0; tt < TG; ++tt)
         wbase[tt] = L.w + ((size_t)(min(gb + tt, L.NT - 1) * L.KS) * 2) * 64 + lane;
 #if SA_MLP_PREFETCH
-    // one-k-step-ahead register prefetch.  (A deeper register ring was tried: hipcc either waits vmcnt(0)
-    // at every ring step or spills; the measured gain of distance 1 over none is 10-20%.)
-    uint4 wh[TG], wl[TG];
+    // Batched k-steps: the weight (L2) and activation (LDS) fragments of KB consecutive k-steps are requested
+    // together, then their MFMAs run back to back: one L2 round trip (~600-700 cycles measured) per KB k-steps
+    // instead of one per k-step (a k-step is only 96 x TG cycles of MFMA issue).  The sched_barrier keeps hipcc
+    // from sinking the later loads back down to their uses, which silently re-serialises the loop.
+#ifndef SA_MLP_KB1
+#define SA_MLP_KB1 4
+#endif
+    constexpr int KB = TG >= 4 ? 1 : (TG == 2 ? (SA_MLP_KB1 >= 2 ? 2 : 1) : SA_MLP_KB1);
+    for (int ks0 = 0; ks0 < L.KS; ks0 += KB) {
+        uint4 wh[KB][TG], wl[KB][TG], ah[KB], al[KB];
 #pragma unroll
-    for (int tt = 0; tt < TG; ++tt) { wh[tt] = wbase[tt][0]; wl[tt] = wbase[tt][64]; }
-    uint4 ah = *(const uint4 *)(arow), al = *(const uint4 *)(arow + 16);
-    for (int ks = 0; ks < L.KS; ++ks) {
-        uint4 nwh[TG], nwl[TG], nah = ah, nal = al;
-        const int kn = ks + 1 < L.KS ? ks + 1 : ks;
+        for (int d = 0; d < KB; ++d) {
+            const int ks = ks0 + d < L.KS ? ks0 + d : L.KS - 1;
 #pragma unroll
-        for (int tt = 0; tt < TG; ++tt) { nwh[tt] = wbase[tt][kn * 128]; nwl[tt] = wbase[tt][kn * 128 + 64]; }
-        nah = *(const uint4 *)(arow + kn * 64);
-        nal = *(const uint4 *)(arow + kn * 64 + 16);
+            for (int tt = 0; tt < TG; ++tt) { wh[d][tt] = wbase[tt][ks * 128]; wl[d][tt] = wbase[tt][ks * 128 + 64]; }
+            ah[d] = *(const uint4 *)(arow + ks * 64);
+            al[d] = *(const uint4 *)(arow + ks * 64 + 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int tt = 0; tt < TG; ++tt) {
-            if (gb + tt < L.NT) {
-                if (WFIRST) {
-                    acc[tt] = mfma_bf16(wh[tt], ah, acc[tt]);
-                    acc[tt] = mfma_bf16(wl[tt], ah, acc[tt]);
-                    acc[tt] = mfma_bf16(wh[tt], al, acc[tt]);
-                } else {
-                    acc[tt] = mfma_bf16(ah, wh[tt], acc[tt]);
-                    acc[tt] = mfma_bf16(ah, wl[tt], acc[tt]);
-                    acc[tt] = mfma_bf16(al, wh[tt], acc[tt]);
+        for (int d = 0; d < KB; ++d) {
+            if (ks0 + d < L.KS) {
+#pragma unroll
+                for (int tt = 0; tt < TG; ++tt) {
+                    if (gb + tt < L.NT) {
+                        if (WFIRST) {
+                            acc[tt] = mfma_bf16(wh[d][tt], ah[d], acc[tt]);
+                            acc[tt] = mfma_bf16(wl[d][tt], ah[d], acc[tt]);
+                            acc[tt] = mfma_bf16(wh[d][tt], al[d], acc[tt]);
+                        } else {
+                            acc[tt] = mfma_bf16(ah[d], wh[d][tt], acc[tt]);
+                            acc[tt] = mfma_bf16(ah[d], wl[d][tt], acc[tt]);
+                            acc[tt] = mfma_bf16(al[d], wh[d][tt], acc[tt]);
+                        }
+                    }
                 }
             }
         }
-#pragma unroll
-        for (int tt = 0; tt < TG; ++tt) { wh[tt] = nwh[tt]; wl[tt] = nwl[tt]; }
-        ah = nah; al = nal;
+        __builtin_amdgcn_sched_barrier(0);
     }
 #else
 #ifdef SA_MLP_KUNROLL
