@@ -1,0 +1,278 @@
+// Ball query through a uniform x-z grid: same outputs as ballquery.hip (first nsample hits in index order,
+// padding with the first hit, zero rows for empty balls), ~10x fewer distance evaluations on large frames.
+//
+// The brute-force kernel evaluates all n x m pairs because "the first nsample in index order" looks inherently
+// serial.  It is not: the result of a band is the set of the nsample SMALLEST indices among the points inside
+// the band.  So: (1) per frame, bucket the points into grid cells at least r_max wide (one workgroup: LDS
+// histogram, scan, scatter -- order inside a cell is irrelevant); (2) per query, visit the 3 x 3 cells around it,
+// evaluate exactly the same d2 and thresholds as ballquery.hip on those candidates only, collect the hits of
+// every band in LDS, and place hit h at output slot rank(h) = #{hits with a smaller index} if rank < nsample.
+// A query whose candidate list overflows the LDS buffer falls back to the ordered full scan inside the kernel.
+//
+// Cell geometry: cell = clamp(int((coord - min) * inv), 0, kNX-1) with cell size >= r_max * (1 + 1e-4): monotone in
+// the coordinate, so |dx| <= r_max implies a cell difference of at most 1 (the margin absorbs the fp32 rounding of
+// the product), and clamping only merges cells.  y is not gridded (LiDAR frames are flat); it enters through d2.
+#include <math.h>
+
+#include "sa_common.h"
+
+namespace {
+
+constexpr int kNX = 128;                 // grid is kNX x kNX cells
+constexpr int kNC = kNX * kNX;
+constexpr int kMaxBands = 4;
+constexpr int kCap = 512;                // hits per band kept in LDS per query (more -> ordered full scan)
+constexpr int kQWaves = 4;               // waves (= queries in flight) per workgroup
+
+struct GBands {
+    float tlo[kMaxBands], thi[kMaxBands];
+    int ns[kMaxBands];
+    int *idx[kMaxBands];
+    int *cnt[kMaxBands];
+    float thi_max;
+    int nbands, dilated;
+};
+
+__device__ __forceinline__ float wave_allmin_f(float x) { return -sa::wave_allmax(-x); }
+
+// workspace per frame: cell_start[kNC + 1] ints | sorted[n] ints | params[4] floats (minx, minz, inv, 0)
+__device__ __forceinline__ size_t ws_stride(int n) { return ((size_t)(kNC + 1) + n + 4 + 3) / 4 * 4; }
+
+__global__ __launch_bounds__(1024) void bq_grid_build_kernel(int n, float cell_min, const float *__restrict__ xyz1,
+                                                             int *__restrict__ ws) {
+    __shared__ int s_cnt[kNC];
+    __shared__ float s_red[4][16];
+    __shared__ int s_wsum[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float *p = xyz1 + (size_t)b * n * 3;
+    int *cell_start = ws + (size_t)b * ws_stride(n);
+    int *sorted = cell_start + (kNC + 1);
+    float *params = (float *)(sorted + n);
+
+    float mnx = 3e38f, mxx = -3e38f, mnz = 3e38f, mxz = -3e38f;
+    for (int k = tid; k < n; k += 1024) {
+        const float x = p[k * 3 + 0], z = p[k * 3 + 2];
+        mnx = sa::fmin_nn(mnx, x); mxx = sa::fmax_nn(mxx, x);
+        mnz = sa::fmin_nn(mnz, z); mxz = sa::fmax_nn(mxz, z);
+    }
+    mnx = wave_allmin_f(mnx); mxx = sa::wave_allmax(mxx);
+    mnz = wave_allmin_f(mnz); mxz = sa::wave_allmax(mxz);
+    if (lane == 0) { s_red[0][w] = mnx; s_red[1][w] = mxx; s_red[2][w] = mnz; s_red[3][w] = mxz; }
+    for (int i = tid; i < kNC; i += 1024) s_cnt[i] = 0;
+    __syncthreads();
+    mnx = s_red[0][0]; mxx = s_red[1][0]; mnz = s_red[2][0]; mxz = s_red[3][0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) {
+        mnx = sa::fmin_nn(mnx, s_red[0][i]); mxx = sa::fmax_nn(mxx, s_red[1][i]);
+        mnz = sa::fmin_nn(mnz, s_red[2][i]); mxz = sa::fmax_nn(mxz, s_red[3][i]);
+    }
+    // cell size: at least cell_min (= r_max with margin), and large enough that the frame spans <= kNX-2 cells
+    float cs = sa::fmax_nn(cell_min, sa::fmax_nn(mxx - mnx, mxz - mnz) / (float)(kNX - 2));
+    cs = sa::fmax_nn(cs, 1e-20f);
+    const float inv = 1.0f / cs;
+    if (tid == 0) { params[0] = mnx; params[1] = mnz; params[2] = inv; params[3] = 0.0f; }
+
+    for (int k = tid; k < n; k += 1024) {
+        const int cx = min(kNX - 1, max(0, (int)((p[k * 3 + 0] - mnx) * inv)));
+        const int cz = min(kNX - 1, max(0, (int)((p[k * 3 + 2] - mnz) * inv)));
+        atomicAdd(&s_cnt[cz * kNX + cx], 1);
+    }
+    __syncthreads();
+    // exclusive scan of the 16384 counters: 16 consecutive cells per thread
+    int loc[16], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { loc[i] = s_cnt[tid * 16 + i]; sum += loc[i]; }
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(incl, d);
+        if (lane >= d) incl += y;
+    }
+    if (lane == 63) s_wsum[w] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int i = 0; i < w; ++i) woff += s_wsum[i];
+    int run = woff + incl - sum;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        cell_start[tid * 16 + i] = run;
+        s_cnt[tid * 16 + i] = run;          // becomes the scatter cursor
+        run += loc[i];
+    }
+    if (tid == 1023) cell_start[kNC] = run;
+    __syncthreads();
+    for (int k = tid; k < n; k += 1024) {
+        const int cx = min(kNX - 1, max(0, (int)((p[k * 3 + 0] - mnx) * inv)));
+        const int cz = min(kNX - 1, max(0, (int)((p[k * 3 + 2] - mnz) * inv)));
+        const int pos = atomicAdd(&s_cnt[cz * kNX + cx], 1);
+        sorted[pos] = k;
+    }
+}
+
+// ordered full scan of one query by one wave (the fallback; same logic as ballquery.hip); counts go to `fcnt`
+__device__ __noinline__ void scan_all(const GBands &B, const float *P, int n, float x2, float y2, float z2,
+                                      int (*rows)[kCap], int *fcnt, int lane) {
+    int c[kMaxBands] = {0, 0, 0, 0};
+    for (int base = 0; base < n; base += 64) {
+        const int k = base + lane;
+        const bool valid = k < n;
+        const int kk = valid ? k : n - 1;
+        const float dx = x2 - P[kk * 3 + 0], dy = y2 - P[kk * 3 + 1], dz = z2 - P[kk * 3 + 2];
+        const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));
+        bool full = true;
+#pragma unroll
+        for (int i = 0; i < kMaxBands; ++i) {
+            if (i >= B.nbands) break;
+            const int nsi = min(B.ns[i], kCap);
+            if (c[i] < nsi) {
+                const bool hit = valid && (B.dilated ? (d2 == 0.0f || (d2 >= B.tlo[i] && d2 < B.thi[i])) : (d2 < B.thi[i]));
+                const unsigned long long hm = __ballot(hit);
+                const int pos = c[i] + __popcll(hm & ((1ull << lane) - 1ull));
+                if (hit && pos < nsi) rows[i][pos] = k;
+                c[i] = min(nsi, c[i] + (int)__popcll(hm));
+            }
+            full = full && c[i] >= nsi;
+        }
+        if (full) break;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < kMaxBands; ++i) fcnt[i] = c[i];
+    }
+}
+
+__global__ __launch_bounds__(kQWaves * 64) void bq_grid_query_kernel(int n, int m, const float *__restrict__ xyz1,
+                                                                     const float *__restrict__ xyz2,
+                                                                     const int *__restrict__ ws, GBands B) {
+    __shared__ int s_hits[kQWaves][kMaxBands][kCap];
+    __shared__ int s_fcnt[kQWaves][kMaxBands];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float *P = xyz1 + (size_t)b * n * 3;
+    const int *cell_start = ws + (size_t)b * ws_stride(n);
+    const int *sorted = cell_start + (kNC + 1);
+    const float *params = (const float *)(sorted + n);
+    const float mnx = params[0], mnz = params[1], inv = params[2];
+    int (*hits)[kCap] = s_hits[w];
+
+    for (int q = blockIdx.x * kQWaves + w; q < m; q += gridDim.x * kQWaves) {
+        const size_t qi = (size_t)b * m + q;
+        const float x2 = xyz2[qi * 3 + 0], y2 = xyz2[qi * 3 + 1], z2 = xyz2[qi * 3 + 2];
+        const int cx = min(kNX - 1, max(0, (int)((x2 - mnx) * inv)));
+        const int cz = min(kNX - 1, max(0, (int)((z2 - mnz) * inv)));
+        const int x_lo = max(cx - 1, 0), x_hi = min(cx + 1, kNX - 1);
+        int cnts[kMaxBands] = {0, 0, 0, 0};
+        bool overflow = false;
+        for (int iz = max(cz - 1, 0); iz <= min(cz + 1, kNX - 1); ++iz) {
+            const int s = cell_start[iz * kNX + x_lo], e = cell_start[iz * kNX + x_hi + 1];   // 3 cells, one range
+            for (int pos0 = s; pos0 < e; pos0 += 64) {
+                const int pos = pos0 + lane;
+                const bool valid = pos < e;
+                const int k = sorted[valid ? pos : e - 1];
+                const float dx = x2 - P[k * 3 + 0], dy = y2 - P[k * 3 + 1], dz = z2 - P[k * 3 + 2];
+                const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));   // as ballquery.hip
+                if (__ballot(valid && d2 < B.thi_max) == 0ull) continue;
+#pragma unroll
+                for (int i = 0; i < kMaxBands; ++i) {
+                    if (i >= B.nbands) break;
+                    const bool hit = valid && (B.dilated ? (d2 == 0.0f || (d2 >= B.tlo[i] && d2 < B.thi[i])) : (d2 < B.thi[i]));
+                    const unsigned long long hm = __ballot(hit);
+                    if (hm != 0ull) {
+                        const int at = cnts[i] + __popcll(hm & ((1ull << lane) - 1ull));
+                        if (hit && at < kCap) hits[i][at] = k;
+                        cnts[i] += (int)__popcll(hm);
+                        overflow = overflow || cnts[i] > kCap;
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (overflow) {
+            // too many candidates for the LDS lists: ordered full scan, rows come out final (sorted, capped)
+            scan_all(B, P, n, x2, y2, z2, hits, s_fcnt[w], lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < kMaxBands; ++i) {
+                if (i >= B.nbands) break;
+                const int c = s_fcnt[w][i], nsi = B.ns[i];
+                for (int l = lane; l < nsi; l += 64) B.idx[i][qi * nsi + l] = c > 0 ? hits[i][l < c ? l : 0] : 0;
+                if (lane == 0) B.cnt[i][qi] = c;
+            }
+            continue;
+        }
+#pragma unroll
+        for (int i = 0; i < kMaxBands; ++i) {
+            if (i >= B.nbands) break;
+            const int H = cnts[i], nsi = B.ns[i];
+            const int c = min(H, nsi);
+            int *row = B.idx[i] + qi * nsi;
+            if (H == 0) {
+                for (int l = lane; l < nsi; l += 64) row[l] = 0;           // empty ball: zero row
+            } else {
+                // rank of every hit among the hits of this band; the nsample smallest indices fill slots 0..c-1
+                int kmin = 0x7FFFFFFF;
+                for (int h0 = 0; h0 < H; h0 += 64) {
+                    const int h = h0 + lane;
+                    const int k = h < H ? hits[i][h] : 0x7FFFFFFF;
+                    int rank = 0;
+                    for (int j = 0; j < H; ++j) rank += hits[i][j] < k ? 1 : 0;
+                    if (h < H && rank < nsi) row[rank] = k;
+                    kmin = min(kmin, k);
+                }
+                kmin = (int)sa::wave_allmin_u32((unsigned)kmin);
+                for (int l = c + lane; l < nsi; l += 64) row[l] = kmin;     // padding: the first hit
+            }
+            if (lane == 0) B.cnt[i][qi] = c;
+        }
+    }
+}
+
+float sqrt_ge_threshold_g(float r) {
+    if (!(r > 0.0f)) return 0.0f;
+    float x = r * r;
+    if (isinf(x)) return sqrtf(3.402823466e+38f) >= r ? 3.402823466e+38f : INFINITY;
+    while (sqrtf(x) < r) x = nextafterf(x, INFINITY);
+    while (x > 0.0f && sqrtf(nextafterf(x, 0.0f)) >= r) x = nextafterf(x, 0.0f);
+    return x;
+}
+
+}  // namespace
+
+// Bytes of device workspace sa_query_ball_point_grid needs for (b, n).
+extern "C" size_t sa_query_ball_point_grid_ws_bytes(int b, int n) {
+    return (size_t)b * (((size_t)(kNC + 1) + n + 4 + 3) / 4 * 4) * sizeof(int);
+}
+
+// Same contract as sa_query_ball_point_multi (all bands of one SA layer), through the grid.  `workspace` is
+// caller-owned device memory of sa_query_ball_point_grid_ws_bytes(b, n) bytes.  nbands <= 4.
+extern "C" int sa_query_ball_point_grid(int b, int n, int m, int nbands, const float *rmin, const float *rmax,
+                                        const int *ns, int dilated, const float *xyz1, const float *xyz2,
+                                        int *const *idx, int *const *cnt, void *workspace, hipStream_t stream) {
+    if (b <= 0 || n <= 0 || m <= 0 || nbands <= 0 || nbands > kMaxBands || !xyz1 || !xyz2 || !idx || !cnt || !workspace)
+        return SA_ERR_INVALID;
+    GBands B;
+    B.nbands = nbands;
+    B.dilated = dilated ? 1 : 0;
+    B.thi_max = 0.0f;
+    float rmax_all = 0.0f;
+    for (int i = 0; i < kMaxBands; ++i) {
+        const bool on = i < nbands;
+        if (on && (ns[i] <= 0 || !(rmax[i] > 0.0f))) return SA_ERR_INVALID;
+        if (on && dilated && rmin[i] < 0.0f) return SA_ERR_INVALID;
+        B.tlo[i] = on && dilated ? sqrt_ge_threshold_g(rmin[i]) : 0.0f;
+        B.thi[i] = on ? ((!dilated && rmax[i] <= 1e-20f) ? 0.0f : sqrt_ge_threshold_g(rmax[i])) : 0.0f;
+        B.ns[i] = on ? ns[i] : 0;
+        B.idx[i] = on ? idx[i] : nullptr;
+        B.cnt[i] = on ? cnt[i] : nullptr;
+        if (on && B.thi[i] > B.thi_max) B.thi_max = B.thi[i];
+        if (on && rmax[i] > rmax_all) rmax_all = rmax[i];
+    }
+    const float cell_min = rmax_all * 1.0001f + 1e-6f;
+    hipLaunchKernelGGL(bq_grid_build_kernel, dim3(b), dim3(1024), 0, stream, n, cell_min, xyz1, (int *)workspace);
+    SA_CHECK_LAUNCH();
+    int gx = (m + kQWaves - 1) / kQWaves;
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(bq_grid_query_kernel, dim3(gx, b), dim3(kQWaves * 64), 0, stream, n, m, xyz1, xyz2,
+                       (const int *)workspace, B);
+    SA_CHECK_LAUNCH();
+    return SA_OK;
+}

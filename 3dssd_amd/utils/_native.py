@@ -27,6 +27,7 @@ SIGNATURES = {
     "sa_fps_generic": [_c_int] * 4 + [_vp, _vp, _vp, _c_int, _vp],
     "sa_calc_square_dist_split": [_c_int] * 5 + [_vp, _vp, _vp, _vp, _vp, _vp],
     "sa_query_ball_point_multi": [_c_int] * 4 + [_vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _vp],
+    "sa_query_ball_point_grid": [_c_int] * 4 + [_vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _vp, _vp],
     "sa_group_mlp_max": [_c_int] * 5 + [_vp] * 5 + [_c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp],
     "sa_dense": [_c_long, _c_int, _c_int, _vp, _vp, _vp, _c_int, _vp, _vp],
     "sa_decode_anchor_free": [_c_int] * 4 + [_vp] * 7,
@@ -56,6 +57,8 @@ def lib():
             fn = getattr(h, name)  # AttributeError if the symbol is not exported
             fn.argtypes = argtypes
             fn.restype = _c_int
+        h.sa_query_ball_point_grid_ws_bytes.argtypes = [_c_int, _c_int]     # the one non-status function
+        h.sa_query_ball_point_grid_ws_bytes.restype = ctypes.c_size_t
         _LIB = h
     return _LIB
 

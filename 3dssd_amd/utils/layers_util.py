@@ -25,6 +25,8 @@ from .tf_ops.grouping.tf_grouping import query_ball_point, query_ball_point_dila
 # cfg.MODEL.NETWORK.AGGREGATION_SA_FEATURE and cfg.MODEL.MAX_TRANSLATE_RANGE of the reference's global
 # config (configs/kitti/3dssd/3dssd.yaml:39,44); set by the backbone driver.
 AGGREGATION_SA_FEATURE = True
+# frames with at least this many points go through the grid ball query (csrc/ballquery_grid.hip)
+GRID_BALL_QUERY_MIN_N = int(__import__("os").environ.get("SA_GRID_BQ_MIN_N", "2048"))
 MAX_TRANSLATE_RANGE = (-3.0, -2.0, -3.0)
 
 
@@ -184,8 +186,14 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
         nsa = (ctypes.c_int * nscale)(*[int(v) for v in nsample_list])
         idxp = (ctypes.c_void_p * nscale)(*[t.data_ptr() for t in idx_list])
         cntp = (ctypes.c_void_p * nscale)(*[t.data_ptr() for t in cnt_list])
-        st = lib.sa_query_ball_point_multi(bs, n_all, m, nscale, rmin, rmax, nsa, 1 if dilated_group else 0,
-                                           xyz.data_ptr(), new_xyz.data_ptr(), idxp, cntp, stream)
+        if n_all >= GRID_BALL_QUERY_MIN_N and nscale <= 4:
+            # large frames: per-frame x-z grid, candidates from the 3 x 3 cells around each centre (same outputs)
+            ws = torch.empty((lib.sa_query_ball_point_grid_ws_bytes(bs, n_all) + 3) // 4, dtype=torch.int32, device=dev)
+            st = lib.sa_query_ball_point_grid(bs, n_all, m, nscale, rmin, rmax, nsa, 1 if dilated_group else 0,
+                                              xyz.data_ptr(), new_xyz.data_ptr(), idxp, cntp, ws.data_ptr(), stream)
+        else:
+            st = lib.sa_query_ball_point_multi(bs, n_all, m, nscale, rmin, rmax, nsa, 1 if dilated_group else 0,
+                                               xyz.data_ptr(), new_xyz.data_ptr(), idxp, cntp, stream)
         N.check(st, "query_ball_point")
         # ---- per scale: fused mask/group/concat/MLP/max/mask (:157-181) into the concat buffer (:183)
         layers = [[vs.layer("%s/conv%d_%d" % (scope, i, j), bn) for j in range(len(mlp_list[i]))]

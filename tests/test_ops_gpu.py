@@ -354,3 +354,59 @@ def test_calc_square_dist_symmetric_path(gpu, oracle, n, c):
     got = M.calc_square_dist(ta, ta).cpu().numpy()
     assert np.array_equal(got, oracle.calc_square_dist(a, a))
     assert np.array_equal(got, got.transpose(0, 2, 1))
+
+
+def _run_grid_bq(gpu, xyz1, xyz2, rmins, rmaxs, nss, dilated):
+    import ctypes
+    N = pkg("utils._native")
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    nb = len(rmaxs)
+    t1, t2 = _t(xyz1, gpu), _t(xyz2, gpu)
+    idx = [torch.full((b, m, s), -5, dtype=torch.int32, device=gpu) for s in nss]
+    cnt = [torch.full((b, m), -5, dtype=torch.int32, device=gpu) for _ in nss]
+    ws = torch.empty((N.lib().sa_query_ball_point_grid_ws_bytes(b, n) + 3) // 4, dtype=torch.int32, device=gpu)
+    st = N.lib().sa_query_ball_point_grid(
+        b, n, m, nb, (ctypes.c_float * nb)(*rmins), (ctypes.c_float * nb)(*rmaxs), (ctypes.c_int * nb)(*nss), int(dilated),
+        t1.data_ptr(), t2.data_ptr(), (ctypes.c_void_p * nb)(*[t.data_ptr() for t in idx]),
+        (ctypes.c_void_p * nb)(*[t.data_ptr() for t in cnt]), ws.data_ptr(), N.current_stream())
+    assert st == 0
+    return [t.cpu().numpy() for t in idx], [t.cpu().numpy() for t in cnt]
+
+
+@pytest.mark.parametrize("n,m,scale,radii,nss,dil", [
+    (5000, 640, 5.0, [0.4, 0.8, 1.6], [32, 32, 64], True),
+    (16384, 1000, 30.0, [0.2, 0.4, 0.8], [32, 32, 64], True),
+    (3000, 300, 2.0, [1.5], [16], False),
+    (2048, 256, 1.0, [0.3, 5.0], [8, 100], True),          # second band larger than the whole cloud, nsample > 64
+    (700, 90, 3.0, [0.5, 1.0, 2.0, 3.0], [4, 8, 16, 32], True),
+])
+def test_grid_ball_query_matches_oracle(gpu, oracle, n, m, scale, radii, nss, dil):
+    rng = np.random.default_rng(n + m)
+    b = 2
+    xyz1 = _cloud(rng, b, n, scale=scale, dup=n // 10)
+    xyz1[:, :, 1] *= 0.1
+    inside = xyz1[:, rng.permutation(n)[:m - m // 4]]
+    outside = _cloud(rng, b, m // 4, scale=scale * 1.6)                   # centres outside the cloud's bounding box
+    xyz2 = np.concatenate([inside, outside], 1).astype(np.float32)
+    rmins = [0.0] + radii[:-1]
+    idx, cnt = _run_grid_bq(gpu, xyz1, xyz2, rmins, radii, nss, dil)
+    for i in range(len(radii)):
+        if dil:
+            ridx, rcnt = oracle.query_ball_point_dilated(rmins[i], radii[i], nss[i], xyz1, xyz2)
+        else:
+            ridx, rcnt = oracle.query_ball_point(radii[i], nss[i], xyz1, xyz2)
+        _check_ball(idx[i], cnt[i], ridx, rcnt)
+
+
+def test_grid_ball_query_overflow_falls_back_to_full_scan(gpu, oracle):
+    # a dense clump: > 512 candidates inside one ball -> the in-kernel ordered full scan path
+    rng = np.random.default_rng(77)
+    n, m = 4096, 64
+    xyz1 = rng.normal(0, 0.05, (1, n, 3)).astype(np.float32)
+    xyz1[:, 3000:] += 20.0
+    xyz2 = np.ascontiguousarray(xyz1[:, :m])
+    idx, cnt = _run_grid_bq(gpu, xyz1, xyz2, [0.0, 0.1], [0.1, 0.5], [64, 32], True)
+    for i, (a, r, s) in enumerate([(0.0, 0.1, 64), (0.1, 0.5, 32)]):
+        ridx, rcnt = oracle.query_ball_point_dilated(a, r, s, xyz1, xyz2)
+        _check_ball(idx[i], cnt[i], ridx, rcnt)
