@@ -26,7 +26,7 @@ from .tf_ops.grouping.tf_grouping import query_ball_point, query_ball_point_dila
 # config (configs/kitti/3dssd/3dssd.yaml:39,44); set by the backbone driver.
 AGGREGATION_SA_FEATURE = True
 # frames with at least this many points go through the grid ball query (csrc/ballquery_grid.hip)
-GRID_BALL_QUERY_MIN_N = int(__import__("os").environ.get("SA_GRID_BQ_MIN_N", "2048"))
+GRID_BALL_QUERY_MIN_N = int(__import__("os").environ.get("SA_GRID_BQ_MIN_N", "512"))
 MAX_TRANSLATE_RANGE = (-3.0, -2.0, -3.0)
 
 
