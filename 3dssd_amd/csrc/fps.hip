@@ -25,13 +25,25 @@ constexpr float kAbsent = -3.0e38f; // slot of a thread that owns no point: neve
 
 // Cross-wave stage shared by all three kernels.  Wave w has published (value, payload) in slot w of
 // buffer `par`; returns the payload of the winning wave to every thread.
+// BCAST: value and payload of slot lane&15 are requested together and the winner's payload is taken with
+// v_readlane (scalar result) -- one LDS round trip instead of two dependent ones.  Used where only the index is
+// consumed (distance-matrix / generic kernels, -4 % measured); the coordinate kernel keeps the second LDS read:
+// its payload feeds every VALU instruction of the next iteration, and a VALU instruction with an SGPR source
+// issues at half the rate of the all-VGPR form on gfx950 (tools/microbench/valu_rates.hip).
+template <bool BCAST>
 __device__ __forceinline__ float4 cross_wave_pick(const float (*s_val)[kWaves],
                                                   const float4 (*s_pt)[kWaves], int par, int lane) {
-    float v = s_val[par][lane & (kWaves - 1)];
-    float M = sa::row16_allmax(v);
-    unsigned long long eq = __ballot(v == M);
-    int ws = __builtin_ctzll(eq) & (kWaves - 1);   // lowest wave holding the maximum
-    return s_pt[par][ws];
+    const float v = s_val[par][lane & (kWaves - 1)];
+    float4 pt;
+    if (BCAST) pt = s_pt[par][lane & (kWaves - 1)];
+    const float M = sa::row16_allmax(v);
+    const unsigned long long eq = __ballot(v == M);
+    const int ws = __builtin_ctzll(eq) & (kWaves - 1);   // lowest wave holding the maximum
+    if (!BCAST) return s_pt[par][ws];
+    float4 r;
+    r.x = r.y = r.z = 0.0f;
+    r.w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pt.w), ws));
+    return r;
 }
 
 // ---- D-FPS, c == 3, n <= 1024*PPT, everything register resident ------------------------------
@@ -86,7 +98,7 @@ __global__ __launch_bounds__(kBlock) void fps3_reg_kernel(int n, int m, const fl
             s_pt[par][w] = make_float4(px[ju], py[ju], pz[ju], __int_as_float(t + kBlock * ju));
         }
         __syncthreads();
-        const float4 wp = cross_wave_pick(s_val, s_pt, par, lane);
+        const float4 wp = cross_wave_pick<false>(s_val, s_pt, par, lane);
         ox = wp.x; oy = wp.y; oz = wp.z;
         if (t == 0) o[it] = __float_as_int(wp.w) + idx_off;
     }
@@ -138,7 +150,7 @@ __global__ __launch_bounds__(kBlock) void fpsdist_reg_kernel(int n, int m,
             s_pt[par][w] = make_float4(0.f, 0.f, 0.f, __int_as_float(bk));
         }
         __syncthreads();
-        const float4 wp = cross_wave_pick(s_val, s_pt, par, lane);
+        const float4 wp = cross_wave_pick<true>(s_val, s_pt, par, lane);
         old = __builtin_amdgcn_readfirstlane(__float_as_int(wp.w));
         if (t == 0) o[it] = old + idx_off;
     }
@@ -193,7 +205,7 @@ __global__ __launch_bounds__(kBlock) void fps_generic_kernel(int n, int c, int m
             s_pt[par][w] = make_float4(0.f, 0.f, 0.f, __int_as_float(bk));
         }
         __syncthreads();
-        const float4 wp = cross_wave_pick(s_val, s_pt, par, lane);
+        const float4 wp = cross_wave_pick<true>(s_val, s_pt, par, lane);
         old = __builtin_amdgcn_readfirstlane(__float_as_int(wp.w));
         if (t == 0) o[it] = old + idx_off;
     }
@@ -216,11 +228,9 @@ extern "C" int sa_fps_bucket_ex(int b, int n, int m, const float *inp, int *out,
 extern "C" int sa_fps_ex(int b, int n, int c, int m, const float *inp, float *temp, int *out,
                          int out_stride, int idx_off, hipStream_t stream) {
     if (b <= 0 || n <= 0 || c <= 0 || m <= 0 || !inp || !out || out_stride < m) return SA_ERR_INVALID;
-    // Experimental: the bucket-culled kernel (fps_bucket.hip), bit-identical output.  It skips ~99% of the
-    // distance evaluations but measured no faster than the plain kernel on MI355X (the iteration is bound by
-    // the serial reduce/exchange chain of the one wave that still has work, not by VALU throughput), so it
-    // is off by default.  SA_FPS_BUCKET_MIN_N = smallest n it is used for (0 = never).
-    static const int bucket_min_n = getenv("SA_FPS_BUCKET_MIN_N") ? atoi(getenv("SA_FPS_BUCKET_MIN_N")) : 0;
+    // Layer-1 shape: the wave-bucket culled kernel (fps_bucket.hip), bit-identical output, ~1.4x faster than the
+    // plain kernel at 16384 -> 4096.  SA_FPS_BUCKET_MIN_N = smallest n it is used for (0 = never).
+    static const int bucket_min_n = getenv("SA_FPS_BUCKET_MIN_N") ? atoi(getenv("SA_FPS_BUCKET_MIN_N")) : 8192;
     if (c == 3 && bucket_min_n > 0 && n >= bucket_min_n && n <= 16384 && m >= 64)
         return sa_fps_bucket_ex(b, n, m, inp, out, out_stride, idx_off, stream);
     const int ppt = ppt_for(n);

@@ -1,30 +1,39 @@
-// D-FPS with spatial culling, n <= 16384 (the layer-1 shape, 16384 -> 4096).
+// D-FPS with spatial culling at WAVE granularity, n <= 16384 (the layer-1 shape, 16384 -> 4096).
 //
-// The running min-distance td[k] of a point only changes when the newly selected point is closer to it
-// than every earlier pick, i.e. within sqrt(td[k]).  After the first few dozen picks that is a small
-// neighbourhood, yet the plain kernel (fps.hip, like the reference) re-evaluates all n distances in each
-// of the m-1 dependent iterations.  Here the frame is first sorted along a Morton curve (bitonic sort in
-// LDS, inside the same kernel) and every thread owns 16 CONSECUTIVE sorted points -- a compact bucket with
-// its own bounding box.  A thread re-evaluates its bucket in an iteration only if the box's lower-bound
-// distance to the new point is below the bucket's current maximum of td; otherwise its cached
-// (max, arg-max) is still exact.  A wave whose 64 buckets are all skipped spends ~15 VALU instructions in
-// that iteration instead of ~180.
-//
-// Exactness: the skip test is conservative (relative margin 1e-5 against the <= 8 ulp error of the fp32
-// chains), every evaluated distance uses exactly the arithmetic of fps.hip, and ties are broken with the
-// reference's (k mod 1024, k) order on the ORIGINAL indices carried as 32-bit tie keys (each thread keeps
-// its 16 points sorted by that key, so "first strict maximum" inside a thread is the key order), so the
-// output is bit-identical to the plain kernel and to the oracle -- the spatial order only affects speed.
+// The running min-distance td[k] of a point only changes when the newly selected point is closer to it than
+// every earlier pick, i.e. within sqrt(td[k]).  After the first few dozen picks that is a small neighbourhood,
+// yet the plain kernel (fps.hip, like the reference) re-evaluates all n distances in each of the m-1 dependent
+// iterations (~2500 cycles per iteration on one CU, measured).  Here:
+//   * the frame is sorted along a Morton curve in the x-z plane (bitonic sort in LDS, inside the kernel) and cut
+//     into 64 buckets of 256 consecutive points; a bucket lives in ONE wave (4 points per lane, registers:
+//     coordinates, td and tie keys) and has a bounding box.  Bucket b belongs to wave b mod 8, so that the
+//     neighbouring buckets a pick usually touches are re-evaluated by different waves in parallel;
+//   * a 64-entry table in LDS holds every bucket's current (max td, tie key of its arg-max, arg-max xyz).  An
+//     iteration is: every wave reads the table (lane b <-> bucket b), takes the global arg-max with one wave
+//     reduction, tests all 64 boxes against the new point in one lane-parallel pass, and re-evaluates only the
+//     buckets it owns whose box lower bound is below their max td -- typically one or two buckets of the whole
+//     frame.  One barrier per iteration (the table is double buffered; untouched entries are copied forward by
+//     their owner).
+// Exactness: the skip test is conservative (the lower bound uses the same monotone fp32 operation chain as the
+// distance itself, plus a 1e-5 relative margin), every evaluated distance uses exactly the arithmetic of fps.hip,
+// and ties are broken with the reference's (k mod 1024, k) order (tf_sampling_g.cu:142,154-171) on the ORIGINAL
+// indices, carried as 32-bit tie keys: the four slots of a lane are ordered by tie key so "first strict maximum"
+// inside a lane is the key order, equal wave / table maxima are resolved by the minimum key.  The output is
+// bit-identical to the plain kernel and to the oracle -- the spatial order only affects speed.
 #include "sa_common.h"
 
 namespace {
 
-constexpr int kBW = 16;                // waves
-constexpr int kBThreads = kBW * 64;    // 1024
-constexpr int kPPT = 16;               // points per thread = bucket size
-constexpr int kCap = kBThreads * kPPT; // 16384 points
+constexpr int kW = 8;                  // waves per workgroup (2 per SIMD)
+constexpr int kT = kW * 64;            // 512 threads
+constexpr int kNB = 64;                // buckets == table entries == lanes of a wave
+constexpr int kBPW = kNB / kW;         // buckets owned by a wave
+constexpr int kSL = 4;                 // points per lane per bucket
+constexpr int kBS = 64 * kSL;          // points per bucket
+constexpr int kCap = kNB * kBS;        // 16384 points
+constexpr int kPPT = kBPW * kSL;       // 32 points per thread
 constexpr float kInitTd = 1e38f;       // tf_sampling_g.cu:136
-constexpr float kGone = -3.0e38f;      // padding slots: never selected, never updated
+constexpr float kGone = -3.0e38f;      // padding slots / empty buckets: never selected, never updated
 constexpr float kSkipMargin = 1.0f - 1e-5f;
 constexpr unsigned kNoKey = 0xFFFFFFFFu;
 
@@ -40,24 +49,41 @@ __device__ __forceinline__ float wave_allmin_f(float x) { return -sa::wave_allma
 // reference tie order (k mod 1024, k) as one unsigned key, and back
 __device__ __forceinline__ unsigned tie_key(unsigned k) { return ((k & 1023u) << 16) | (k >> 10); }
 __device__ __forceinline__ unsigned tie_key_index(unsigned t) { return ((t >> 16) & 1023u) | ((t & 0xFFFFu) << 10); }
+__device__ __forceinline__ float bcast(float x, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l));
+}
 
-__global__ __launch_bounds__(kBThreads) void fps3_bucket_kernel(int n, int m, const float *__restrict__ inp,
-                                                                int *__restrict__ out, int out_stride,
-                                                                int idx_off) {
+#ifdef SA_FPSB_PROF
+// debug build only (tools/fps_bucket_prof.py): per-phase clocks of wave 0 / of the waves that had work
+__device__ unsigned long long g_fpsb_prof[16];
+#define FP_T(i) { const unsigned long long n__ = __builtin_readcyclecounter(); pacc[i] += n__ - pt0; pt0 = n__; }
+#else
+#define FP_T(i)
+#endif
+
+struct Table {
+    float val[2][kNB];
+    unsigned key[2][kNB];
+    float4 pt[2][kNB];
+};
+
+__global__ __launch_bounds__(kT) void fps3_wave_bucket_kernel(int n, int m, const float *__restrict__ inp,
+                                                             int *__restrict__ out, int out_stride,
+                                                             int idx_off) {
     __shared__ unsigned s_sorted[kCap];          // (morton << 14) | original index, ascending; 64 KiB;
-                                                 // afterwards: tie key of (thread t, slot j) at [t*16 + j]
-    __shared__ float s_red[4][kBW];
-    __shared__ float s_val[2][kBW];
-    __shared__ unsigned s_key[2][kBW];
-    __shared__ float4 s_pt[2][kBW];
+
+    __shared__ float s_red[4][kW];
+    __shared__ float s_box[6][kNB];
+    __shared__ Table s_tbl;
     const int bidx = blockIdx.x;
     const float *p = inp + (size_t)bidx * n * 3;
     int *o = out + (size_t)bidx * out_stride;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // ---- frame bounding box in x and z (the Morton plane; LiDAR frames are flat in y)
     float mnx = 3e38f, mxx = -3e38f, mnz = 3e38f, mxz = -3e38f;
-    for (int k = tid; k < n; k += kBThreads) {
+    for (int k = tid; k < n; k += kT) {
         const float x = p[k * 3 + 0], z = p[k * 3 + 2];
         mnx = sa::fmin_nn(mnx, x); mxx = sa::fmax_nn(mxx, x);
         mnz = sa::fmin_nn(mnz, z); mxz = sa::fmax_nn(mxz, z);
@@ -68,7 +94,7 @@ __global__ __launch_bounds__(kBThreads) void fps3_bucket_kernel(int n, int m, co
     __syncthreads();
     mnx = s_red[0][0]; mxx = s_red[1][0]; mnz = s_red[2][0]; mxz = s_red[3][0];
 #pragma unroll
-    for (int i = 1; i < kBW; ++i) {
+    for (int i = 1; i < kW; ++i) {
         mnx = sa::fmin_nn(mnx, s_red[0][i]); mxx = sa::fmax_nn(mxx, s_red[1][i]);
         mnz = sa::fmin_nn(mnz, s_red[2][i]); mxz = sa::fmax_nn(mxz, s_red[3][i]);
     }
@@ -76,7 +102,7 @@ __global__ __launch_bounds__(kBThreads) void fps3_bucket_kernel(int n, int m, co
     const float sclz = 511.0f / sa::fmax_nn(mxz - mnz, 1e-20f);
 
     // ---- Morton keys, bitonic sort in LDS (padding keys 0xFFFFFFFF sort to the end)
-    for (int k = tid; k < kCap; k += kBThreads) {
+    for (int k = tid; k < kCap; k += kT) {
         unsigned key = kNoKey;
         if (k < n) {
             const int qx = min(511, max(0, (int)((p[k * 3 + 0] - mnx) * sclx)));
@@ -88,7 +114,7 @@ __global__ __launch_bounds__(kBThreads) void fps3_bucket_kernel(int n, int m, co
     __syncthreads();
     for (int kk = 2; kk <= kCap; kk <<= 1) {
         for (int j = kk >> 1; j > 0; j >>= 1) {
-            for (int q = tid; q < kCap / 2; q += kBThreads) {
+            for (int q = tid; q < kCap / 2; q += kT) {
                 const int i = ((q & ~(j - 1)) << 1) | (q & (j - 1));
                 const int l = i | j;
                 const unsigned a = s_sorted[i], b = s_sorted[l];
@@ -99,126 +125,179 @@ __global__ __launch_bounds__(kBThreads) void fps3_bucket_kernel(int n, int m, co
         }
     }
 
-    // ---- my bucket: sorted positions tid*16 .. +15, re-ordered inside the thread by tie key
-    unsigned TK[kPPT];
+    // ---- my points: bucket 8i+w, sorted positions (8i+w)*256 + 4*lane + s; the four slots of a lane are then
+    //      re-ordered by tie key (kept in registers).
+    typedef float vecf __attribute__((ext_vector_type(kPPT)));
+    typedef unsigned vecu __attribute__((ext_vector_type(kPPT)));
+    vecf X, Y, Z, TD;
+    vecu TK;
+    const int pos0 = w * kBS + lane * kSL;
 #pragma unroll
-    for (int j = 0; j < kPPT; ++j) {
-        const unsigned pk = s_sorted[tid * kPPT + j];
-        TK[j] = pk == kNoKey ? kNoKey : tie_key(pk & 0x3FFFu);
-    }
+    for (int i = 0; i < kBPW; ++i) {
+        unsigned tk[kSL];
 #pragma unroll
-    for (int r = 0; r < kPPT; ++r) {               // odd-even transposition sort, ascending tie key
+        for (int s = 0; s < kSL; ++s) {
+            const unsigned pk = s_sorted[pos0 + i * kW * kBS + s];
+            tk[s] = pk == kNoKey ? kNoKey : tie_key(pk & 0x3FFFu);
+        }
+        // 4-element sorting network, ascending
+#define SA_CSWAP(a, b) { const unsigned x_ = tk[a], y_ = tk[b]; tk[a] = x_ < y_ ? x_ : y_; tk[b] = x_ < y_ ? y_ : x_; }
+        SA_CSWAP(0, 1) SA_CSWAP(2, 3) SA_CSWAP(0, 2) SA_CSWAP(1, 3) SA_CSWAP(1, 2)
+#undef SA_CSWAP
+        float bx0 = 3e38f, bx1 = -3e38f, by0 = 3e38f, by1 = -3e38f, bz0 = 3e38f, bz1 = -3e38f;
 #pragma unroll
-        for (int j = (r & 1); j + 1 < kPPT; j += 2) {
-            const unsigned a = TK[j], b = TK[j + 1];
-            TK[j] = a < b ? a : b;
-            TK[j + 1] = a < b ? b : a;
+        for (int s = 0; s < kSL; ++s) {
+            TK[i * kSL + s] = tk[s];
+            const bool ok = tk[s] != kNoKey;
+            const unsigned k = ok ? tie_key_index(tk[s]) : 0u;
+            const float x = p[k * 3 + 0], y = p[k * 3 + 1], z = p[k * 3 + 2];
+            X[i * kSL + s] = x; Y[i * kSL + s] = y; Z[i * kSL + s] = z;
+            TD[i * kSL + s] = ok ? kInitTd : kGone;
+            if (ok) {
+                bx0 = sa::fmin_nn(bx0, x); bx1 = sa::fmax_nn(bx1, x);
+                by0 = sa::fmin_nn(by0, y); by1 = sa::fmax_nn(by1, y);
+                bz0 = sa::fmin_nn(bz0, z); bz1 = sa::fmax_nn(bz1, z);
+            }
+        }
+        bx0 = wave_allmin_f(bx0); bx1 = sa::wave_allmax(bx1);
+        by0 = wave_allmin_f(by0); by1 = sa::wave_allmax(by1);
+        bz0 = wave_allmin_f(bz0); bz1 = sa::wave_allmax(bz1);
+        if (lane == 0) {
+            const int b = i * kW + w;
+            s_box[0][b] = bx0; s_box[1][b] = bx1; s_box[2][b] = by0;
+            s_box[3][b] = by1; s_box[4][b] = bz0; s_box[5][b] = bz1;
         }
     }
-    __syncthreads();                               // everybody has read its Morton keys
-#pragma unroll
-    for (int j = 0; j < kPPT; ++j) s_sorted[tid * kPPT + j] = TK[j];   // now: tie keys
-    const unsigned anyk = TK[0] == kNoKey ? 0u : tie_key_index(TK[0]);  // a real point of this bucket (or 0)
-    float X[kPPT], Y[kPPT], Z[kPPT], TD[kPPT];
-    float bx0 = 3e38f, bx1 = -3e38f, by0 = 3e38f, by1 = -3e38f, bz0 = 3e38f, bz1 = -3e38f;
-#pragma unroll
-    for (int j = 0; j < kPPT; ++j) {
-        const bool ok = TK[j] != kNoKey;
-        const unsigned k = ok ? tie_key_index(TK[j]) : anyk;
-        X[j] = p[k * 3 + 0];
-        Y[j] = p[k * 3 + 1];
-        Z[j] = p[k * 3 + 2];
-        TD[j] = ok ? kInitTd : kGone;
-        bx0 = sa::fmin_nn(bx0, X[j]); bx1 = sa::fmax_nn(bx1, X[j]);
-        by0 = sa::fmin_nn(by0, Y[j]); by1 = sa::fmax_nn(by1, Y[j]);
-        bz0 = sa::fmin_nn(bz0, Z[j]); bz1 = sa::fmax_nn(bz1, Z[j]);
-    }
-    // bucket state: its maximum of td and where it is (slot with the smallest tie key among equals)
-    float best = TK[0] != kNoKey ? kInitTd : kGone;
-    int bj = 0;
+    __syncthreads();
+    // lane b of EVERY wave holds the box of bucket b (an empty bucket has an inverted box and val = kGone)
+    const float bx0 = s_box[0][lane], bx1 = s_box[1][lane], by0 = s_box[2][lane];
+    const float by1 = s_box[3][lane], bz0 = s_box[4][lane], bz1 = s_box[5][lane];
+    // register copy of the table entry of bucket `lane`
+    float val = bx0 <= bx1 ? kInitTd : kGone;
+    unsigned key = kNoKey;
+    float4 pt = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool owner = (lane & (kW - 1)) == w;    // buckets w, w+8, ..., w+56
 
     float ox = p[0], oy = p[1], oz = p[2];         // old = 0, tf_sampling_g.cu:130-133
     if (tid == 0) o[0] = idx_off;
-    // this wave's published candidate (wave-uniform), re-derived only when one of its buckets changed
-    float pubM = kGone, pubX = 0.f, pubY = 0.f, pubZ = 0.f;
-    unsigned pubKey = kNoKey;
-    bool first = true;
 
+#ifdef SA_FPSB_PROF
+    unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt0 = __builtin_readcyclecounter(), pact = 0, pmine = 0, pbusy = 0;
+#endif
     for (int it = 1; it < m; ++it) {
-        // ---- can my bucket change?  lower bound of the distance from the new point to the bucket's box
+        const int par = it & 1;
+        // ---- which buckets can change?  lower bound of the distance from the new point to each box
         const float ex = sa::fmax_nn(sa::fmax_nn(bx0 - ox, ox - bx1), 0.0f);
         const float ey = sa::fmax_nn(sa::fmax_nn(by0 - oy, oy - by1), 0.0f);
         const float ez = sa::fmax_nn(sa::fmax_nn(bz0 - oz, oz - bz1), 0.0f);
         const float lb = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
-        const bool need = lb * kSkipMargin < best;
-        const bool touched = __ballot(need) != 0ull;
-        if (touched) {
-            if (need) {
+        const bool need = lb * kSkipMargin < val;
+        const unsigned long long act = __ballot(need);
+        const unsigned long long mine = (act >> w) & 0x0101010101010101ull;   // bit 8i <-> my bucket 8i+w
+#ifdef SA_FPSB_PROF
+        pact += __builtin_popcountll(act); pmine += __builtin_popcountll(mine); pbusy += mine != 0;
+#endif
+        FP_T(0)
+        // ---- re-evaluate my active buckets and publish their new entries
+#pragma unroll
+        for (int i = 0; i < kBPW; ++i) {
+            if ((mine >> (8 * i)) & 1ull) {
                 float nb = -1.0f;                   // tf_sampling_g.cu:141
                 int nj = 0;
+                // (packed v_pk_*_f32 arithmetic was tried here: the aligned register pairs it needs made the
+                //  kernel spill and it measured 10 % slower)
 #pragma unroll
-                for (int j = 0; j < kPPT; ++j) {
-                    const float dx = X[j] - ox, dy = Y[j] - oy, dz = Z[j] - oz;
+                for (int s = 0; s < kSL; ++s) {
+                    const int r = i * kSL + s;
+                    const float dx = X[r] - ox, dy = Y[r] - oy, dz = Z[r] - oz;
                     const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));   // as fps.hip
-                    const float t2 = sa::fmin_nn(d, TD[j]);
-                    TD[j] = t2;
+                    const float t2 = sa::fmin_nn(d, TD[r]);
+                    TD[r] = t2;
                     const bool g = t2 > nb;         // strict: the smallest tie key among equal maxima
                     nb = g ? t2 : nb;
-                    nj = g ? j : nj;
+                    nj = g ? s : nj;
                 }
-                best = nb;
-                bj = nj;
-            }
-        }
-        if (touched || first) {
-            // ---- this wave's candidate: maximum td, ties by tie key
-            first = false;
-            const float Mw = sa::wave_allmax(best);
-            const unsigned long long cand = __ballot(best == Mw);
-            unsigned mykey = kNoKey;
-            if (best == Mw) mykey = s_sorted[tid * kPPT + bj];
-            const unsigned kmin = sa::wave_allmin_u32(mykey);
-            const int wl = __builtin_ctzll(__ballot(mykey == kmin && best == Mw) | (cand == 0ull ? 1ull : 0ull));
-            float cx = X[0], cy = Y[0], cz = Z[0];
+                const float Mw = sa::wave_allmax(nb);
+                unsigned long long cand = __ballot(nb == Mw);
+                unsigned tkw = TK[i * kSL];
 #pragma unroll
-            for (int j = 1; j < kPPT; ++j) {
-                const bool sel = bj == j;
-                cx = sel ? X[j] : cx; cy = sel ? Y[j] : cy; cz = sel ? Z[j] : cz;
+                for (int s = 1; s < kSL; ++s) tkw = nj == s ? TK[i * kSL + s] : tkw;
+                if (__builtin_popcountll(cand) > 1) {           // equal maxima in several lanes: minimum tie key
+                    const unsigned mykey = nb == Mw ? tkw : kNoKey;
+                    const unsigned kmin = sa::wave_allmin_u32(mykey);
+                    cand = __ballot(mykey == kmin);             // keys are unique
+                }
+                const int wl = __builtin_ctzll(cand);
+                if (lane == wl) {
+                    float cx = X[i * kSL], cy = Y[i * kSL], cz = Z[i * kSL];
+#pragma unroll
+                    for (int s = 1; s < kSL; ++s) {
+                        const bool sel = nj == s;
+                        cx = sel ? X[i * kSL + s] : cx; cy = sel ? Y[i * kSL + s] : cy; cz = sel ? Z[i * kSL + s] : cz;
+                    }
+                    const int b = i * kW + w;
+                    s_tbl.val[par][b] = Mw;
+                    s_tbl.key[par][b] = tkw;
+                    s_tbl.pt[par][b] = make_float4(cx, cy, cz, 0.0f);
+                }
             }
-            pubM = Mw;
-            pubKey = kmin;
-            pubX = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cx), wl));
-            pubY = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cy), wl));
-            pubZ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cz), wl));
         }
-        const int par = it & 1;
-        if (lane == 0) {
-            s_val[par][w] = pubM;
-            s_key[par][w] = pubKey;
-            s_pt[par][w] = make_float4(pubX, pubY, pubZ, 0.0f);
+        FP_T(1)
+        // ---- carry my untouched entries forward into this iteration's buffer
+        if (owner && !need) {
+            s_tbl.val[par][lane] = val;
+            s_tbl.key[par][lane] = key;
+            s_tbl.pt[par][lane] = pt;
         }
+        FP_T(2)
         __syncthreads();
-        // ---- cross-wave: maximum value, then minimum tie key among the waves that hold it
-        const float v = s_val[par][lane & (kBW - 1)];
-        const unsigned kq = s_key[par][lane & (kBW - 1)];
-        const float M = sa::row16_allmax(v);
-        const unsigned kmn = sa::row16_allmin_u32(v == M ? kq : kNoKey);
-        const unsigned long long eq = __ballot(v == M && kq == kmn);
-        const int ws = __builtin_ctzll(eq) & (kBW - 1);
-        const float4 wp = s_pt[par][ws];
-        ox = wp.x; oy = wp.y; oz = wp.z;
-        if (tid == 0) o[it] = (int)tie_key_index(__builtin_amdgcn_readfirstlane(kmn)) + idx_off;
+        FP_T(3)
+        // ---- global arg-max over the 64 buckets: maximum value, then minimum tie key
+        val = s_tbl.val[par][lane];
+        key = s_tbl.key[par][lane];
+        pt = s_tbl.pt[par][lane];
+        const float M = sa::wave_allmax(val);
+        unsigned long long eq = __ballot(val == M);
+        if (__builtin_popcountll(eq) > 1) {
+            const unsigned kmn = sa::wave_allmin_u32(val == M ? key : kNoKey);
+            eq = __ballot(val == M && key == kmn);
+        }
+        const int bl = __builtin_ctzll(eq);
+        ox = bcast(pt.x, bl); oy = bcast(pt.y, bl); oz = bcast(pt.z, bl);
+        // VGPR copies: an SGPR source halves the issue rate of the distance instructions (valu_rates.hip)
+        asm volatile("" : "+v"(ox), "+v"(oy), "+v"(oz));
+        if (tid == 0) o[it] = (int)tie_key_index((unsigned)__builtin_amdgcn_readlane((int)key, bl)) + idx_off;
+        FP_T(4)
     }
+#ifdef SA_FPSB_PROF
+    if (bidx == 0 && lane == 0) {
+        if (w == 0) { for (int i = 0; i < 5; ++i) g_fpsb_prof[i] = pacc[i]; g_fpsb_prof[5] = pact; }
+        atomicAdd(&g_fpsb_prof[6], pmine); atomicAdd(&g_fpsb_prof[7], pbusy);
+        atomicAdd(&g_fpsb_prof[8], pacc[1]); atomicAdd(&g_fpsb_prof[9], pacc[3]);
+    }
+#endif
 }
 
 }  // namespace
 
-// D-FPS on coordinates with bucket culling; same contract as sa_fps_ex with c == 3, n <= 16384.
+// D-FPS on coordinates with wave-bucket culling; same contract as sa_fps_ex with c == 3, n <= 16384.
 extern "C" int sa_fps_bucket_ex(int b, int n, int m, const float *inp, int *out, int out_stride, int idx_off,
                                 hipStream_t stream) {
     if (b <= 0 || n <= 0 || n > kCap || m <= 0 || !inp || !out || out_stride < m) return SA_ERR_INVALID;
-    hipLaunchKernelGGL(fps3_bucket_kernel, dim3(b), dim3(kBThreads), 0, stream, n, m, inp, out, out_stride,
+    hipLaunchKernelGGL(fps3_wave_bucket_kernel, dim3(b), dim3(kT), 0, stream, n, m, inp, out, out_stride,
                        idx_off);
     SA_CHECK_LAUNCH();
     return SA_OK;
 }
+
+#ifdef SA_FPSB_PROF
+extern "C" int sa_debug_fpsb_prof(unsigned long long *host16, int reset) {
+    if (host16 && hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_fpsb_prof), sizeof(g_fpsb_prof)) != hipSuccess) return SA_ERR_LAUNCH;
+    if (reset) {
+        void *d = nullptr;
+        if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_fpsb_prof)) != hipSuccess) return SA_ERR_LAUNCH;
+        if (hipMemset(d, 0, sizeof(g_fpsb_prof)) != hipSuccess) return SA_ERR_LAUNCH;
+    }
+    return SA_OK;
+}
+#endif
