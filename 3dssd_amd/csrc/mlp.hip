@@ -891,6 +891,12 @@ int roundup(int x, int q) { return (x + q - 1) / q * q; }
 
 }  // namespace
 
+// mlp_rowwave.hip: LDS-resident-weight / register-resident-activation kernel for the narrow and mid scales
+int sa_rowwave_try(int b, int n, int m, int ns, int c, const float *xyz, const float *feat, const float *new_xyz,
+                   const int *idx, const int *cnt, int nl, const int *dims, const void *const *wpack,
+                   const float *const *bias, float *out, int out_stride, int out_off, hipStream_t stream,
+                   int *st);
+
 // One scale of an SA layer.  Layer l: wpack[l] (device, fragment-packed hi/lo bf16, see header),
 // bias[l] (device, fp32, zero-padded to a multiple of 32), dims[0] = C+3, dims[l+1] = output channels.
 // out[(b*m + j)*out_stride + out_off + c] receives the pooled channel c.  Additional to the reference
@@ -903,6 +909,14 @@ extern "C" int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float 
     if (!xyz || !new_xyz || !idx || !cnt || !out || !dims || !wpack || !bias) return SA_ERR_INVALID;
     if (c > 0 && !feat) return SA_ERR_INVALID;
     if (dims[0] != c + 3) return SA_ERR_INVALID;
+    for (int l = 0; l < nl; ++l)
+        if (dims[l + 1] <= 0 || !wpack[l] || !bias[l]) return SA_ERR_INVALID;
+    {
+        int st = SA_OK;
+        if (sa_rowwave_try(b, n, m, ns, c, xyz, feat, new_xyz, idx, cnt, nl, dims, wpack, bias, out, out_stride,
+                           out_off, stream, &st))
+            return st;
+    }
     MlpParams P{};
     P.xyz = xyz; P.feat = feat; P.new_xyz = new_xyz; P.idx = idx; P.cnt = cnt; P.out = out;
     P.n = n; P.m = m; P.ns = ns; P.C = c; P.nballs = (long)b * m;

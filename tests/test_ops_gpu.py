@@ -251,6 +251,30 @@ def test_group_mlp_max(gpu, oracle, c, ns, dims):
     assert (got[cnt == 0] == 0).all()
 
 
+@pytest.mark.parametrize("c,ns,dims,m", [(1, 8, [16, 16, 32], 45), (1, 16, [32, 32, 64], 45), (1, 20, [16, 16, 32], 33),
+                                         (8, 32, [12, 16, 20], 45), (64, 16, [64, 64, 128], 45),
+                                         (64, 48, [64, 96, 128], 29), (64, 96, [64, 64, 128], 7),
+                                         (64, 32, [40, 50, 100], 300), (1, 64, [32, 32, 64], 1100)])
+def test_group_mlp_max_rowwave_shapes(gpu, oracle, c, ns, dims, m):
+    # the LDS-resident-weight / register-resident-activation kernel (mlp_rowwave.hip): every pooling layout
+    # (4, 2, 1 balls per 32-row tile, 2 and 3 tiles per ball), padded channel counts, ragged ball counts and
+    # enough balls for several tiles per wave (software-pipelined gathers)
+    rng = np.random.default_rng(c * 1000 + ns + m)
+    b, n = 2, 600
+    xyz = _cloud(rng, b, n, scale=4.0)
+    feat = rng.normal(0, 1, (b, n, c)).astype(np.float32)
+    new_xyz = xyz[:, rng.integers(0, n, m)] + rng.normal(0, 0.1, (b, m, 3)).astype(np.float32)
+    idx = rng.integers(0, n, (b, m, ns)).astype(np.int32)
+    cnt = rng.integers(0, ns + 1, (b, m)).astype(np.int32)
+    cnt[:, ::5] = 0
+    ws, bs = _rand_layers(rng, [c + 3] + dims)
+    got = _run_group_mlp(gpu, xyz, feat, new_xyz, idx, cnt, ws, bs)
+    ref = oracle.group_mlp_max(xyz, feat, new_xyz, idx, cnt, ws, bs)
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    assert err < MLP_TOL, "relative error %g" % err
+    assert (got[cnt == 0] == 0).all()
+
+
 def test_group_mlp_max_identity_layout_probe(gpu):
     # asymmetric probe of the MFMA operand/accumulator mapping: one layer whose weight matrix selects
     # and scales single input channels, so any row/column/transposition mix-up shows up exactly
