@@ -35,6 +35,8 @@ struct RwParams {
     int out_stride, out_off;
     int rp;        // rows per ball after padding: 8, 16, 32 or a multiple of 32
     int rp_shift;  // log2(rp) when rp <= 32
+    int m_shift;   // log2(m) when m is a power of two, else -1
+    float inv_m;
     int N3;        // true output channels of the last layer
     int ntiles;    // 32-row tiles
     int tpu;       // tiles per pooling unit (rp / 32 when rp > 32, else 1)
@@ -64,23 +66,45 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4 &hi, uint4 &lo
     split2(v[6], v[7], hi.w, lo.w);
 }
 
+#ifdef SA_RW_TIMING
+// debug build only (tools/rw_phase_prof.py): per-wave phase clocks, one row of 8 per wave, summed on the host
+__device__ unsigned long long g_rw_prof[65536 * 8];
+#define RW_T0() unsigned long long t__ = __builtin_readcyclecounter(), acc__[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define RW_TICK(i) { const unsigned long long n__ = __builtin_readcyclecounter(); acc__[i] += n__ - t__; t__ = n__; }
+#define RW_COUNT() acc__[7]++
+#define RW_FLUSH(wave) if (lane == 0) { unsigned long long *r__ = g_rw_prof + (size_t)((wave) & 65535) * 8; for (int i__ = 0; i__ < 8; ++i__) r__[i__] += acc__[i__]; }
+#else
+#define RW_T0()
+#define RW_TICK(i)
+#define RW_COUNT()
+#define RW_FLUSH(wave)
+#endif
+
 struct RowRef { int pt, ball, cnt; };   // source point (flat index), ball and its count for this lane's row
 
-// (ball, sample) of tile T, row r  ->  source point; both loads issue together
-// unit u (a ball when rp > 32, else the tile itself), tile tp of the unit
+// All element offsets on this path fit 32 bits (checked on the host), so every access is base pointer (SGPR
+// pair) + 32-bit lane offset: no 64-bit address arithmetic on the VALU.
+// unit u (a ball when rp > 32, else the tile itself), tile tp of the unit, row of the tile -> source point;
+// the index and count loads issue together
 __device__ __forceinline__ RowRef load_row_ref(const RwParams &P, int u, int tp, int row) {
-    long ball;
-    int s;
-    if (P.rp <= 32) { const int bl = row >> P.rp_shift; ball = ((long)u << (5 - P.rp_shift)) + bl; s = row - (bl << P.rp_shift); }
+    int ball, s;
+    if (P.rp <= 32) { const int bl = row >> P.rp_shift; ball = (u << (5 - P.rp_shift)) + bl; s = row - (bl << P.rp_shift); }
     else { ball = u; s = tp * 32 + row; }
-    if (ball >= P.nballs) ball = P.nballs - 1;
+    if (ball >= (int)P.nballs) ball = (int)P.nballs - 1;
     if (s >= P.ns) s = 0;                                   // padded rows repeat sample 0
-    const int a_raw = P.idx[ball * P.ns + s];
-    const int c = P.cnt[ball];
+    const int a_raw = P.idx[(unsigned)(ball * P.ns + s)];
+    const int c = P.cnt[(unsigned)ball];
+    int frame;
+    if (P.m_shift >= 0) frame = ball >> P.m_shift;
+    else {                                                  // ball < 2^24: one float estimate, exact after +-1
+        frame = (int)((float)ball * P.inv_m);
+        const int r = ball - frame * P.m;
+        frame += r >= P.m ? 1 : (r < 0 ? -1 : 0);
+    }
     RowRef r;
     r.cnt = c;
-    r.ball = (int)ball;
-    r.pt = (int)((ball / P.m) * P.n) + (c > 0 ? a_raw : 0); // layers_util.py:157-159
+    r.ball = ball;
+    r.pt = frame * P.n + (c > 0 ? a_raw : 0);               // layers_util.py:157-159
     return r;
 }
 
@@ -89,10 +113,11 @@ struct RowTail { float t[4]; };
 template <int TAILF>
 __device__ __forceinline__ RowTail load_row_tail(const RwParams &P, const RowRef &rr) {
     RowTail r;
-    const float px = P.xyz[(long)rr.pt * 3 + 0] - P.new_xyz[(long)rr.ball * 3 + 0];
-    const float py = P.xyz[(long)rr.pt * 3 + 1] - P.new_xyz[(long)rr.ball * 3 + 1];
-    const float pz = P.xyz[(long)rr.pt * 3 + 2] - P.new_xyz[(long)rr.ball * 3 + 2];
-    if (TAILF) { r.t[0] = P.feat[(long)rr.pt * P.C + (P.C - 1)]; r.t[1] = px; r.t[2] = py; r.t[3] = pz; }
+    const unsigned po = (unsigned)rr.pt * 3u, bo = (unsigned)rr.ball * 3u;
+    const float px = P.xyz[po + 0] - P.new_xyz[bo + 0];
+    const float py = P.xyz[po + 1] - P.new_xyz[bo + 1];
+    const float pz = P.xyz[po + 2] - P.new_xyz[bo + 2];
+    if (TAILF) { r.t[0] = P.feat[(unsigned)(rr.pt * P.C + (P.C - 1))]; r.t[1] = px; r.t[2] = py; r.t[3] = pz; }
     else { r.t[0] = px; r.t[1] = py; r.t[2] = pz; r.t[3] = 0.0f; }
     return r;
 }
@@ -104,8 +129,9 @@ __device__ __forceinline__ void load_group(const RwParams &P, const RowRef &rr, 
                                            float (&v)[8]) {
     const int GF = P.C >> 3;
     if (g < GF) {
-        const float4 f0 = *(const float4 *)(P.feat + (long)rr.pt * P.C + 8 * g);
-        const float4 f1 = *(const float4 *)(P.feat + (long)rr.pt * P.C + 8 * g + 4);
+        const unsigned fo = (unsigned)(rr.pt * P.C + 8 * g);
+        const float4 f0 = *(const float4 *)(P.feat + fo);
+        const float4 f1 = *(const float4 *)(P.feat + fo + 4);
         v[0] = f0.x; v[1] = f0.y; v[2] = f0.z; v[3] = f0.w;
         v[4] = f1.x; v[5] = f1.y; v[6] = f1.z; v[7] = f1.w;
     } else {
@@ -150,9 +176,13 @@ __device__ __forceinline__ void tile_ball_max(const f32x16 &a, int rp, float (&b
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
         qm[q] = sa::fmax_nn(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
     }
-    if (rp == 8) { bm[0] = qm[0]; bm[1] = qm[1]; bm[2] = qm[2]; bm[3] = qm[3]; }
-    else if (rp == 16) { bm[0] = sa::fmax_nn(qm[0], qm[1]); bm[1] = sa::fmax_nn(qm[2], qm[3]); bm[2] = bm[3] = 0.f; }
-    else { bm[0] = sa::fmax_nn(sa::fmax_nn(qm[0], qm[1]), sa::fmax_nn(qm[2], qm[3])); bm[1] = bm[2] = bm[3] = 0.f; }
+    // selects, not branches: branches turn bm[] into a private-memory object
+    const float m01 = sa::fmax_nn(qm[0], qm[1]), m23 = sa::fmax_nn(qm[2], qm[3]);
+    const float m = sa::fmax_nn(m01, m23);
+    bm[0] = rp == 8 ? qm[0] : (rp == 16 ? m01 : m);
+    bm[1] = rp == 8 ? qm[1] : (rp == 16 ? m23 : 0.0f);
+    bm[2] = rp == 8 ? qm[2] : 0.0f;
+    bm[3] = rp == 8 ? qm[3] : 0.0f;
 }
 
 // hidden layer: KS k-steps of input fragments (ih, il) -> NT output tiles -> next layer's fragments (oh, ol)
@@ -203,14 +233,39 @@ __global__ __launch_bounds__(NW * 64, WPE) void mlp_rw_kernel(RwParams P) {
     float *b0 = (float *)(W2 + nW2), *b1 = b0 + NT1 * 32, *b2 = b1 + NT2 * 32;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int i = tid; i < nW0; i += NW * 64) W0[i] = P.w[0][i];
-    for (int i = tid; i < nW1; i += NW * 64) W1[i] = P.w[1][i];
-    for (int i = tid; i < nW2; i += NW * 64) W2[i] = P.w[2][i];
-    for (int i = tid; i < NT1 * 32; i += NW * 64) b0[i] = P.bias[0][i];
-    for (int i = tid; i < NT2 * 32; i += NW * 64) b1[i] = P.bias[1][i];
-    for (int i = tid; i < NT3 * 32; i += NW * 64) b2[i] = P.bias[2][i];
+    RW_T0();
+    // one-time copy of the packed weights and biases: all loads of a layer are issued before its stores
+    {
+        constexpr int NT_ = NW * 64;
+        static_assert(nW0 <= 8 * NT_ && nW1 <= 8 * NT_ && nW2 <= 8 * NT_, "weight copy batch too small");
+#define SA_RW_COPY(SRC, DST, CNT)                                                                         \
+        {                                                                                                 \
+            uint4 tmp[8];                                                                                 \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                 \
+                if (j * NT_ < (CNT)) { const int i = j * NT_ + tid; tmp[j] = (SRC)[i < (CNT) ? i : (CNT) - 1]; } \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                 \
+                if (j * NT_ < (CNT)) { const int i = j * NT_ + tid; if (i < (CNT)) (DST)[i] = tmp[j]; }   \
+        }
+        SA_RW_COPY(P.w[0], W0, nW0)
+        SA_RW_COPY(P.w[1], W1, nW1)
+        SA_RW_COPY(P.w[2], W2, nW2)
+#undef SA_RW_COPY
+        if (tid < NT1 * 32) b0[tid] = P.bias[0][tid];
+        if (tid < NT2 * 32) b1[tid] = P.bias[1][tid];
+        if (tid < NT3 * 32) b2[tid] = P.bias[2][tid];
+        static_assert(NT1 * 32 <= NT_ && NT2 * 32 <= NT_ && NT3 * 32 <= NT_, "bias copy needs one pass");
+    }
     __syncthreads();
+    RW_TICK(0)
 
+    // A wave's own MFMA and VALU instructions do not overlap on gfx950, those of two waves on one SIMD do
+    // (tools/microbench/mfma_valu_overlap.hip).  Waves that start in lockstep stay in lockstep -- both in their
+    // matrix phase, then both in their VALU phase, each at half rate.  Unequal issue priorities break the tie:
+    // the high-priority wave runs at full rate and the other one's matrix work fills its VALU phases.
+    if (NW >= 8) {
+        if ((w / 4) & 1) __builtin_amdgcn_s_setprio(0);
+        else __builtin_amdgcn_s_setprio(2);
+    }
     const int row = lane & 31, half = lane >> 5;
     const int gw = blockIdx.x * NW + w, nwaves = gridDim.x * NW;
     const int nunits = P.ntiles / P.tpu;
@@ -244,6 +299,8 @@ __global__ __launch_bounds__(NW * 64, WPE) void mlp_rw_kernel(RwParams P) {
 #pragma unroll
         for (int ks = 0; ks < KS0; ++ks) split8(raw[ks], h0[ks], l0[ks]);
         const int cnt_row = cur.cnt;
+        RW_COUNT();
+        RW_TICK(1)
         // ---- loads of the next tile (features) and of the one after (indices), then pin them above the math
         cur = nxt;
         {
@@ -256,11 +313,14 @@ __global__ __launch_bounds__(NW * 64, WPE) void mlp_rw_kernel(RwParams P) {
         advance(uf, tf);
         advance(ui, ti);
         __builtin_amdgcn_sched_barrier(0);
+        RW_TICK(2)
 
         uint4 h1[KS1], l1[KS1];
         hidden_layer<KS0, NT1, KS1>(W0, b0, h0, l0, h1, l1, lane);
+        RW_TICK(3)
         uint4 h2[KS2], l2[KS2];
         hidden_layer<KS1, NT2, KS2>(W1, b1, h1, l1, h2, l2, lane);
+        RW_TICK(4)
         // ---- last layer (D form) + max over the rows of each ball
         constexpr int TG = NT3 >= 2 ? 2 : 1;
 #pragma unroll
@@ -294,17 +354,18 @@ __global__ __launch_bounds__(NW * 64, WPE) void mlp_rw_kernel(RwParams P) {
                 }
             }
         }
+        RW_TICK(5)
         // ---- write out after the last tile of the unit: relu(max + bias), zero for empty balls
         //      (layers_util.py:178-181)
         if (tp == P.tpu - 1) {
             const int nb = P.rp <= 32 ? 32 >> P.rp_shift : 1;
-            const long ball0 = P.rp <= 32 ? (long)T_u * nb : T_u;
+            const int ball0 = P.rp <= 32 ? T_u * nb : T_u;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 if (g < nb) {
-                    const long ball = ball0 + g;
+                    const int ball = ball0 + g;
                     const int cg = __builtin_amdgcn_readlane(cnt_row, P.rp <= 32 ? g * P.rp : 0);
-                    if (ball < P.nballs && lane < 32) {
+                    if (ball < (int)P.nballs && lane < 32) {
 #pragma unroll
                         for (int ct = 0; ct < NT3; ++ct) {
                             const int c = ct * 32 + lane;
@@ -312,14 +373,236 @@ __global__ __launch_bounds__(NW * 64, WPE) void mlp_rw_kernel(RwParams P) {
                                 float v = pooled[ct][g] + b2[c];
                                 v = v > 0.0f ? v : 0.0f;
                                 if (cg <= 0) v = 0.0f;
-                                P.out[ball * P.out_stride + P.out_off + c] = v;
+                                P.out[(unsigned)(ball * P.out_stride + P.out_off + c)] = v;
                             }
                         }
                     }
                 }
             }
         }
+        RW_TICK(6)
     }
+    RW_FLUSH(gw)
+}
+
+// =====================================================================================================
+// Streamed-weight variant for the mid-width scales (layer3 of 3dssd.yaml: 131 -> 128 -> 128..256 -> 256) whose
+// packed weights (264 .. 456 KiB) do not fit LDS.  Same wave-owns-a-tile / activations-in-registers structure,
+// but the NW waves of a workgroup walk the weight stream together: it is cut into chunks of G k-step tiles
+// (2 KiB each, in exactly the order the unrolled MFMA loops consume them == the packed global order), two chunk
+// slots live in LDS, and at every chunk boundary (a compile-time position in the unrolled code)
+//     barrier -> store the staged registers of chunk c+1 into the slot chunk c-1 just vacated
+//             -> issue the global loads of chunk c+2 into the staging registers -> compute on chunk c.
+// One barrier per chunk, every weight byte crosses L2 -> LDS once per NW*32 rows (mlp.hip: once per 32 rows),
+// and the loads of a chunk have a whole chunk of matrix work (~G*96 cycles per wave) to land.
+// Two accumulators per output tile (even / odd k-steps) keep two independent MFMA chains in flight.
+// staging registers as named fields (an indexed array survived as a private-memory object in this kernel)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector: plain loads / stores, no memcpy
+struct RsStage { u32x4 a0, a1, a2, a3, a4, a5, a6, a7; };
+__device__ __forceinline__ u32x4 &rs_st(RsStage &s, int i) {
+    switch (i) {
+        case 0: return s.a0; case 1: return s.a1; case 2: return s.a2; case 3: return s.a3;
+        case 4: return s.a4; case 5: return s.a5; case 6: return s.a6; default: return s.a7;
+    }
+}
+struct RsCtx {
+    uint4 *ring;          // 2 slots x PC x 64 uint4
+    int w, lane;
+    int gc0;              // global chunk counter at the start of the pass
+    int abase;            // uint4 index of this lane's fragment slot in the current chunk
+};
+
+// global loads of stream chunk sc (0 .. CPP-1) into the staging registers: piece q = w + NW*i of the chunk.
+// The three layers of the scale are packed back to back in ONE device buffer (checked on the host), so the
+// stream is a plain linear array of 1 KiB pieces.
+template <int KT0, int KT1, int KT2, int G, int NW, int PPW>
+__device__ __forceinline__ void rs_issue_chunk(const RwParams &P, RsCtx &X, RsStage &stage, int sc) {
+    int wl = X.w;
+    asm volatile("" : "+s"(wl));        // opaque: keeps the per-chunk addresses from being hoisted out of the pass loop
+    const unsigned off = (unsigned)((sc * 2 * G + wl) * 64 + X.lane);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) rs_st(stage, i) = *(const u32x4 *)(P.w[0] + (off + (unsigned)(NW * i * 64)));
+}
+template <int G, int NW, int PPW>
+__device__ __forceinline__ void rs_store_stage(RsCtx &X, RsStage &stage, int slot) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) *(u32x4 *)(X.ring + ((slot * 2 * G + X.w + NW * i) * 64 + X.lane)) = rs_st(stage, i);
+}
+// chunk boundary in front of stream position p (p % G == 0)
+template <int KT0, int KT1, int KT2, int G, int NW, int PPW>
+__device__ __forceinline__ void rs_boundary(const RwParams &P, RsCtx &X, RsStage &stage, int p) {
+    constexpr int CPP = (KT0 + KT1 + KT2) / G;
+    const int cidx = p / G;
+    const int gc = X.gc0 + cidx;
+    __builtin_amdgcn_sched_barrier(0);      // the chunk's loads must not drift up across earlier boundaries
+    __syncthreads();
+    rs_store_stage<G, NW, PPW>(X, stage, (gc + 1) & 1);
+    rs_issue_chunk<KT0, KT1, KT2, G, NW, PPW>(P, X, stage, (cidx + 2) % CPP);
+    __builtin_amdgcn_sched_barrier(0);
+    X.abase = (gc & 1) * 2 * G * 64 + X.lane;
+}
+// one output tile of a layer: k-step tiles base .. base+KS-1 of the stream, even / odd k-steps in two chains
+template <int KS, int KT0, int KT1, int KT2, int G, int NW, int PPW, bool WFIRST>
+__device__ __forceinline__ void rs_tile_mma(const RwParams &P, RsCtx &X, RsStage &stage, const uint4 (&ih)[KS],
+                                            const uint4 (&il)[KS], int base, f32x16 &acc_e, f32x16 &acc_o) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int p = base + ks;
+        if (p % G == 0) rs_boundary<KT0, KT1, KT2, G, NW, PPW>(P, X, stage, p);
+        const uint4 wh = X.ring[X.abase + ((p % G) * 2) * 64];
+        const uint4 wl = X.ring[X.abase + ((p % G) * 2 + 1) * 64];
+        f32x16 &acc = (ks & 1) ? acc_o : acc_e;
+        if (WFIRST) {
+            acc = mfma_bf16(wh, ih[ks], acc);
+            acc = mfma_bf16(wl, ih[ks], acc);
+            acc = mfma_bf16(wh, il[ks], acc);
+        } else {
+            acc = mfma_bf16(ih[ks], wh, acc);
+            acc = mfma_bf16(ih[ks], wl, acc);
+            acc = mfma_bf16(il[ks], wh, acc);
+        }
+    }
+}
+__device__ __forceinline__ void load_bias_tile(const float *bias, int ct, int half, f32x16 &a) {
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+        const float4 bv = *(const float4 *)(bias + ct * 32 + 8 * qd + 4 * half);
+        a[4 * qd + 0] = bv.x; a[4 * qd + 1] = bv.y; a[4 * qd + 2] = bv.z; a[4 * qd + 3] = bv.w;
+    }
+}
+
+template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF, int G, int NBALL>
+__global__ __launch_bounds__(NW * 64, WPE) void mlp_rs_kernel(RwParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int KT0 = NT1 * KS0, KT1 = NT2 * KS1, KT2 = NT3 * KS2, TOT = KT0 + KT1 + KT2;
+    static_assert(TOT % G == 0, "chunk size must divide the k-step tiles of a pass");
+    constexpr int CPP = TOT / G;             // chunks per pass
+    constexpr int PC = 2 * G;                // 1 KiB pieces (one plane of one k-step tile) per chunk
+    static_assert(PC % NW == 0, "pieces of a chunk must split evenly over the waves");
+    constexpr int PPW = PC / NW;             // pieces a wave moves per chunk
+    RsCtx X;
+    RsStage stage;           // the pieces of the next chunk this wave moves
+    static_assert(PPW <= 8, "staging registers");
+    X.ring = (uint4 *)smem;
+    float *b0 = (float *)(X.ring + 2 * PC * 64), *b1 = b0 + NT1 * 32, *b2 = b1 + NT2 * 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row = lane & 31, half = lane >> 5;
+    X.w = w; X.lane = lane; X.gc0 = 0; X.abase = 0;
+
+    for (int i = tid; i < NT1 * 32; i += NW * 64) b0[i] = P.bias[0][i];
+    for (int i = tid; i < NT2 * 32; i += NW * 64) b1[i] = P.bias[1][i];
+    for (int i = tid; i < NT3 * 32; i += NW * 64) b2[i] = P.bias[2][i];
+    RW_T0();
+
+    // every wave of the grid runs the same number of tiles (barriers inside): clamped repeats at the end
+    const int nunits = P.ntiles / P.tpu;
+    const int nwaves = gridDim.x * NW, gw = blockIdx.x * NW + w;
+    const int npass = ((nunits + nwaves - 1) / nwaves) * P.tpu;
+    int uc = gw, tc = 0, uf = gw, tf = 0;
+    if (tf + 1 < P.tpu) ++tf; else { uf += nwaves; tf = 0; }
+
+    // ---- prologue: chunk 0 into slot 0, chunk 1 staged; first tile's rows and features
+    rs_issue_chunk<KT0, KT1, KT2, G, NW, PPW>(P, X, stage, 0);
+    RowRef cur = load_row_ref(P, uc < nunits ? uc : nunits - 1, tc, row);
+    rs_store_stage<G, NW, PPW>(X, stage, 0);
+    rs_issue_chunk<KT0, KT1, KT2, G, NW, PPW>(P, X, stage, 1 % CPP);
+    float raw[KS0][8];
+    {
+        const RowTail tl = load_row_tail<TAILF>(P, cur);
+#pragma unroll
+        for (int ks = 0; ks < KS0; ++ks) load_group(P, cur, tl, 2 * ks + half, raw[ks]);
+    }
+    RowRef nxt = load_row_ref(P, uf < nunits ? uf : nunits - 1, tf, row);
+    float pooled[NT3][NBALL];
+
+    RW_TICK(0)
+    for (int q = 0; q < npass; ++q) {
+        const int T_u = uc, tp = tc;
+        RW_COUNT();
+        uint4 h0[KS0], l0[KS0];
+#pragma unroll
+        for (int ks = 0; ks < KS0; ++ks) split8(raw[ks], h0[ks], l0[ks]);
+        const int cnt_row = cur.cnt;
+        RW_TICK(1)
+
+        // ---- hidden layer 0
+        uint4 h1[KS1], l1[KS1];
+#pragma unroll
+        for (int ct = 0; ct < NT1; ++ct) {
+            f32x16 ae, ao;
+            load_bias_tile(b0, ct, half, ae);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ao[r] = 0.0f;
+            rs_tile_mma<KS0, KT0, KT1, KT2, G, NW, PPW, true>(P, X, stage, h0, l0, ct * KS0, ae, ao);
+            ae += ao;
+            acc_to_frags<KS1>(ae, ct, h1, l1);
+        }
+        RW_TICK(2)
+        // ---- hidden layer 1
+        uint4 h2[KS2], l2[KS2];
+#pragma unroll
+        for (int ct = 0; ct < NT2; ++ct) {
+            f32x16 ae, ao;
+            load_bias_tile(b1, ct, half, ae);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ao[r] = 0.0f;
+            rs_tile_mma<KS1, KT0, KT1, KT2, G, NW, PPW, true>(P, X, stage, h1, l1, KT0 + ct * KS1, ae, ao);
+            ae += ao;
+            acc_to_frags<KS2>(ae, ct, h2, l2);
+        }
+        RW_TICK(3)
+        // ---- the next tile's loads go out here: the input and first-hidden fragments are dead, their registers
+        //      hold the raw features until the next iteration converts them
+        if (tc + 1 < P.tpu) ++tc; else { uc += nwaves; tc = 0; }
+        if (tf + 1 < P.tpu) ++tf; else { uf += nwaves; tf = 0; }
+        cur = nxt;
+        {
+            const RowTail tl = load_row_tail<TAILF>(P, cur);
+#pragma unroll
+            for (int ks = 0; ks < KS0; ++ks) load_group(P, cur, tl, 2 * ks + half, raw[ks]);
+        }
+        nxt = load_row_ref(P, uf < nunits ? uf : nunits - 1, tf, row);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- last layer (D form) + max over the rows of each ball
+#pragma unroll
+        for (int ct = 0; ct < NT3; ++ct) {
+            f32x16 ae, ao;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { ae[r] = 0.0f; ao[r] = 0.0f; }
+            rs_tile_mma<KS2, KT0, KT1, KT2, G, NW, PPW, false>(P, X, stage, h2, l2, KT0 + KT1 + ct * KS2, ae, ao);
+            ae += ao;
+            float bm[4];
+            tile_ball_max(ae, P.rp, bm);
+#pragma unroll
+            for (int g = 0; g < NBALL; ++g) pooled[ct][g] = tp == 0 ? bm[g] : sa::fmax_nn(pooled[ct][g], bm[g]);
+        }
+        X.gc0 += CPP;
+        RW_TICK(4)
+        // ---- write out after the last tile of the unit
+        if (tp == P.tpu - 1 && T_u < nunits) {
+            const int ball0 = P.rp <= 32 ? T_u * NBALL : T_u;
+#pragma unroll
+            for (int g = 0; g < NBALL; ++g) {
+                const int ball = ball0 + g;
+                const int cg = __builtin_amdgcn_readlane(cnt_row, P.rp <= 32 ? g * P.rp : 0);
+                if (ball < (int)P.nballs && lane < 32) {
+#pragma unroll
+                    for (int ct = 0; ct < NT3; ++ct) {
+                        const int c = ct * 32 + lane;
+                        if (c < P.N3) {
+                            float v = pooled[ct][g] + b2[c];
+                            v = v > 0.0f ? v : 0.0f;
+                            if (cg <= 0) v = 0.0f;
+                            P.out[(unsigned)(ball * P.out_stride + P.out_off + c)] = v;
+                        }
+                    }
+                }
+            }
+        }
+        RW_TICK(5)
+    }
+    RW_FLUSH(gw)
 }
 
 int roundup(int x, int q) { return (x + q - 1) / q * q; }
@@ -353,6 +636,23 @@ int launch_rw(const RwParams &P, int wgs_per_cu, hipStream_t stream) {
     return SA_OK;
 }
 
+template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF, int G, int NBALL>
+int launch_rs(const RwParams &P, int wgs_per_cu, hipStream_t stream) {
+    constexpr size_t lds = (size_t)2 * 2 * G * 1024 + (size_t)(NT1 + NT2 + NT3) * 128;
+    auto kern = mlp_rs_kernel<KS0, NT1, KS1, NT2, KS2, NT3, NW, WPE, TAILF, G, NBALL>;
+    if (lds > 48 * 1024) {
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipGetLastError();
+    }
+    const long nunits = P.ntiles / P.tpu;
+    long grid = (nunits + NW - 1) / NW;
+    const long cap = (long)num_cus() * wgs_per_cu;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, stream, P);
+    SA_CHECK_LAUNCH();
+    return SA_OK;
+}
+
 }  // namespace
 
 // Returns 1 when the shape has a row-wave instantiation and the launch was issued (status in *st), 0 when the
@@ -364,6 +664,11 @@ int sa_rowwave_try(int b, int n, int m, int ns, int c, const float *xyz, const f
     static const bool enabled = !(getenv("SA_MLP_ROWWAVE") && atoi(getenv("SA_MLP_ROWWAVE")) == 0);
     if (!enabled || nl != 3) return 0;
     if (!(c == 1 || (c > 0 && (c & 7) == 0))) return 0;      // input layouts the in-register gather handles
+    // 32-bit element offsets everywhere (and a float-exact ball / m)
+    const long nb_ = (long)b * m;
+    if (nb_ >= (1l << 24) || (long)b * n * (c > 3 ? c : 3) >= (1l << 31) || nb_ * ns >= (1l << 31) ||
+        nb_ * out_stride + out_off + dims[3] >= (1l << 31))
+        return 0;
     const int KS0 = roundup(dims[0], 16) / 16;
     const int NT1 = roundup(dims[1], 32) / 32, KS1 = roundup(dims[1], 16) / 16;
     const int NT2 = roundup(dims[2], 32) / 32, KS2 = roundup(dims[2], 16) / 16;
@@ -376,6 +681,9 @@ int sa_rowwave_try(int b, int n, int m, int ns, int c, const float *xyz, const f
     P.rp = ns <= 8 ? 8 : (ns <= 16 ? 16 : roundup(ns, 32));
     P.N3 = dims[3];
     P.rp_shift = P.rp == 8 ? 3 : (P.rp == 16 ? 4 : 5);
+    P.m_shift = -1;
+    for (int sft = 0; sft < 31; ++sft) if (m == (1 << sft)) P.m_shift = sft;
+    P.inv_m = 1.0f / (float)m;
     P.tpu = P.rp <= 32 ? 1 : P.rp / 32;
     const int bpt = P.rp <= 32 ? 32 / P.rp : 1;
     const long ntiles = P.rp <= 32 ? (P.nballs + bpt - 1) / bpt : P.nballs * P.tpu;
@@ -392,5 +700,41 @@ int sa_rowwave_try(int b, int n, int m, int ns, int c, const float *xyz, const f
     SA_RW(5, 2, 4, 2, 4, 4, 8, 2, 1)      // 67 -> 64 -> 64 -> 128    (layer2 scales 0/1)
     SA_RW(5, 2, 4, 3, 6, 4, 8, 2, 1)      // 67 -> 64 -> 96 -> 128    (layer2 scale 2)
 #undef SA_RW
+    // the streamed kernel walks the three layers as one linear weight stream: they must be packed back to back
+    // (utils/weights.py pack_scale does that); separately allocated layers take the generic kernel
+    const bool contiguous =
+        (const char *)wpack[1] == (const char *)wpack[0] + (size_t)NT1 * KS0 * 2048 &&
+        (const char *)wpack[2] == (const char *)wpack[1] + (size_t)NT2 * KS1 * 2048;
+    static const bool stream_enabled = !(getenv("SA_MLP_ROWSTREAM") && atoi(getenv("SA_MLP_ROWSTREAM")) == 0);
+#define SA_RS(K0, N1, K1, N2, K2, N3_, NW_, WPE_, WGS, G_)                                          \
+    if (stream_enabled && contiguous && c != 1 && KS0 == K0 && NT1 == N1 && KS1 == K1 && NT2 == N2 && KS2 == K2 && NT3 == N3_) { \
+        *st = P.rp >= 32 ? launch_rs<K0, N1, K1, N2, K2, N3_, NW_, WPE_, 0, G_, 1>(P, WGS, stream)   \
+            : (P.rp == 16 ? launch_rs<K0, N1, K1, N2, K2, N3_, NW_, WPE_, 0, G_, 2>(P, WGS, stream)  \
+                          : launch_rs<K0, N1, K1, N2, K2, N3_, NW_, WPE_, 0, G_, 4>(P, WGS, stream)); \
+        return 1;                                                                                   \
+    }
+    SA_RS(9, 4, 8, 4, 8, 8, 4, 1, 1, 12)      // 131 -> 128 -> 128 -> 256   (layer3 scale 0): 132 k-step tiles
+    SA_RS(9, 4, 8, 6, 12, 8, 4, 1, 1, 12)     // 131 -> 128 -> 192 -> 256   (layer3 scale 1): 180
+    SA_RS(9, 4, 8, 8, 16, 8, 4, 1, 1, 12)     // 131 -> 128 -> 256 -> 256   (layer3 scale 2): 228
+#undef SA_RS
     return 0;
 }
+
+#ifdef SA_RW_TIMING
+extern "C" int sa_debug_rw_prof(unsigned long long *host8, int reset) {
+    static unsigned long long *h = (unsigned long long *)calloc(65536 * 8, sizeof(unsigned long long));
+    if (host8) {
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_rw_prof), 65536 * 8 * sizeof(unsigned long long)) != hipSuccess) return SA_ERR_LAUNCH;
+        for (int i = 0; i < 8; ++i) host8[i] = 0;
+        unsigned long long waves = 0;
+        for (int r = 0; r < 65536; ++r) { if (h[r * 8 + 7]) ++waves; for (int i = 0; i < 8; ++i) host8[i] += h[r * 8 + i]; }
+        host8[8] = waves;
+    }
+    if (reset) {
+        void *d = nullptr;
+        if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_rw_prof)) != hipSuccess) return SA_ERR_LAUNCH;
+        if (hipMemset(d, 0, 65536 * 8 * sizeof(unsigned long long)) != hipSuccess) return SA_ERR_LAUNCH;
+    }
+    return SA_OK;
+}
+#endif

@@ -196,7 +196,7 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
                                                xyz.data_ptr(), new_xyz.data_ptr(), idxp, cntp, stream)
         N.check(st, "query_ball_point")
         # ---- per scale: fused mask/group/concat/MLP/max/mask (:157-181) into the concat buffer (:183)
-        layers = [[vs.layer("%s/conv%d_%d" % (scope, i, j), bn) for j in range(len(mlp_list[i]))]
+        layers = [vs.scale(["%s/conv%d_%d" % (scope, i, j) for j in range(len(mlp_list[i]))], bn)
                   for i in range(nscale)]
         ctot = sum(ls[-1].N for ls in layers)
         new_points_concat = torch.empty((bs, m, ctot), dtype=torch.float32, device=dev)

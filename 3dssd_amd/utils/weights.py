@@ -61,11 +61,29 @@ def pack_layer(w, bias):
 class PackedLayer:
     __slots__ = ("K", "N", "w", "bias")
 
-    def __init__(self, w, bias, device):
-        arr, bp = pack_layer(w, bias)
+    def __init__(self, w, bias, device, _packed=None):
         self.K, self.N = int(w.shape[0]), int(w.shape[1])
+        if _packed is not None:                      # views into a buffer shared with the other layers of a scale
+            self.w, self.bias = _packed
+            return
+        arr, bp = pack_layer(w, bias)
         self.w = torch.from_numpy(arr.view(np.int16).reshape(-1)).to(device)
         self.bias = torch.from_numpy(bp).to(device)
+
+
+def pack_scale(ws, bs, device):
+    """The layers of one MLP scale packed back to back in ONE device buffer (layer l+1 starts where layer l
+    ends): the streamed-weight kernel of csrc/mlp_rowwave.hip walks them as a single linear stream.  Every
+    kernel accepts these layers; separately allocated PackedLayers simply never take the streamed path."""
+    packed = [pack_layer(w, b) for w, b in zip(ws, bs)]
+    flat = np.concatenate([arr.view(np.int16).reshape(-1) for arr, _ in packed])
+    buf = torch.from_numpy(flat).to(device)
+    out, off = [], 0
+    for (arr, bp), w in zip(packed, ws):
+        n = arr.size
+        out.append(PackedLayer(w, None, device, _packed=(buf[off:off + n], torch.from_numpy(bp).to(device))))
+        off += n
+    return out
 
 
 class VariableStore:
@@ -81,6 +99,14 @@ class VariableStore:
         if key not in self._cache:
             w, b = fold_conv_bn(self.params, scope, bn)
             self._cache[key] = PackedLayer(w, b, self.device)
+        return self._cache[key]
+
+    def scale(self, scopes, bn=True):
+        """The conv layers of one MLP scale, packed contiguously (pack_scale)."""
+        key = (tuple(scopes), bool(bn))
+        if key not in self._cache:
+            folded = [fold_conv_bn(self.params, sc, bn) for sc in scopes]
+            self._cache[key] = pack_scale([w for w, _ in folded], [b for _, b in folded], self.device)
         return self._cache[key]
 
 

@@ -205,14 +205,16 @@ def _rand_layers(rng, dims):
     return ws, bs
 
 
-def _run_group_mlp(gpu, xyz, feat, new_xyz, idx, cnt, ws, bs):
+def _run_group_mlp(gpu, xyz, feat, new_xyz, idx, cnt, ws, bs, contiguous=True):
     import ctypes
     N = pkg("utils._native")
     Wt = pkg("utils.weights")
     b, n, _ = xyz.shape
     _, m, ns = idx.shape
     c = 0 if feat is None else feat.shape[2]
-    layers = [Wt.PackedLayer(w, bb, gpu) for w, bb in zip(ws, bs)]
+    # one buffer per scale (the library's own host side does the same); contiguous=False: separately allocated
+    # layers, which must still work (they take the non-streamed kernels)
+    layers = Wt.pack_scale(ws, bs, gpu) if contiguous else [Wt.PackedLayer(w, bb, gpu) for w, bb in zip(ws, bs)]
     nl = len(layers)
     out = torch.full((b, m, layers[-1].N + 5), -7.0, dtype=torch.float32, device=gpu)   # strided output
     dims = (ctypes.c_int * (nl + 1))(*([c + 3] + [l.N for l in layers]))
@@ -254,9 +256,13 @@ def test_group_mlp_max(gpu, oracle, c, ns, dims):
 @pytest.mark.parametrize("c,ns,dims,m", [(1, 8, [16, 16, 32], 45), (1, 16, [32, 32, 64], 45), (1, 20, [16, 16, 32], 33),
                                          (8, 32, [12, 16, 20], 45), (64, 16, [64, 64, 128], 45),
                                          (64, 48, [64, 96, 128], 29), (64, 96, [64, 64, 128], 7),
-                                         (64, 32, [40, 50, 100], 300), (1, 64, [32, 32, 64], 1100)])
+                                         (64, 32, [40, 50, 100], 300), (1, 64, [32, 32, 64], 1100),
+                                         (128, 32, [128, 128, 256], 45), (128, 16, [128, 256, 256], 45),
+                                         (128, 64, [128, 192, 256], 20), (128, 8, [100, 130, 250], 33),
+                                         (128, 32, [128, 128, 256], 700)])
 def test_group_mlp_max_rowwave_shapes(gpu, oracle, c, ns, dims, m):
-    # the LDS-resident-weight / register-resident-activation kernel (mlp_rowwave.hip): every pooling layout
+    # the LDS-resident-weight / register-resident-activation kernels (mlp_rowwave.hip; C = 128 rows take the
+    # streamed-weight variant, several passes per workgroup at m = 700): every pooling layout
     # (4, 2, 1 balls per 32-row tile, 2 and 3 tiles per ball), padded channel counts, ragged ball counts and
     # enough balls for several tiles per wave (software-pipelined gathers)
     rng = np.random.default_rng(c * 1000 + ns + m)
@@ -273,6 +279,21 @@ def test_group_mlp_max_rowwave_shapes(gpu, oracle, c, ns, dims, m):
     err = np.abs(got - ref).max() / np.abs(ref).max()
     assert err < MLP_TOL, "relative error %g" % err
     assert (got[cnt == 0] == 0).all()
+
+
+def test_group_mlp_max_separately_allocated_layers(gpu, oracle):
+    # layer-3 shape with the three layers in three device buffers: no streamed path, same result
+    rng = np.random.default_rng(77)
+    b, n, m, ns, c = 2, 600, 45, 32, 128
+    xyz = _cloud(rng, b, n, scale=4.0)
+    feat = rng.normal(0, 1, (b, n, c)).astype(np.float32)
+    new_xyz = xyz[:, :m].copy()
+    idx = rng.integers(0, n, (b, m, ns)).astype(np.int32)
+    cnt = rng.integers(1, ns + 1, (b, m)).astype(np.int32)
+    ws, bs = _rand_layers(rng, [c + 3, 128, 128, 256])
+    got = _run_group_mlp(gpu, xyz, feat, new_xyz, idx, cnt, ws, bs, contiguous=False)
+    ref = oracle.group_mlp_max(xyz, feat, new_xyz, idx, cnt, ws, bs)
+    assert np.abs(got - ref).max() / np.abs(ref).max() < MLP_TOL
 
 
 def test_group_mlp_max_identity_layout_probe(gpu):
