@@ -388,69 +388,83 @@ __global__ __launch_bounds__(NW * 64, WPE) void mlp_rw_kernel(RwParams P) {
 // =====================================================================================================
 // Streamed-weight variant for the mid-width scales (layer3 of 3dssd.yaml: 131 -> 128 -> 128..256 -> 256) whose
 // packed weights (264 .. 456 KiB) do not fit LDS.  Same wave-owns-a-tile / activations-in-registers structure,
-// but the NW waves of a workgroup walk the weight stream together: it is cut into chunks of G k-step tiles
+// but the NW waves of a workgroup walk the weight stream together: it is cut into 12 chunks of G k-step tiles
 // (2 KiB each, in exactly the order the unrolled MFMA loops consume them == the packed global order), two chunk
 // slots live in LDS, and at every chunk boundary (a compile-time position in the unrolled code)
 //     barrier -> store the staged registers of chunk c+1 into the slot chunk c-1 just vacated
-//             -> issue the global loads of chunk c+2 into the staging registers -> compute on chunk c.
+//             -> issue the global loads of chunk c+1+DEPTH into that staging set -> compute on chunk c.
 // One barrier per chunk, every weight byte crosses L2 -> LDS once per NW*32 rows (mlp.hip: once per 32 rows),
-// and the loads of a chunk have a whole chunk of matrix work (~G*96 cycles per wave) to land.
+// and the loads of a chunk have DEPTH chunks of matrix work (~G*96 cycles per wave each) to land.
 // Two accumulators per output tile (even / odd k-steps) keep two independent MFMA chains in flight.
-// staging registers as named fields (an indexed array survived as a private-memory object in this kernel)
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector: plain loads / stores, no memcpy
-struct RsStage { u32x4 a0, a1, a2, a3, a4, a5, a6, a7; };
-__device__ __forceinline__ u32x4 &rs_st(RsStage &s, int i) {
-    switch (i) {
-        case 0: return s.a0; case 1: return s.a1; case 2: return s.a2; case 3: return s.a3;
-        case 4: return s.a4; case 5: return s.a5; case 6: return s.a6; default: return s.a7;
-    }
-}
 struct RsCtx {
     uint4 *ring;          // 2 slots x PC x 64 uint4
     int w, lane;
-    int gc0;              // global chunk counter at the start of the pass
     int abase;            // uint4 index of this lane's fragment slot in the current chunk
+    u32x4 nh, nl;         // weight fragment (hi, lo plane) of the NEXT k-step tile, already requested from LDS
 };
 
-// global loads of stream chunk sc (0 .. CPP-1) into the staging registers: piece q = w + NW*i of the chunk.
-// The three layers of the scale are packed back to back in ONE device buffer (checked on the host), so the
-// stream is a plain linear array of 1 KiB pieces.
-template <int KT0, int KT1, int KT2, int G, int NW, int PPW>
-__device__ __forceinline__ void rs_issue_chunk(const RwParams &P, RsCtx &X, RsStage &stage, int sc) {
+// The stream of a pass is cut into CPP = 12 chunks of G = TOT/12 k-step tiles (PC = 2G pieces of 1 KiB; wave w
+// moves pieces w, w+NW, ...).  DEPTH staging sets: chunk k travels in set k % DEPTH, its loads are issued DEPTH
+// boundaries before the boundary that stores it into LDS (12 % DEPTH == 0 keeps every index a compile-time
+// constant across passes), i.e. they have DEPTH chunks of matrix work to land.
+constexpr int kRsCPP = 12;
+
+// global loads of stream chunk sc (0 .. 11) into staging set `st`.  The three layers of the scale are packed
+// back to back in ONE device buffer (checked on the host): the stream is a plain linear array of pieces.
+template <int G, int NW, int PPW>
+__device__ __forceinline__ void rs_issue_chunk(const RwParams &P, RsCtx &X, u32x4 (&st)[PPW], int sc) {
     int wl = X.w;
     asm volatile("" : "+s"(wl));        // opaque: keeps the per-chunk addresses from being hoisted out of the pass loop
     const unsigned off = (unsigned)((sc * 2 * G + wl) * 64 + X.lane);
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) rs_st(stage, i) = *(const u32x4 *)(P.w[0] + (off + (unsigned)(NW * i * 64)));
+    for (int i = 0; i < PPW; ++i)
+        if (NW * i + NW <= 2 * G || wl + NW * i < 2 * G)          // ragged last round: wave-uniform
+            st[i] = *(const u32x4 *)(P.w[0] + (off + (unsigned)(NW * i * 64)));
 }
 template <int G, int NW, int PPW>
-__device__ __forceinline__ void rs_store_stage(RsCtx &X, RsStage &stage, int slot) {
+__device__ __forceinline__ void rs_store_stage(RsCtx &X, const u32x4 (&st)[PPW], int slot) {
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) *(u32x4 *)(X.ring + ((slot * 2 * G + X.w + NW * i) * 64 + X.lane)) = rs_st(stage, i);
+    for (int i = 0; i < PPW; ++i)
+        if (NW * i + NW <= 2 * G || X.w + NW * i < 2 * G)
+            *(u32x4 *)(X.ring + ((slot * 2 * G + X.w + NW * i) * 64 + X.lane)) = st[i];
 }
 // chunk boundary in front of stream position p (p % G == 0)
-template <int KT0, int KT1, int KT2, int G, int NW, int PPW>
-__device__ __forceinline__ void rs_boundary(const RwParams &P, RsCtx &X, RsStage &stage, int p) {
-    constexpr int CPP = (KT0 + KT1 + KT2) / G;
+template <int G, int NW, int PPW, int DEPTH>
+__device__ __forceinline__ void rs_boundary(const RwParams &P, RsCtx &X, u32x4 (&st)[DEPTH][PPW], int p) {
     const int cidx = p / G;
-    const int gc = X.gc0 + cidx;
     __builtin_amdgcn_sched_barrier(0);      // the chunk's loads must not drift up across earlier boundaries
     __syncthreads();
-    rs_store_stage<G, NW, PPW>(X, stage, (gc + 1) & 1);
-    rs_issue_chunk<KT0, KT1, KT2, G, NW, PPW>(P, X, stage, (cidx + 2) % CPP);
+    rs_store_stage<G, NW, PPW>(X, st[(cidx + 1) % DEPTH], (cidx + 1) & 1);
+    rs_issue_chunk<G, NW, PPW>(P, X, st[(cidx + 1) % DEPTH], (cidx + 1 + DEPTH) % kRsCPP);
     __builtin_amdgcn_sched_barrier(0);
-    X.abase = (gc & 1) * 2 * G * 64 + X.lane;
+    X.abase = (cidx & 1) * 2 * G * 64 + X.lane;
 }
 // one output tile of a layer: k-step tiles base .. base+KS-1 of the stream, even / odd k-steps in two chains
-template <int KS, int KT0, int KT1, int KT2, int G, int NW, int PPW, bool WFIRST>
-__device__ __forceinline__ void rs_tile_mma(const RwParams &P, RsCtx &X, RsStage &stage, const uint4 (&ih)[KS],
-                                            const uint4 (&il)[KS], int base, f32x16 &acc_e, f32x16 &acc_o) {
+template <int KS, int G, int NW, int PPW, int DEPTH, bool WFIRST>
+__device__ __forceinline__ void rs_tile_mma(const RwParams &P, RsCtx &X, u32x4 (&st)[DEPTH][PPW],
+                                            const uint4 (&ih)[KS], const uint4 (&il)[KS], int base,
+                                            f32x16 &acc_e, f32x16 &acc_o) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         const int p = base + ks;
-        if (p % G == 0) rs_boundary<KT0, KT1, KT2, G, NW, PPW>(P, X, stage, p);
-        const uint4 wh = X.ring[X.abase + ((p % G) * 2) * 64];
-        const uint4 wl = X.ring[X.abase + ((p % G) * 2 + 1) * 64];
+        u32x4 ch, cl;
+        if (p % G == 0) {
+            rs_boundary<G, NW, PPW, DEPTH>(P, X, st, p);
+            ch = *(const u32x4 *)(X.ring + (X.abase + ((p % G) * 2) * 64));
+            cl = *(const u32x4 *)(X.ring + (X.abase + ((p % G) * 2 + 1) * 64));
+        } else {
+            ch = X.nh;
+            cl = X.nl;
+        }
+        // the next k-step tile's fragments are requested before this one's MFMAs are issued (one wave per SIMD:
+        // nobody else hides the LDS round trip); the first tile of a chunk cannot be requested before its barrier
+        if ((p + 1) % G != 0) {
+            X.nh = *(const u32x4 *)(X.ring + (X.abase + (((p + 1) % G) * 2) * 64));
+            X.nl = *(const u32x4 *)(X.ring + (X.abase + (((p + 1) % G) * 2 + 1) * 64));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const uint4 wh = __builtin_bit_cast(uint4, ch), wl = __builtin_bit_cast(uint4, cl);
         f32x16 &acc = (ks & 1) ? acc_o : acc_e;
         if (WFIRST) {
             acc = mfma_bf16(wh, ih[ks], acc);
@@ -471,24 +485,22 @@ __device__ __forceinline__ void load_bias_tile(const float *bias, int ct, int ha
     }
 }
 
-template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF, int G, int NBALL>
+template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF, int DEPTH, int NBALL>
 __global__ __launch_bounds__(NW * 64, WPE) void mlp_rs_kernel(RwParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KT0 = NT1 * KS0, KT1 = NT2 * KS1, KT2 = NT3 * KS2, TOT = KT0 + KT1 + KT2;
-    static_assert(TOT % G == 0, "chunk size must divide the k-step tiles of a pass");
-    constexpr int CPP = TOT / G;             // chunks per pass
+    static_assert(TOT % kRsCPP == 0 && kRsCPP % DEPTH == 0, "12 chunks per pass, staging depth a divisor of 12");
+    constexpr int G = TOT / kRsCPP;          // k-step tiles per chunk
     constexpr int PC = 2 * G;                // 1 KiB pieces (one plane of one k-step tile) per chunk
-    static_assert(PC % NW == 0, "pieces of a chunk must split evenly over the waves");
-    constexpr int PPW = PC / NW;             // pieces a wave moves per chunk
+    constexpr int PPW = (PC + NW - 1) / NW;  // pieces a wave moves per chunk (last round may be ragged)
     RsCtx X;
-    RsStage stage;           // the pieces of the next chunk this wave moves
-    static_assert(PPW <= 8, "staging registers");
+    u32x4 stage[DEPTH][PPW];                 // chunk k waits in stage[k % DEPTH]
     X.ring = (uint4 *)smem;
     float *b0 = (float *)(X.ring + 2 * PC * 64), *b1 = b0 + NT1 * 32, *b2 = b1 + NT2 * 32;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row = lane & 31, half = lane >> 5;
-    X.w = w; X.lane = lane; X.gc0 = 0; X.abase = 0;
+    X.w = w; X.lane = lane; X.abase = 0;
 
     for (int i = tid; i < NT1 * 32; i += NW * 64) b0[i] = P.bias[0][i];
     for (int i = tid; i < NT2 * 32; i += NW * 64) b1[i] = P.bias[1][i];
@@ -502,11 +514,12 @@ __global__ __launch_bounds__(NW * 64, WPE) void mlp_rs_kernel(RwParams P) {
     int uc = gw, tc = 0, uf = gw, tf = 0;
     if (tf + 1 < P.tpu) ++tf; else { uf += nwaves; tf = 0; }
 
-    // ---- prologue: chunk 0 into slot 0, chunk 1 staged; first tile's rows and features
-    rs_issue_chunk<KT0, KT1, KT2, G, NW, PPW>(P, X, stage, 0);
+    // ---- prologue: chunk 0 into slot 0, chunks 1 .. DEPTH staged; first tile's rows and features
+    rs_issue_chunk<G, NW, PPW>(P, X, stage[0], 0);
     RowRef cur = load_row_ref(P, uc < nunits ? uc : nunits - 1, tc, row);
-    rs_store_stage<G, NW, PPW>(X, stage, 0);
-    rs_issue_chunk<KT0, KT1, KT2, G, NW, PPW>(P, X, stage, 1 % CPP);
+    rs_store_stage<G, NW, PPW>(X, stage[0], 0);
+#pragma unroll
+    for (int k = 1; k <= DEPTH; ++k) rs_issue_chunk<G, NW, PPW>(P, X, stage[k % DEPTH], k % kRsCPP);
     float raw[KS0][8];
     {
         const RowTail tl = load_row_tail<TAILF>(P, cur);
@@ -534,7 +547,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void mlp_rs_kernel(RwParams P) {
             load_bias_tile(b0, ct, half, ae);
 #pragma unroll
             for (int r = 0; r < 16; ++r) ao[r] = 0.0f;
-            rs_tile_mma<KS0, KT0, KT1, KT2, G, NW, PPW, true>(P, X, stage, h0, l0, ct * KS0, ae, ao);
+            rs_tile_mma<KS0, G, NW, PPW, DEPTH, true>(P, X, stage, h0, l0, ct * KS0, ae, ao);
             ae += ao;
             acc_to_frags<KS1>(ae, ct, h1, l1);
         }
@@ -547,7 +560,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void mlp_rs_kernel(RwParams P) {
             load_bias_tile(b1, ct, half, ae);
 #pragma unroll
             for (int r = 0; r < 16; ++r) ao[r] = 0.0f;
-            rs_tile_mma<KS1, KT0, KT1, KT2, G, NW, PPW, true>(P, X, stage, h1, l1, KT0 + ct * KS1, ae, ao);
+            rs_tile_mma<KS1, G, NW, PPW, DEPTH, true>(P, X, stage, h1, l1, KT0 + ct * KS1, ae, ao);
             ae += ao;
             acc_to_frags<KS2>(ae, ct, h2, l2);
         }
@@ -570,14 +583,13 @@ __global__ __launch_bounds__(NW * 64, WPE) void mlp_rs_kernel(RwParams P) {
             f32x16 ae, ao;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { ae[r] = 0.0f; ao[r] = 0.0f; }
-            rs_tile_mma<KS2, KT0, KT1, KT2, G, NW, PPW, false>(P, X, stage, h2, l2, KT0 + KT1 + ct * KS2, ae, ao);
+            rs_tile_mma<KS2, G, NW, PPW, DEPTH, false>(P, X, stage, h2, l2, KT0 + KT1 + ct * KS2, ae, ao);
             ae += ao;
             float bm[4];
             tile_ball_max(ae, P.rp, bm);
 #pragma unroll
             for (int g = 0; g < NBALL; ++g) pooled[ct][g] = tp == 0 ? bm[g] : sa::fmax_nn(pooled[ct][g], bm[g]);
         }
-        X.gc0 += CPP;
         RW_TICK(4)
         // ---- write out after the last tile of the unit
         if (tp == P.tpu - 1 && T_u < nunits) {
@@ -636,10 +648,11 @@ int launch_rw(const RwParams &P, int wgs_per_cu, hipStream_t stream) {
     return SA_OK;
 }
 
-template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF, int G, int NBALL>
+template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF, int DEPTH, int NBALL>
 int launch_rs(const RwParams &P, int wgs_per_cu, hipStream_t stream) {
+    constexpr int G = (NT1 * KS0 + NT2 * KS1 + NT3 * KS2) / kRsCPP;
     constexpr size_t lds = (size_t)2 * 2 * G * 1024 + (size_t)(NT1 + NT2 + NT3) * 128;
-    auto kern = mlp_rs_kernel<KS0, NT1, KS1, NT2, KS2, NT3, NW, WPE, TAILF, G, NBALL>;
+    auto kern = mlp_rs_kernel<KS0, NT1, KS1, NT2, KS2, NT3, NW, WPE, TAILF, DEPTH, NBALL>;
     if (lds > 48 * 1024) {
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipGetLastError();
@@ -706,16 +719,19 @@ int sa_rowwave_try(int b, int n, int m, int ns, int c, const float *xyz, const f
         (const char *)wpack[1] == (const char *)wpack[0] + (size_t)NT1 * KS0 * 2048 &&
         (const char *)wpack[2] == (const char *)wpack[1] + (size_t)NT2 * KS1 * 2048;
     static const bool stream_enabled = !(getenv("SA_MLP_ROWSTREAM") && atoi(getenv("SA_MLP_ROWSTREAM")) == 0);
-#define SA_RS(K0, N1, K1, N2, K2, N3_, NW_, WPE_, WGS, G_)                                          \
+#define SA_RS(K0, N1, K1, N2, K2, N3_, NW_, WPE_, WGS, D_)                                          \
     if (stream_enabled && contiguous && c != 1 && KS0 == K0 && NT1 == N1 && KS1 == K1 && NT2 == N2 && KS2 == K2 && NT3 == N3_) { \
-        *st = P.rp >= 32 ? launch_rs<K0, N1, K1, N2, K2, N3_, NW_, WPE_, 0, G_, 1>(P, WGS, stream)   \
-            : (P.rp == 16 ? launch_rs<K0, N1, K1, N2, K2, N3_, NW_, WPE_, 0, G_, 2>(P, WGS, stream)  \
-                          : launch_rs<K0, N1, K1, N2, K2, N3_, NW_, WPE_, 0, G_, 4>(P, WGS, stream)); \
+        *st = P.rp >= 32 ? launch_rs<K0, N1, K1, N2, K2, N3_, NW_, WPE_, 0, D_, 1>(P, WGS, stream)   \
+            : (P.rp == 16 ? launch_rs<K0, N1, K1, N2, K2, N3_, NW_, WPE_, 0, D_, 2>(P, WGS, stream)  \
+                          : launch_rs<K0, N1, K1, N2, K2, N3_, NW_, WPE_, 0, D_, 4>(P, WGS, stream)); \
         return 1;                                                                                   \
     }
-    SA_RS(9, 4, 8, 4, 8, 8, 4, 1, 1, 12)      // 131 -> 128 -> 128 -> 256   (layer3 scale 0): 132 k-step tiles
-    SA_RS(9, 4, 8, 6, 12, 8, 4, 1, 1, 12)     // 131 -> 128 -> 192 -> 256   (layer3 scale 1): 180
-    SA_RS(9, 4, 8, 8, 16, 8, 4, 1, 1, 12)     // 131 -> 128 -> 256 -> 256   (layer3 scale 2): 228
+#ifndef SA_RS_DEPTH
+#define SA_RS_DEPTH 3
+#endif
+    SA_RS(9, 4, 8, 4, 8, 8, 4, 1, 1, SA_RS_DEPTH)      // 131 -> 128 -> 128 -> 256   (layer3 scale 0): 132 k-step tiles
+    SA_RS(9, 4, 8, 6, 12, 8, 4, 1, 1, SA_RS_DEPTH)     // 131 -> 128 -> 192 -> 256   (layer3 scale 1): 180
+    SA_RS(9, 4, 8, 8, 16, 8, 4, 1, 1, 2)               // 131 -> 128 -> 256 -> 256   (layer3 scale 2): 228
 #undef SA_RS
     return 0;
 }

@@ -26,7 +26,7 @@ class Proxy:
             waves, tiles = max(v[8], 1), max(v[7], 1)
             if v[7]:
                 if dims[0] > 100:    # streamed-weight kernel: phases are (prologue, compute, barrier wait, stage store, chunk issue, write)
-                    print("m=%d ns=%d %s: %.3f ms | waves %d tiles/wave %.1f | per wave: prologue %d | per tile: compute %d barrier-wait %d stage-store %d chunk-issue %d write %d | total/wave %d cycles" % (
+                    print("m=%d ns=%d %s: %.3f ms | waves %d tiles/wave %.1f | per wave: prologue %d | per tile: convert %d hidden0 %d hidden1 %d gather-issue+last %d write %d | total/wave %d cycles" % (
                         a[2], a[3], "-".join(map(str, dims)), s.elapsed_time(e), waves, tiles / waves, v[0] // waves,
                         v[1] // tiles, v[2] // tiles, v[3] // tiles, v[4] // tiles, v[5] // tiles, sum(v[:7]) // waves))
                 else:
