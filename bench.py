@@ -148,6 +148,8 @@ def _pmc_traffic(stage):
         while ppt * 1024 < n:
             ppt *= 2
         name = "fps3_reg_kernel<%d>" % ppt
+        if 8192 <= n <= 16384 and int(os.environ.get("SA_FPS_BUCKET_MIN_N", "8192")) > 0:
+            name = "fps3_wave_bucket_kernel"          # the culled kernel takes the layer-1 shape (fps.hip dispatch)
     elif stage["kernel"] == "sa_fps_with_distance_ex":
         n = int(label.split("n=")[1].split("->")[0])
         ppt = 1
@@ -175,7 +177,8 @@ def roofline_of(stage):
     if k.startswith("sa_fps"):
         # FPS is a serial dependent chain on ONE CU per frame: neither HBM- nor MFMA-bound;
         # the fp32 VALU rate is the meaningful ceiling, quoted beside the (tiny) algorithmic HBM figure.
-        r["note"] = "latency/VALU-bound serial chain; see valu_tflops"
+        r["note"] = ("latency/VALU-bound serial chain; valu_tflops counts the reference's n*(m-1) pair evaluations "
+                     "(the wave-bucket kernel used for n >= 8192 skips ~94% of them, bit-identically)")
         r["valu_tflops"] = stage.get("tflops", 0.0)
         r["valu_frac"] = round(stage.get("tflops", 0.0) / VALU_F32_PEAK_TF, 5)
         # one workgroup (one CU) per frame by construction: fraction of the fp32 VALU peak of the CUs it can use
