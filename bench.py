@@ -163,6 +163,28 @@ def _pmc_traffic(stage):
         return None
 
 
+def _pmc_mlp_util():
+    """MFMA utilisation of the grouped-MLP kernels from the committed PMC pass (profiles/r01_traffic.json):
+    sum of SQ_VALU_MFMA_BUSY_CYCLES over sum of (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), per launch, over the MLP
+    kernels of one step.  None when the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None
+    busy = cap = 0.0
+    per_kernel = {}
+    for k, e in d.items():
+        if ("mlp_r" in k or "group_mlp" in k) and "mfma_util" in e:
+            busy += e["mfma_busy_cycles_per_launch"]
+            cap += e["gui_active_cycles_per_launch"] / 8.0 * 1024.0
+            per_kernel[k] = e["mfma_util"]
+    if cap <= 0:
+        return None
+    return dict(mfma_util=round(busy / cap, 4), per_kernel=per_kernel,
+                source="profiles/r01_traffic.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE)")
+
+
 def roofline_of(stage):
     k = stage["kernel"]
     if k in ("sa_group_mlp_max", "sa_dense", "sa_calc_square_dist_split"):
@@ -325,7 +347,8 @@ def main():
             "roofline_grouped_mlp": {"bound": "mfma", "achieved": round(mlp_fl / mlp_ms, 3) if mlp_ms else 0.0,
                                      "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                                      "frac": round(mlp_fl / mlp_ms / MFMA_BF16_PEAK_TF, 5) if mlp_ms else 0.0,
-                                     "note": "algorithmic fp32-equivalent flops; the split-bf16 form issues 3x as many MFMA flops"},
+                                     "note": "algorithmic fp32-equivalent flops; the split-bf16 form issues 3x as many MFMA flops",
+                                     "pmc": _pmc_mlp_util()},
             "roofline_ball_query": {"bound": "hbm", "achieved": round(bq_mb / bq_ms, 2) if bq_ms else 0.0,
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": round(bq_mb / bq_ms / HBM_PEAK_GBS, 6) if bq_ms else 0.0},

@@ -43,4 +43,20 @@ for cname in ("FETCH_SIZE", "WRITE_SIZE"):
             tr.setdefault(k, {})[cname + "_KiB_per_launch"] = agg[k] / cnt[k]
 for k, d in tr.items():
     d["hbm_bytes_per_launch"] = int(1024 * (2.0 * d.get("FETCH_SIZE_KiB_per_launch", 0.0) + d.get("WRITE_SIZE_KiB_per_launch", 0.0)))
+# MFMA utilisation per kernel: SQ_VALU_MFMA_BUSY_CYCLES (summed over SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)
+for f in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter(); seen = set()
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] not in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"):
+            continue
+        k = short(r["Kernel_Name"])
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if (k, r["Dispatch_Id"]) not in seen:
+            seen.add((k, r["Dispatch_Id"])); cnt[k] += 1
+    for k, d in agg.items():
+        if d.get("GRBM_GUI_ACTIVE", 0) > 0 and "SQ_VALU_MFMA_BUSY_CYCLES" in d:
+            e = tr.setdefault(k, {})
+            e["mfma_busy_cycles_per_launch"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / cnt[k]
+            e["gui_active_cycles_per_launch"] = d["GRBM_GUI_ACTIVE"] / cnt[k]
+            e["mfma_util"] = round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 4)
 json.dump(tr, open(os.path.join(root, "traffic.json"), "w"), indent=1, sort_keys=True)
