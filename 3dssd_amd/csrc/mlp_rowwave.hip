@@ -395,7 +395,9 @@ __global__ __launch_bounds__(NW * 64, WPE) void mlp_rw_kernel(RwParams P) {
 //             -> issue the global loads of chunk c+1+DEPTH into that staging set -> compute on chunk c.
 // One barrier per chunk, every weight byte crosses L2 -> LDS once per NW*32 rows (mlp.hip: once per 32 rows),
 // and the loads of a chunk have DEPTH chunks of matrix work (~G*96 cycles per wave each) to land.
-// Two accumulators per output tile (even / odd k-steps) keep two independent MFMA chains in flight.
+// Eight waves per workgroup (two per SIMD): a wave's own MFMA and VALU work serialise on gfx950, the other
+// wave of the SIMD fills the gaps; that halves the register budget (256), hence one accumulator chain and the
+// next tile's loads issued after the tile instead of under its last layer.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector: plain loads / stores, no memcpy
 struct RsCtx {
     uint4 *ring;          // 2 slots x PC x 64 uint4
@@ -440,11 +442,13 @@ __device__ __forceinline__ void rs_boundary(const RwParams &P, RsCtx &X, u32x4 (
     __builtin_amdgcn_sched_barrier(0);
     X.abase = (cidx & 1) * 2 * G * 64 + X.lane;
 }
-// one output tile of a layer: k-step tiles base .. base+KS-1 of the stream, even / odd k-steps in two chains
+// one output tile of a layer: k-step tiles base .. base+KS-1 of the stream.  One accumulator chain: two waves
+// share a SIMD in this kernel, their chains interleave on the matrix pipe, and the register budget (256) has no
+// room for a second accumulator.
 template <int KS, int G, int NW, int PPW, int DEPTH, bool WFIRST>
 __device__ __forceinline__ void rs_tile_mma(const RwParams &P, RsCtx &X, u32x4 (&st)[DEPTH][PPW],
                                             const uint4 (&ih)[KS], const uint4 (&il)[KS], int base,
-                                            f32x16 &acc_e, f32x16 &acc_o) {
+                                            f32x16 &acc) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         const int p = base + ks;
@@ -465,7 +469,6 @@ __device__ __forceinline__ void rs_tile_mma(const RwParams &P, RsCtx &X, u32x4 (
             __builtin_amdgcn_sched_barrier(0);
         }
         const uint4 wh = __builtin_bit_cast(uint4, ch), wl = __builtin_bit_cast(uint4, cl);
-        f32x16 &acc = (ks & 1) ? acc_o : acc_e;
         if (WFIRST) {
             acc = mfma_bf16(wh, ih[ks], acc);
             acc = mfma_bf16(wl, ih[ks], acc);
@@ -543,12 +546,9 @@ __global__ __launch_bounds__(NW * 64, WPE) void mlp_rs_kernel(RwParams P) {
         uint4 h1[KS1], l1[KS1];
 #pragma unroll
         for (int ct = 0; ct < NT1; ++ct) {
-            f32x16 ae, ao;
+            f32x16 ae;
             load_bias_tile(b0, ct, half, ae);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ao[r] = 0.0f;
-            rs_tile_mma<KS0, G, NW, PPW, DEPTH, true>(P, X, stage, h0, l0, ct * KS0, ae, ao);
-            ae += ao;
+            rs_tile_mma<KS0, G, NW, PPW, DEPTH, true>(P, X, stage, h0, l0, ct * KS0, ae);
             acc_to_frags<KS1>(ae, ct, h1, l1);
         }
         RW_TICK(2)
@@ -556,35 +556,19 @@ __global__ __launch_bounds__(NW * 64, WPE) void mlp_rs_kernel(RwParams P) {
         uint4 h2[KS2], l2[KS2];
 #pragma unroll
         for (int ct = 0; ct < NT2; ++ct) {
-            f32x16 ae, ao;
+            f32x16 ae;
             load_bias_tile(b1, ct, half, ae);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ao[r] = 0.0f;
-            rs_tile_mma<KS1, G, NW, PPW, DEPTH, true>(P, X, stage, h1, l1, KT0 + ct * KS1, ae, ao);
-            ae += ao;
+            rs_tile_mma<KS1, G, NW, PPW, DEPTH, true>(P, X, stage, h1, l1, KT0 + ct * KS1, ae);
             acc_to_frags<KS2>(ae, ct, h2, l2);
         }
         RW_TICK(3)
-        // ---- the next tile's loads go out here: the input and first-hidden fragments are dead, their registers
-        //      hold the raw features until the next iteration converts them
-        if (tc + 1 < P.tpu) ++tc; else { uc += nwaves; tc = 0; }
-        if (tf + 1 < P.tpu) ++tf; else { uf += nwaves; tf = 0; }
-        cur = nxt;
-        {
-            const RowTail tl = load_row_tail<TAILF>(P, cur);
-#pragma unroll
-            for (int ks = 0; ks < KS0; ++ks) load_group(P, cur, tl, 2 * ks + half, raw[ks]);
-        }
-        nxt = load_row_ref(P, uf < nunits ? uf : nunits - 1, tf, row);
-        __builtin_amdgcn_sched_barrier(0);
         // ---- last layer (D form) + max over the rows of each ball
 #pragma unroll
         for (int ct = 0; ct < NT3; ++ct) {
-            f32x16 ae, ao;
+            f32x16 ae;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { ae[r] = 0.0f; ao[r] = 0.0f; }
-            rs_tile_mma<KS2, G, NW, PPW, DEPTH, false>(P, X, stage, h2, l2, KT0 + KT1 + ct * KS2, ae, ao);
-            ae += ao;
+            for (int r = 0; r < 16; ++r) ae[r] = 0.0f;
+            rs_tile_mma<KS2, G, NW, PPW, DEPTH, false>(P, X, stage, h2, l2, KT0 + KT1 + ct * KS2, ae);
             float bm[4];
             tile_ball_max(ae, P.rp, bm);
 #pragma unroll
@@ -612,6 +596,17 @@ __global__ __launch_bounds__(NW * 64, WPE) void mlp_rs_kernel(RwParams P) {
                 }
             }
         }
+        // ---- the next tile's rows: issued here, converted at the top of the next iteration (the other wave of
+        //      the SIMD works under their latency; during the last layer the register budget has no room for them)
+        if (tc + 1 < P.tpu) ++tc; else { uc += nwaves; tc = 0; }
+        if (tf + 1 < P.tpu) ++tf; else { uf += nwaves; tf = 0; }
+        cur = nxt;
+        {
+            const RowTail tl = load_row_tail<TAILF>(P, cur);
+#pragma unroll
+            for (int ks = 0; ks < KS0; ++ks) load_group(P, cur, tl, 2 * ks + half, raw[ks]);
+        }
+        nxt = load_row_ref(P, uf < nunits ? uf : nunits - 1, tf, row);
         RW_TICK(5)
     }
     RW_FLUSH(gw)
@@ -726,12 +721,10 @@ int sa_rowwave_try(int b, int n, int m, int ns, int c, const float *xyz, const f
                           : launch_rs<K0, N1, K1, N2, K2, N3_, NW_, WPE_, 0, D_, 4>(P, WGS, stream)); \
         return 1;                                                                                   \
     }
-#ifndef SA_RS_DEPTH
-#define SA_RS_DEPTH 3
-#endif
-    SA_RS(9, 4, 8, 4, 8, 8, 4, 1, 1, SA_RS_DEPTH)      // 131 -> 128 -> 128 -> 256   (layer3 scale 0): 132 k-step tiles
-    SA_RS(9, 4, 8, 6, 12, 8, 4, 1, 1, SA_RS_DEPTH)     // 131 -> 128 -> 192 -> 256   (layer3 scale 1): 180
-    SA_RS(9, 4, 8, 8, 16, 8, 4, 1, 1, 2)               // 131 -> 128 -> 256 -> 256   (layer3 scale 2): 228
+    // 8 waves (2 per SIMD, 256 registers each), 1 workgroup per CU; staging depth as the register budget allows
+    SA_RS(9, 4, 8, 4, 8, 8, 8, 2, 1, 2)       // 131 -> 128 -> 128 -> 256   (layer3 scale 0): 132 k-step tiles
+    SA_RS(9, 4, 8, 6, 12, 8, 8, 2, 1, 2)      // 131 -> 128 -> 192 -> 256   (layer3 scale 1): 180
+    SA_RS(9, 4, 8, 8, 16, 8, 8, 2, 1, 1)      // 131 -> 128 -> 256 -> 256   (layer3 scale 2): 228
 #undef SA_RS
     return 0;
 }
