@@ -210,6 +210,7 @@ __device__ __forceinline__ void gather8(const MlpParams &P, long pt, long ball, 
 template <int ROWS, int NTHR>
 __device__ __forceinline__ void gather_tile(const MlpParams &P, unsigned char *buf, int stride, long ball0,
                                             int pass, int G0, int tid) {
+    asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
     // rows lane and lane+64 (ROWS == 64) / lane&31 (ROWS == 32) resolved by this lane
     int r_pt[ROWS / 32 > 1 ? 1 : 1], r_ball[1];
@@ -486,6 +487,7 @@ template <int TG>
 __device__ __forceinline__ void wide_hidden(const unsigned char *in, int strideIn, unsigned char *outb,
                                             int strideOut, const LayerDesc &L, int tile_lo, int tile_hi,
                                             int lane, int w) {
+    asm volatile("" : "+v"(lane));
     const int half = lane >> 5, col = lane & 31;
     const unsigned char *arow0 = in + col * strideIn + half * 32;
     const unsigned char *arow1 = arow0 + 32 * strideIn;
@@ -574,6 +576,7 @@ __device__ __forceinline__ void wide_hidden(const unsigned char *in, int strideI
 template <int TGL>
 __device__ __forceinline__ void wide_last_partial(f32x16 (&acc)[TGL][2], const unsigned char *in, int strideIn,
                                                   const LayerDesc &L, int ks_lo, int ks_hi, int lane, int w) {
+    asm volatile("" : "+v"(lane));
     const int half = lane >> 5, col = lane & 31;
     const unsigned char *arow0 = in + col * strideIn + half * 32;
     const unsigned char *arow1 = arow0 + 32 * strideIn;
@@ -682,6 +685,7 @@ __device__ __forceinline__ void wide_item_layers(const WideParams &WP, unsigned 
         }
     }
     // pooling: row tile j covers rows 32j..32j+31 of the item
+    asm volatile("" : "+v"(lane));
     const int col = lane & 31;
 #pragma unroll
     for (int tt = 0; tt < TGL; ++tt) {
@@ -716,7 +720,7 @@ __global__ __launch_bounds__(kThreads, 2) void group_mlp_wide_kernel(WideParams 
     unsigned char *bufA = smem;
     unsigned char *bufB = smem + kWRows * P.strideA;
     float *pooled = (float *)(smem + P.pool_off);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bpi = P.rp <= 64 ? 64 / P.rp : 1;        // balls per item
     const int passes = P.rp <= 64 ? 1 : P.rp / 64;     // 64-row passes per item
     const long nitems = (P.nballs + bpi - 1) / bpi;
