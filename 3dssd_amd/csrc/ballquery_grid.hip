@@ -146,7 +146,8 @@ __global__ __launch_bounds__(kQWaves * 64) void bq_grid_query_kernel(int n, int 
                                                                      const int *__restrict__ ws, GBands B) {
     __shared__ int s_hits[kQWaves][kMaxBands][kCap];
     __shared__ int s_fcnt[kQWaves][kMaxBands];
-    const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // wave-uniform: the per-query loads are scalar
     const float *P = xyz1 + (size_t)b * n * 3;
     const int *cell_start = ws + (size_t)b * ws_stride(n);
     const int *sorted = cell_start + (kNC + 1);
@@ -162,26 +163,39 @@ __global__ __launch_bounds__(kQWaves * 64) void bq_grid_query_kernel(int n, int 
         const int x_lo = max(cx - 1, 0), x_hi = min(cx + 1, kNX - 1);
         int cnts[kMaxBands] = {0, 0, 0, 0};
         bool overflow = false;
-        for (int iz = max(cz - 1, 0); iz <= min(cz + 1, kNX - 1); ++iz) {
-            const int s = cell_start[iz * kNX + x_lo], e = cell_start[iz * kNX + x_hi + 1];   // 3 cells, one range
-            for (int pos0 = s; pos0 < e; pos0 += 64) {
-                const int pos = pos0 + lane;
-                const bool valid = pos < e;
-                const int k = sorted[valid ? pos : e - 1];
-                const float dx = x2 - P[k * 3 + 0], dy = y2 - P[k * 3 + 1], dz = z2 - P[k * 3 + 2];
-                const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));   // as ballquery.hip
-                if (__ballot(valid && d2 < B.thi_max) == 0ull) continue;
+        // the three z-rows of the 3 x 3 neighbourhood are three index ranges of `sorted` (3 cells each, contiguous
+        // in x).  Their bounds are fetched together and the candidates are walked as ONE flattened list, 64 per
+        // step: per query the dependent chain is bounds -> sorted index -> point, once, instead of once per row.
+        int rs[3], rc[3];
 #pragma unroll
-                for (int i = 0; i < kMaxBands; ++i) {
-                    if (i >= B.nbands) break;
-                    const bool hit = valid && (B.dilated ? (d2 == 0.0f || (d2 >= B.tlo[i] && d2 < B.thi[i])) : (d2 < B.thi[i]));
-                    const unsigned long long hm = __ballot(hit);
-                    if (hm != 0ull) {
-                        const int at = cnts[i] + __popcll(hm & ((1ull << lane) - 1ull));
-                        if (hit && at < kCap) hits[i][at] = k;
-                        cnts[i] += (int)__popcll(hm);
-                        overflow = overflow || cnts[i] > kCap;
-                    }
+        for (int r = 0; r < 3; ++r) {
+            const int iz = cz - 1 + r;
+            const bool in = iz >= 0 && iz < kNX;
+            const int izc = in ? iz : cz;
+            const int s = cell_start[izc * kNX + x_lo], e = cell_start[izc * kNX + x_hi + 1];
+            rs[r] = s;
+            rc[r] = in ? e - s : 0;
+        }
+        const int c01 = rc[0] + rc[1], T = c01 + rc[2];
+        for (int base = 0; base < T; base += 64) {
+            const int j = base + lane;
+            const bool valid = j < T;
+            const int jj = valid ? j : 0;
+            const int pos = jj < rc[0] ? rs[0] + jj : (jj < c01 ? rs[1] + (jj - rc[0]) : rs[2] + (jj - c01));
+            const int k = sorted[pos];
+            const float dx = x2 - P[k * 3 + 0], dy = y2 - P[k * 3 + 1], dz = z2 - P[k * 3 + 2];
+            const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));   // as ballquery.hip
+            if (__ballot(valid && d2 < B.thi_max) == 0ull) continue;
+#pragma unroll
+            for (int i = 0; i < kMaxBands; ++i) {
+                if (i >= B.nbands) break;
+                const bool hit = valid && (B.dilated ? (d2 == 0.0f || (d2 >= B.tlo[i] && d2 < B.thi[i])) : (d2 < B.thi[i]));
+                const unsigned long long hm = __ballot(hit);
+                if (hm != 0ull) {
+                    const int at = cnts[i] + __popcll(hm & ((1ull << lane) - 1ull));
+                    if (hit && at < kCap) hits[i][at] = k;
+                    cnts[i] += (int)__popcll(hm);
+                    overflow = overflow || cnts[i] > kCap;
                 }
             }
         }

@@ -258,14 +258,9 @@ __global__ __launch_bounds__(NW * 64, WPE) void mlp_rw_kernel(RwParams P) {
     __syncthreads();
     RW_TICK(0)
 
-    // A wave's own MFMA and VALU instructions do not overlap on gfx950, those of two waves on one SIMD do
-    // (tools/microbench/mfma_valu_overlap.hip).  Waves that start in lockstep stay in lockstep -- both in their
-    // matrix phase, then both in their VALU phase, each at half rate.  Unequal issue priorities break the tie:
-    // the high-priority wave runs at full rate and the other one's matrix work fills its VALU phases.
-    if (NW >= 8) {
-        if ((w / 4) & 1) __builtin_amdgcn_s_setprio(0);
-        else __builtin_amdgcn_s_setprio(2);
-    }
+    // (A wave's own MFMA and VALU instructions do not overlap on gfx950, those of two waves on one SIMD can --
+    //  tools/microbench/mfma_valu_overlap.hip.  Neither unequal s_setprio priorities nor staggered wave starts
+    //  changed the measured time of these kernels: it tracks MFMA-busy + VALU-issue cycles.)
     const int row = lane & 31, half = lane >> 5;
     const int gw = blockIdx.x * NW + w, nwaves = gridDim.x * NW;
     const int nunits = P.ntiles / P.tpu;
