@@ -205,6 +205,173 @@ __global__ __launch_bounds__(256) void sqdist_mfma_kernel(int n, int m, RowSrc A
     }
 }
 
+// ---- fp32 MFMA kernel, second form (the one the F-FPS matrix takes) ---------------------------------------
+// Same arithmetic as sqdist_mfma_kernel (same MFMA instruction, same k order, same norm chains, same final
+// expression -> bit-identical output), reorganised around what an ablation of that kernel showed on MI355X:
+// of 0.31 ms at the layer-2 shape, 0.15 ms were the operand staging (80 branchy dword loads + 80 ds_write_b32 +
+// 67 ds_read_b32 per thread and tile) and 0.145 ms the epilogue (64-bit address arithmetic, an LDS norm read
+// and a bounds check per element); the matrix instructions themselves ~0.02 ms.
+//   * up to 68 channels (34 k-pairs) per stage -- the whole K of the layer-2 call in one stage, two barriers
+//     per tile instead of ten;
+//   * the second piece of the rows (the features) is read as float4, 16 consecutive lanes per 256-byte row;
+//   * operands live in LDS as two PARITY PLANES per operand, plane[k & 1][row][k >> 1]: the MFMA lane
+//     (row, half) needs exactly the k of parity `half`, so its 34 values are 9 ds_read_b128 (136 ds_read_b32 in
+//     the first form);
+//   * epilogue: full tiles take a path without bounds checks, 32-bit element offsets from one 64-bit tile base,
+//     the 16 row norms of a lane fetched with 4 ds_read_b128 per row tile.
+constexpr int kKS2 = 36;            // channels per stage (two stages for the 67-channel layer-2 call; LDS 41 KB -> 3 workgroups per CU)
+constexpr int kPL = 20;             // floats per row in a parity plane (18 pairs + 2 padding; 80 B rows)
+
+template <bool SYM>
+__global__ __launch_bounds__(256, 4) void sqdist_mfma2_kernel(int n, int m, RowSrc A, RowSrc Bm,
+                                                             float *__restrict__ out) {
+    // plane[operand][parity][row][pair]; after the k loop the same memory is the per-wave transpose patches
+    __shared__ __attribute__((aligned(16))) float s_pl[2][2][kMT][kPL];
+    // the row norms live behind the four transpose patches in the same (by then dead) plane memory: 40 KiB of LDS
+    // in total, four workgroups per CU
+    static_assert(4 * 64 * 33 + 2 * kMT <= 2 * 2 * kMT * kPL, "patches + norms must fit the operand planes");
+    float *sA = &s_pl[0][0][0][0] + 4 * 64 * 33, *sB = sA + kMT;
+    const int b = blockIdx.z;
+    int bi = blockIdx.y, bj = blockIdx.x;
+    if (SYM) {                                    // linear id over the upper triangle (row-major)
+        const int T = (n + kMT - 1) / kMT;
+        int rem = blockIdx.x;
+        bi = 0;
+        while (rem >= T - bi) { rem -= T - bi; ++bi; }
+        bj = bi + rem;
+    }
+    const int i0 = bi * kMT, j0 = bj * kMT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 1, wc = w & 1;
+    const int half = lane >> 5, col = lane & 31;
+    const int c0 = A.c0, c1 = A.c1, c = c0 + c1;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.0f;
+    float nrm = 0.0f;   // |a_i|^2 (threads 0..127) or |b_j|^2 (threads 128..255), channel-ascending chain
+
+    for (int k0 = 0; k0 < c; k0 += kKS2) {
+        const int cnt = min(kKS2, c - k0);                 // channels of this stage
+        const int npairs = (cnt + 1) >> 1;
+        if (k0 > 0) __syncthreads();                       // the previous stage is fully consumed
+        // ---- stage the two operands: piece 0 (xyz) scalar, piece 1 (features) as float4
+#pragma unroll
+        for (int op = 0; op < 2; ++op) {
+            const RowSrc &S = op == 0 ? A : Bm;
+            const int r0 = op == 0 ? i0 : j0, nr = op == 0 ? n : m;
+            float (*P0)[kPL] = s_pl[op][0], (*P1)[kPL] = s_pl[op][1];
+            for (int e = tid; e < kMT * c0; e += 256) {    // piece 0
+                const int row = e / c0, ch = e - row * c0;
+                if (ch >= k0 && ch < k0 + cnt) {
+                    const long g = (long)b * nr + min(r0 + row, nr - 1);
+                    const float v = S.p0[g * c0 + ch];
+                    const int kk = ch - k0;
+                    ((kk & 1) ? P1 : P0)[row][kk >> 1] = v;
+                }
+            }
+            if (c1 > 0) {                                  // piece 1: float4 q of a row covers channels c0+4q .. c0+4q+3
+                const int Q = c1 >> 2;                     // (c1 % 4 == 0 checked on the host)
+                const int q_lo = max(0, (k0 - c0) >> 2), q_hi = min(Q, (k0 + cnt - c0 + 3) >> 2);
+                const int nq = q_hi - q_lo;
+                for (int e = tid; e < kMT * nq; e += 256) {
+                    const int row = e / nq, q = q_lo + (e - row * nq);
+                    const long g = (long)b * nr + min(r0 + row, nr - 1);
+                    const float4 v4 = *(const float4 *)(S.p1 + g * c1 + 4 * q);
+                    const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {
+                        const int kk = c0 + 4 * q + x - k0;
+                        if (kk >= 0 && kk < cnt) ((kk & 1) ? P1 : P0)[row][kk >> 1] = v[x];
+                    }
+                }
+            }
+            if (cnt & 1) {                                 // odd channel count: the last pair's second element is 0
+                for (int row = tid; row < kMT; row += 256) P1[row][cnt >> 1] = 0.0f;
+            }
+        }
+        __syncthreads();
+        // ---- squared norms: one row per thread, channels ascending (even from plane 0, odd from plane 1)
+        {
+            const int op = tid >> 7, t = tid & (kMT - 1);
+            const float *e0 = s_pl[op][0][t], *e1 = s_pl[op][1][t];
+            for (int p4 = 0; p4 < npairs; p4 += 4) {
+                const float4 a = *(const float4 *)(e0 + p4), d = *(const float4 *)(e1 + p4);
+                const float ev[4] = {a.x, a.y, a.z, a.w}, od[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    if (p4 + x < npairs) {
+                        nrm = __builtin_fmaf(ev[x], ev[x], nrm);
+                        if (2 * (p4 + x) + 1 < cnt) nrm = __builtin_fmaf(od[x], od[x], nrm);
+                    }
+                }
+            }
+        }
+        // ---- matrix work: four k-pairs per LDS round (one ds_read_b128 per 32-row / 32-column tile)
+        const float *pa0 = s_pl[0][half][wr * 64 + col], *pa1 = s_pl[0][half][wr * 64 + 32 + col];
+        const float *pb0 = s_pl[1][half][wc * 64 + col], *pb1 = s_pl[1][half][wc * 64 + 32 + col];
+        for (int p4 = 0; p4 < npairs; p4 += 4) {
+            const float4 a0 = *(const float4 *)(pa0 + p4), a1 = *(const float4 *)(pa1 + p4);
+            const float4 b0 = *(const float4 *)(pb0 + p4), b1 = *(const float4 *)(pb1 + p4);
+            const float av[2][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}};
+            const float bv[2][4] = {{b0.x, b0.y, b0.z, b0.w}, {b1.x, b1.y, b1.z, b1.w}};
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                if (p4 + x < npairs) {
+#pragma unroll
+                    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                        for (int tj = 0; tj < 2; ++tj)
+                            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ti][x], bv[tj][x], acc[ti][tj], 0, 0, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();                               // operand planes dead -> norms and transpose patches
+    if (tid < kMT) sA[tid] = nrm; else sB[tid - kMT] = nrm;
+    __syncthreads();
+
+    float (*sT)[33] = (float (*)[33])(&s_pl[0][0][0][0] + w * (64 * 33));     // this wave's 64 x 33 patch
+    const bool mirror = SYM && bi != bj;
+    const bool full = i0 + kMT <= n && j0 + kMT <= m;
+    float *tile = out + ((size_t)b * n + i0) * m + j0;                           // (i0, j0) of this frame
+    float *tileT = SYM ? out + ((size_t)b * n + j0) * n + i0 : nullptr;          // (j0, i0): the mirrored tile
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        float sa[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *(const float4 *)(sA + wr * 64 + ti * 32 + 8 * q + 4 * half);
+            sa[4 * q + 0] = v.x; sa[4 * q + 1] = v.y; sa[4 * q + 2] = v.z; sa[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            const int jl = wc * 64 + tj * 32 + col;
+            const float sb = sB[jl];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ir = (r & 3) + 8 * (r >> 2) + 4 * half;        // row inside the 32-row tile
+                const int il = wr * 64 + ti * 32 + ir;
+                const float v = (sa[r] + sb) - 2.0f * acc[ti][tj][r];
+                if (full || (i0 + il < n && j0 + jl < m)) tile[(unsigned)(il * m + jl)] = v;
+                if (SYM) sT[tj * 32 + col][ir] = v;
+            }
+        }
+        if (mirror) {                              // out[j][i] for rows j of this wave's patch, 32 columns i
+            for (int r2 = 0; r2 < 32; ++r2) {
+                const int r = r2 * 2 + half;       // two patch rows per step, 32 lanes (128 B) each
+                const int jl = wc * 64 + r, il = wr * 64 + ti * 32 + col;
+                if (full || (j0 + jl < n && i0 + il < n)) tileT[(unsigned)(jl * n + il)] = sT[r][col];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // a = [a0 | a1] rows [b,n,c0+c1], bb = [b0 | b1] rows [b,m,c0+c1]; out [b,n,m].
@@ -218,13 +385,21 @@ extern "C" int sa_calc_square_dist_split(int b, int n, int m, int c0, int c1, co
     if (use_valu) {
         dim3 grid((m + kT - 1) / kT, (n + kT - 1) / kT, b);
         hipLaunchKernelGGL(sqdist_kernel, grid, dim3(256), 0, stream, n, m, A, Bm, out);
-    } else if (n == m && a0 == b0 && a1 == b1) {   // the F-FPS case: symmetric, upper triangle only
-        const int T = (n + kMT - 1) / kMT;
-        dim3 grid(T * (T + 1) / 2, 1, b);
-        hipLaunchKernelGGL(sqdist_mfma_kernel<true>, grid, dim3(256), 0, stream, n, m, A, Bm, out);
     } else {
-        dim3 grid((m + kMT - 1) / kMT, (n + kMT - 1) / kMT, b);
-        hipLaunchKernelGGL(sqdist_mfma_kernel<false>, grid, dim3(256), 0, stream, n, m, A, Bm, out);
+        // second form: needs the feature piece readable as float4 and tile-relative offsets that fit 32 bits
+        static const bool v1_only = getenv("SA_SQDIST_V1") && atoi(getenv("SA_SQDIST_V1")) != 0;
+        const bool v2 = !v1_only && (c1 % 4) == 0 && ((uintptr_t)a1 % 16) == 0 && ((uintptr_t)b1 % 16) == 0 &&
+                        (long)kMT * (m > n ? m : n) + kMT < (1l << 31);
+        if (n == m && a0 == b0 && a1 == b1) {      // the F-FPS case: symmetric, upper triangle only
+            const int T = (n + kMT - 1) / kMT;
+            dim3 grid(T * (T + 1) / 2, 1, b);
+            if (v2) hipLaunchKernelGGL(sqdist_mfma2_kernel<true>, grid, dim3(256), 0, stream, n, m, A, Bm, out);
+            else hipLaunchKernelGGL(sqdist_mfma_kernel<true>, grid, dim3(256), 0, stream, n, m, A, Bm, out);
+        } else {
+            dim3 grid((m + kMT - 1) / kMT, (n + kMT - 1) / kMT, b);
+            if (v2) hipLaunchKernelGGL(sqdist_mfma2_kernel<false>, grid, dim3(256), 0, stream, n, m, A, Bm, out);
+            else hipLaunchKernelGGL(sqdist_mfma_kernel<false>, grid, dim3(256), 0, stream, n, m, A, Bm, out);
+        }
     }
     SA_CHECK_LAUNCH();
     return SA_OK;

@@ -389,6 +389,27 @@ def test_fps_bucket_all_identical_and_kitti_frame(gpu, oracle):
     assert np.array_equal(out.cpu().numpy(), oracle.farthest_point_sample(4096, pts))
 
 
+@pytest.mark.parametrize("n,c1", [(4096, 64), (512, 128), (700, 64), (130, 8), (257, 72)])
+def test_calc_square_dist_split_pieces(gpu, oracle, n, c1):
+    # the SA layer's own call: rows given as [xyz | features] without the concat (sa_calc_square_dist_split), the
+    # symmetric upper-triangle path of the second-form kernel incl. ragged edge tiles and two K stages (3 + 128)
+    import ctypes
+    N = pkg("utils._native")
+    rng = np.random.default_rng(n + c1)
+    xyz = rng.normal(0, 20.0, (2, n, 3)).astype(np.float32)
+    feat = rng.normal(0, 1.0, (2, n, c1)).astype(np.float32)
+    tx, tf = _t(xyz, gpu), _t(feat, gpu)
+    out = torch.empty((2, n, n), dtype=torch.float32, device=gpu)
+    st = N.lib().sa_calc_square_dist_split(2, n, n, 3, c1, tx.data_ptr(), tf.data_ptr(), tx.data_ptr(), tf.data_ptr(),
+                                           out.data_ptr(), N.current_stream())
+    assert st == 0
+    got = out.cpu().numpy()
+    cat = np.concatenate([xyz, feat], -1)
+    ref = oracle.calc_square_dist(cat, cat)
+    assert np.array_equal(got, ref)
+    assert np.array_equal(got, got.transpose(0, 2, 1))
+
+
 @pytest.mark.parametrize("n,c", [(300, 7), (512, 131), (1000, 67), (4096, 35)])
 def test_calc_square_dist_symmetric_path(gpu, oracle, n, c):
     # a is b (the F-FPS call): upper-triangle kernel with mirrored tiles, still bit-exact and bitwise symmetric
