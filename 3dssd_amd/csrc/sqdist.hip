@@ -222,7 +222,10 @@ __global__ __launch_bounds__(256) void sqdist_mfma_kernel(int n, int m, RowSrc A
 constexpr int kKS2 = 36;            // channels per stage (two stages for the 67-channel layer-2 call; LDS 41 KB -> 3 workgroups per CU)
 constexpr int kPL = 20;             // floats per row in a parity plane (18 pairs + 2 padding; 80 B rows)
 
-template <bool SYM>
+// NT: non-temporal stores -- a matrix far larger than L2 + Infinity Cache (537 MB at the layer-2 shape, of which
+// F-FPS later reads one row in eight) should not displace everything else (-5 %); the 8 MB layer-3 matrix is
+// written normally so that the FPS kernel finds its rows on chip (non-temporal there: F-FPS +30 %).
+template <bool SYM, bool NT>
 __global__ __launch_bounds__(256, 4) void sqdist_mfma2_kernel(int n, int m, RowSrc A, RowSrc Bm,
                                                              float *__restrict__ out) {
     // plane[operand][parity][row][pair]; after the k loop the same memory is the per-wave transpose patches
@@ -358,7 +361,10 @@ __global__ __launch_bounds__(256, 4) void sqdist_mfma2_kernel(int n, int m, RowS
                 const int ir = (r & 3) + 8 * (r >> 2) + 4 * half;        // row inside the 32-row tile
                 const int il = wr * 64 + ti * 32 + ir;
                 const float v = (sa[r] + sb) - 2.0f * acc[ti][tj][r];
-                if (full || (i0 + il < n && j0 + jl < m)) tile[(unsigned)(il * m + jl)] = v;
+                if (full || (i0 + il < n && j0 + jl < m)) {
+                    if (NT) __builtin_nontemporal_store(v, &tile[(unsigned)(il * m + jl)]);
+                    else tile[(unsigned)(il * m + jl)] = v;
+                }
                 if (SYM) sT[tj * 32 + col][ir] = v;
             }
         }
@@ -366,7 +372,10 @@ __global__ __launch_bounds__(256, 4) void sqdist_mfma2_kernel(int n, int m, RowS
             for (int r2 = 0; r2 < 32; ++r2) {
                 const int r = r2 * 2 + half;       // two patch rows per step, 32 lanes (128 B) each
                 const int jl = wc * 64 + r, il = wr * 64 + ti * 32 + col;
-                if (full || (j0 + jl < n && i0 + il < n)) tileT[(unsigned)(jl * n + il)] = sT[r][col];
+                if (full || (j0 + jl < n && i0 + il < n)) {
+                    if (NT) __builtin_nontemporal_store(sT[r][col], &tileT[(unsigned)(jl * n + il)]);
+                    else tileT[(unsigned)(jl * n + il)] = sT[r][col];
+                }
             }
         }
     }
@@ -390,14 +399,17 @@ extern "C" int sa_calc_square_dist_split(int b, int n, int m, int c0, int c1, co
         static const bool v1_only = getenv("SA_SQDIST_V1") && atoi(getenv("SA_SQDIST_V1")) != 0;
         const bool v2 = !v1_only && (c1 % 4) == 0 && ((uintptr_t)a1 % 16) == 0 && ((uintptr_t)b1 % 16) == 0 &&
                         (long)kMT * (m > n ? m : n) + kMT < (1l << 31);
+        const bool nt = (size_t)b * n * m * sizeof(float) > ((size_t)192 << 20);
         if (n == m && a0 == b0 && a1 == b1) {      // the F-FPS case: symmetric, upper triangle only
             const int T = (n + kMT - 1) / kMT;
             dim3 grid(T * (T + 1) / 2, 1, b);
-            if (v2) hipLaunchKernelGGL(sqdist_mfma2_kernel<true>, grid, dim3(256), 0, stream, n, m, A, Bm, out);
+            if (v2 && nt) hipLaunchKernelGGL((sqdist_mfma2_kernel<true, true>), grid, dim3(256), 0, stream, n, m, A, Bm, out);
+            else if (v2) hipLaunchKernelGGL((sqdist_mfma2_kernel<true, false>), grid, dim3(256), 0, stream, n, m, A, Bm, out);
             else hipLaunchKernelGGL(sqdist_mfma_kernel<true>, grid, dim3(256), 0, stream, n, m, A, Bm, out);
         } else {
             dim3 grid((m + kMT - 1) / kMT, (n + kMT - 1) / kMT, b);
-            if (v2) hipLaunchKernelGGL(sqdist_mfma2_kernel<false>, grid, dim3(256), 0, stream, n, m, A, Bm, out);
+            if (v2 && nt) hipLaunchKernelGGL((sqdist_mfma2_kernel<false, true>), grid, dim3(256), 0, stream, n, m, A, Bm, out);
+            else if (v2) hipLaunchKernelGGL((sqdist_mfma2_kernel<false, false>), grid, dim3(256), 0, stream, n, m, A, Bm, out);
             else hipLaunchKernelGGL(sqdist_mfma_kernel<false>, grid, dim3(256), 0, stream, n, m, A, Bm, out);
         }
     }
