@@ -61,7 +61,8 @@ def test_fps_tiebreak_and_fma_kats(gpu):
     assert S.farthest_point_sample(2, _t(p, gpu)).cpu().tolist() == [[0, 2]]   # fused chain, see KAT
 
 
-@pytest.mark.parametrize("b,n,c,m", [(2, 300, 5, 40), (1, 2048, 67, 128), (2, 512, 131, 64), (1, 20000, 3, 64)])
+@pytest.mark.parametrize("b,n,c,m", [(2, 300, 5, 40), (1, 2048, 67, 128), (2, 512, 131, 64), (1, 20000, 3, 64),
+                                     (2, 16384, 67, 192)])   # last: BASELINE.json configs[2] (F-FPS isolated, 3+64 channels)
 def test_fps_generic_channels_and_large_n(gpu, oracle, b, n, c, m):
     S = pkg("utils.tf_ops.sampling.tf_sampling")
     rng = np.random.default_rng(c + n)
