@@ -57,7 +57,7 @@ def lib():
             fn = getattr(h, name)  # AttributeError if the symbol is not exported
             fn.argtypes = argtypes
             fn.restype = _c_int
-        h.sa_query_ball_point_grid_ws_bytes.argtypes = [_c_int, _c_int]     # the one non-status function
+        h.sa_query_ball_point_grid_ws_bytes.argtypes = [_c_int, _c_int, _c_int]     # the one non-status function
         h.sa_query_ball_point_grid_ws_bytes.restype = ctypes.c_size_t
         _LIB = h
     return _LIB

@@ -188,7 +188,7 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
         cntp = (ctypes.c_void_p * nscale)(*[t.data_ptr() for t in cnt_list])
         if n_all >= GRID_BALL_QUERY_MIN_N and nscale <= 4:
             # large frames: per-frame x-z grid, candidates from the 3 x 3 cells around each centre (same outputs)
-            ws = torch.empty((lib.sa_query_ball_point_grid_ws_bytes(bs, n_all) + 3) // 4, dtype=torch.int32, device=dev)
+            ws = torch.empty((lib.sa_query_ball_point_grid_ws_bytes(bs, n_all, m) + 3) // 4, dtype=torch.int32, device=dev)
             st = lib.sa_query_ball_point_grid(bs, n_all, m, nscale, rmin, rmax, nsa, 1 if dilated_group else 0,
                                               xyz.data_ptr(), new_xyz.data_ptr(), idxp, cntp, ws.data_ptr(), stream)
         else:

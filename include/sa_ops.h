@@ -91,8 +91,8 @@ int sa_query_ball_point_multi(int b, int n, int m, int nbands, const float *rmin
 
 /* The same through a uniform x-z grid built per frame (3dssd_amd/csrc/ballquery_grid.hip): identical outputs,
  * ~10x fewer distance evaluations on large frames.  workspace: caller-owned device memory of
- * sa_query_ball_point_grid_ws_bytes(b, n) bytes; nbands <= 4. */
-unsigned long sa_query_ball_point_grid_ws_bytes(int b, int n);
+ * sa_query_ball_point_grid_ws_bytes(b, n, m) bytes; nbands <= 4. */
+unsigned long sa_query_ball_point_grid_ws_bytes(int b, int n, int m);
 int sa_query_ball_point_grid(int b, int n, int m, int nbands, const float *rmin, const float *rmax, const int *ns,
                              int dilated, const float *xyz1, const float *xyz2, int *const *idx, int *const *cnt,
                              void *workspace, sa_stream_t stream);

@@ -432,7 +432,7 @@ def _run_grid_bq(gpu, xyz1, xyz2, rmins, rmaxs, nss, dilated):
     t1, t2 = _t(xyz1, gpu), _t(xyz2, gpu)
     idx = [torch.full((b, m, s), -5, dtype=torch.int32, device=gpu) for s in nss]
     cnt = [torch.full((b, m), -5, dtype=torch.int32, device=gpu) for _ in nss]
-    ws = torch.empty((N.lib().sa_query_ball_point_grid_ws_bytes(b, n) + 3) // 4, dtype=torch.int32, device=gpu)
+    ws = torch.empty((N.lib().sa_query_ball_point_grid_ws_bytes(b, n, m) + 3) // 4, dtype=torch.int32, device=gpu)
     st = N.lib().sa_query_ball_point_grid(
         b, n, m, nb, (ctypes.c_float * nb)(*rmins), (ctypes.c_float * nb)(*rmaxs), (ctypes.c_int * nb)(*nss), int(dilated),
         t1.data_ptr(), t2.data_ptr(), (ctypes.c_void_p * nb)(*[t.data_ptr() for t in idx]),
