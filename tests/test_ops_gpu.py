@@ -260,7 +260,8 @@ def test_group_mlp_max(gpu, oracle, c, ns, dims):
                                          (64, 32, [40, 50, 100], 300), (1, 64, [32, 32, 64], 1100),
                                          (128, 32, [128, 128, 256], 45), (128, 16, [128, 256, 256], 45),
                                          (128, 64, [128, 192, 256], 20), (128, 8, [100, 130, 250], 33),
-                                         (128, 32, [128, 128, 256], 700)])
+                                         (128, 32, [128, 128, 256], 700), (256, 16, [256, 256, 512], 45),
+                                         (256, 32, [256, 512, 1024], 45), (256, 16, [256, 256, 512], 700)])
 def test_group_mlp_max_rowwave_shapes(gpu, oracle, c, ns, dims, m):
     # the LDS-resident-weight / register-resident-activation kernels (mlp_rowwave.hip; C = 128 rows take the
     # streamed-weight variant, several passes per workgroup at m = 700): every pooling layout
