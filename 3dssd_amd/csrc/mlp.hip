@@ -820,21 +820,39 @@ __device__ __forceinline__ void dense_body(const DenseParams &P, unsigned char *
             }
             __syncthreads();
             if (gb < L.NT) {
+                // k-steps batched behind a scheduling barrier like mma_k_loop: one L2 round trip per KB k-steps
                 const unsigned char *arow = buf + col * P.stride + half * 32;
-                const int ks0 = k0 / 16;
-                for (int ks = 0; ks < kc / 16; ++ks) {
-                    const uint4 ah = *(const uint4 *)(arow + ks * 64);
-                    const uint4 al = *(const uint4 *)(arow + ks * 64 + 16);
+                const int ks0 = k0 / 16, nks = kc / 16;
+                constexpr int KB = TG >= 4 ? 1 : (TG == 2 ? 2 : 4);
+                const uint4 *wb[TG];
 #pragma unroll
-                    for (int tt = 0; tt < TG; ++tt) {
-                        if (gb + tt < L.NT) {
-                            const uint4 *wp = L.w + ((size_t)((gb + tt) * L.KS + ks0 + ks) * 2) * 64 + lane;
-                            const uint4 wh = wp[0], wl = wp[64];
-                            acc[tt] = mfma_bf16(wh, ah, acc[tt]);
-                            acc[tt] = mfma_bf16(wl, ah, acc[tt]);
-                            acc[tt] = mfma_bf16(wh, al, acc[tt]);
+                for (int tt = 0; tt < TG; ++tt)
+                    wb[tt] = L.w + ((size_t)(min(gb + tt, L.NT - 1) * L.KS + ks0) * 2) * 64 + lane;
+                for (int ksb = 0; ksb < nks; ksb += KB) {
+                    uint4 wh[KB][TG], wl[KB][TG], ah[KB], al[KB];
+#pragma unroll
+                    for (int d = 0; d < KB; ++d) {
+                        const int ks = ksb + d < nks ? ksb + d : nks - 1;
+#pragma unroll
+                        for (int tt = 0; tt < TG; ++tt) { wh[d][tt] = wb[tt][ks * 128]; wl[d][tt] = wb[tt][ks * 128 + 64]; }
+                        ah[d] = *(const uint4 *)(arow + ks * 64);
+                        al[d] = *(const uint4 *)(arow + ks * 64 + 16);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int d = 0; d < KB; ++d) {
+                        if (ksb + d < nks) {
+#pragma unroll
+                            for (int tt = 0; tt < TG; ++tt) {
+                                if (gb + tt < L.NT) {
+                                    acc[tt] = mfma_bf16(wh[d][tt], ah[d], acc[tt]);
+                                    acc[tt] = mfma_bf16(wl[d][tt], ah[d], acc[tt]);
+                                    acc[tt] = mfma_bf16(wh[d][tt], al[d], acc[tt]);
+                                }
+                            }
                         }
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             __syncthreads();
