@@ -1,0 +1,154 @@
+"""Size-independent properties of the HIP path at BASELINE.json's FULL sizes (configs[1]: 8 frames x 16384 points,
+the whole backbone), where the CPU oracle would take minutes: things that must hold for any correct
+implementation of the reference operators and that a wrong kernel would almost surely break.
+
+  * D-FPS: first index 0, no repeated index, and the distance of every new pick to the already picked set is
+    non-increasing (the defining property of farthest-point sampling), checked with torch on the GPU;
+  * ball query: the first cnt entries of a row are strictly increasing point indices (the reference's scan
+    order), every one of them lies in the band, the padding repeats the first hit, cnt <= nsample, and a row with
+    cnt < nsample holds ALL points of the band (torch brute force on a sample of queries);
+  * distance matrix: bitwise symmetric;
+  * fused grouped MLP: invariant (bit for bit) under any permutation of the samples inside a ball;
+  * backbone: batched == frame by frame, bit for bit (no cross-frame coupling);
+  * determinism: two runs of the backbone give identical bits.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def frames(gpu):
+    syn = pkg("synthetic")
+    return torch.from_numpy(syn.kitti_like_batch(8)).to(gpu)
+
+
+def test_dfps_full_size_properties(gpu, frames):
+    S = pkg("utils.tf_ops.sampling.tf_sampling")
+    xyz = frames[:, :, :3].contiguous()
+    m = 4096
+    idx = S.farthest_point_sample(m, xyz)
+    torch.cuda.synchronize()
+    assert idx.shape == (8, m) and idx.dtype == torch.int32
+    assert (idx[:, 0] == 0).all()
+    for b in range(8):
+        assert torch.unique(idx[b]).numel() == m          # distinct points -> distinct picks
+    # distance of pick i to picks 0..i-1, in chunks (fp64 on the GPU): non-increasing
+    for b in (0, 5):
+        p = xyz[b, idx[b].long()].double()                # [m,3]
+        prev = None
+        mind = torch.full((m,), float("inf"), dtype=torch.float64, device=gpu)
+        for s in range(0, m, 512):
+            d = torch.cdist(p[s:s + 512], p)              # [512, m]
+            j = torch.arange(m, device=gpu)[None, :]
+            i = torch.arange(s, min(s + 512, m), device=gpu)[:, None]
+            d = torch.where(j < i, d, torch.full_like(d, float("inf")))
+            mind[s:s + 512] = d.min(1).values
+        seq = mind[1:]
+        assert (seq[1:] <= seq[:-1] * (1 + 1e-6)).all(), "FPS pick distances must be non-increasing"
+        assert seq[-1] > 0
+
+
+def test_ball_query_full_size_properties(gpu, frames):
+    S = pkg("utils.tf_ops.sampling.tf_sampling")
+    G = pkg("utils.tf_ops.grouping.tf_grouping")
+    xyz = frames[:, :, :3].contiguous()
+    ctr = S.gather_point(xyz, S.farthest_point_sample(4096, xyz))
+    for rmin, rmax, ns in ((0.0, 0.2, 32), (0.4, 0.8, 64)):
+        idx, cnt = G.query_ball_point_dilated(rmin, rmax, ns, xyz, ctr)
+        torch.cuda.synchronize()
+        assert idx.shape == (8, 4096, ns) and cnt.shape == (8, 4096)
+        assert (cnt >= 1).all() and (cnt <= ns).all()       # a centre is a member of xyz: d == 0 always hits
+        ar = torch.arange(ns, device=gpu)[None, None, :]
+        valid = ar < cnt[:, :, None]
+        # strictly increasing inside the valid prefix
+        inc = (idx[:, :, 1:] > idx[:, :, :-1]) | ~valid[:, :, 1:]
+        assert inc.all()
+        # padding repeats the first hit
+        assert ((idx == idx[:, :, :1]) | valid).all()
+        # every listed point is in the band (sqrt form of the reference, tf_grouping_g.cu:336-346)
+        g = torch.gather(xyz, 1, idx.reshape(8, -1, 1).expand(-1, -1, 3).long()).reshape(8, 4096, ns, 3)
+        d = torch.sqrt(((g - ctr[:, :, None, :]) ** 2).sum(-1))
+        ok = (d == 0) | ((d >= rmin) & (d < rmax))
+        assert (ok | ~valid).float().mean() > 0.99999       # fp32 re-association at the band edge only
+        # completeness on a sample of queries: cnt < ns  =>  cnt == number of band members
+        for b in (0, 7):
+            q = torch.arange(0, 4096, 37, device=gpu)
+            dd = torch.cdist(ctr[b, q].double(), xyz[b].double())
+            members = ((dd == 0) | ((dd >= rmin) & (dd < rmax))).sum(1)
+            c = cnt[b, q].long()
+            short = c < ns
+            assert ((members[short] - c[short]).abs() <= 1).all()   # +-1: a point exactly on the band edge
+            assert (members[~short] >= ns - 1).all()
+
+
+def test_distance_matrix_bitwise_symmetric_full_size(gpu):
+    M = pkg("utils.model_util")
+    g = torch.Generator(device="cpu").manual_seed(3)
+    a = torch.randn(2, 4096, 67, generator=g).to(gpu)
+    d = M.calc_square_dist(a, a)
+    torch.cuda.synchronize()
+    assert torch.equal(d, d.transpose(1, 2))
+    assert (torch.diagonal(d, dim1=1, dim2=2).abs() < 1e-3).all()
+
+
+@pytest.mark.parametrize("c,ns,dims", [(1, 32, [16, 16, 32]), (64, 64, [64, 96, 128]), (128, 32, [128, 192, 256]),
+                                       (256, 32, [256, 512, 1024])])
+def test_grouped_mlp_is_permutation_invariant_inside_a_ball(gpu, c, ns, dims):
+    import ctypes
+    N, Wt = pkg("utils._native"), pkg("utils.weights")
+    rng = np.random.default_rng(c + ns)
+    b, n, m = 2, 2048, 300
+    xyz = torch.from_numpy(rng.uniform(-5, 5, (b, n, 3)).astype(np.float32)).to(gpu)
+    feat = torch.from_numpy(rng.normal(0, 1, (b, n, c)).astype(np.float32)).to(gpu)
+    new_xyz = xyz[:, :m].contiguous()
+    idx = torch.from_numpy(rng.integers(0, n, (b, m, ns)).astype(np.int32)).to(gpu)
+    cnt = torch.full((b, m), ns, dtype=torch.int32, device=gpu)
+    ws = [rng.normal(0, 1.0 / np.sqrt(k), (k, o)).astype(np.float32) for k, o in zip([c + 3] + dims[:-1], dims)]
+    bs = [rng.normal(0, 0.1, o).astype(np.float32) for o in dims]
+    layers = Wt.pack_scale(ws, bs, gpu)
+    nl = len(layers)
+
+    def run(ix):
+        out = torch.empty((b, m, dims[-1]), dtype=torch.float32, device=gpu)
+        dm = (ctypes.c_int * (nl + 1))(*([c + 3] + dims))
+        st = N.lib().sa_group_mlp_max(b, n, m, ns, c, xyz.data_ptr(), feat.data_ptr(), new_xyz.data_ptr(), ix.data_ptr(),
+                                      cnt.data_ptr(), nl, dm, (ctypes.c_void_p * nl)(*[l.w.data_ptr() for l in layers]),
+                                      (ctypes.c_void_p * nl)(*[l.bias.data_ptr() for l in layers]), out.data_ptr(),
+                                      dims[-1], 0, N.current_stream())
+        assert st == 0
+        torch.cuda.synchronize()
+        return out
+
+    ref = run(idx)
+    perm = torch.from_numpy(np.stack([rng.permutation(ns) for _ in range(b * m)]).reshape(b, m, ns)).to(gpu)
+    shuffled = torch.gather(idx, 2, perm.long()).contiguous()
+    assert torch.equal(run(shuffled), ref)
+
+
+def test_backbone_batched_equals_per_frame_and_is_deterministic(gpu, frames):
+    cfgs, syn = pkg("configs"), pkg("synthetic")
+    arch = cfgs.KITTI_3DSSD_ARCH
+    params = syn.random_backbone_params(arch)
+    net = pkg("backbone").SABackbone(arch, params, gpu, cfgs.KITTI_MAX_TRANSLATE_RANGE)
+    xl, fl, il = net(frames)
+    torch.cuda.synchronize()
+    xl2, fl2, il2 = net(frames)
+    torch.cuda.synchronize()
+    for a, b_ in zip(xl + fl, xl2 + fl2):
+        if a is not None:
+            assert torch.equal(a, b_)
+    assert xl[-1].shape == (8, 256, 3) and fl[-1].shape == (8, 256, 512)
+    assert torch.isfinite(fl[-1]).all()
+    for f in (0, 3, 7):
+        x1, f1, i1 = net(frames[f:f + 1].contiguous())
+        torch.cuda.synchronize()
+        for li in range(1, len(xl)):
+            assert torch.equal(x1[li][0], xl[li][f]), "centres of list index %d differ for frame %d" % (li, f)
+            assert torch.equal(f1[li][0], fl[li][f]), "features of list index %d differ for frame %d" % (li, f)
+            if il[li] is not None:
+                assert torch.equal(i1[li][0], il[li][f])
