@@ -1,0 +1,95 @@
+"""Host-side KITTI input pipeline (3dssd_amd/dataset/kitti_input.py): calibration maths, crop semantics, resampling."""
+import numpy as np
+import pytest
+
+from conftest import pkg
+
+# calibration of KITTI object training frame 000000 (public devkit example values)
+CALIB_TXT = """P0: 7.070493e+02 0.000000e+00 6.040814e+02 0.000000e+00 0.000000e+00 7.070493e+02 1.805066e+02 0.000000e+00 0.000000e+00 0.000000e+00 1.000000e+00 0.000000e+00
+P2: 7.070493e+02 0.000000e+00 6.040814e+02 4.575831e+01 0.000000e+00 7.070493e+02 1.805066e+02 -3.454157e-01 0.000000e+00 0.000000e+00 1.000000e+00 4.981016e-03
+R0_rect: 9.999128e-01 1.009263e-02 -8.511932e-03 -1.012729e-02 9.999406e-01 -4.037671e-03 8.470675e-03 4.123522e-03 9.999556e-01
+Tr_velo_to_cam: 6.927964e-03 -9.999722e-01 -2.757829e-03 -2.457729e-02 -1.162982e-03 2.749836e-03 -9.999955e-01 -6.127237e-02 9.999753e-01 6.931141e-03 -1.143899e-03 -3.321029e-01
+Tr_imu_to_velo: 9.999976e-01 7.553071e-04 -2.035826e-03 -8.086759e-01 -7.854027e-04 9.998898e-01 -1.482298e-02 3.195559e-01 2.024406e-03 1.482454e-02 9.998881e-01 -7.997231e-01
+"""
+
+
+@pytest.fixture()
+def calib(tmp_path):
+    K = pkg("dataset.kitti_input")
+    p = tmp_path / "000000.txt"
+    p.write_text(CALIB_TXT)
+    return K.Calibration(str(p))
+
+
+def test_velo_to_rect_and_image_projection(calib):
+    pts = np.array([[10.0, 0.0, -1.0], [25.0, -3.0, 0.5], [5.0, 2.0, -1.5]])
+    rect = calib.project_velo_to_rect(pts)
+    # hand evaluation: R0 @ (V2C @ [p;1])
+    for p, r in zip(pts, rect):
+        ref = calib.V2C @ np.append(p, 1.0)
+        assert np.allclose(r, calib.R0 @ ref, rtol=0, atol=1e-12)
+    # velodyne x (forward) becomes rect z, velodyne -y (right) becomes rect x, velodyne -z becomes rect y
+    assert abs(rect[0, 2] - 10.0) < 0.5 and abs(rect[0, 0]) < 0.5 and abs(rect[0, 1] - 1.0) < 0.2
+    uv = calib.project_rect_to_image(rect)
+    for r, (u, v) in zip(rect, uv):
+        h = calib.P @ np.append(r, 1.0)
+        assert np.allclose([u, v], [h[0] / h[2], h[1] / h[2]])
+    assert 500 < uv[0, 0] < 720 and 150 < uv[0, 1] < 300          # a point straight ahead lands near the principal point
+
+
+def test_crop_semantics(calib):
+    K = pkg("dataset.kitti_input")
+    e = K.KITTI_POINT_CLOUD_RANGE
+    p = np.array([[0.0, 0.0, 10.0], [-40.0, 0.0, 10.0], [39.999, 0.0, 10.0], [0.0, 3.0, 10.0], [0.0, 2.999, 69.999],
+                  [0.0, 0.0, 0.0], [0.0, 0.0, 70.0]])
+    assert K.point_filter_extents(p, e).tolist() == [True, False, True, False, True, False, False]   # strict on both sides
+    rect = np.array([[0.0, 1.0, 10.0], [0.0, 1.0, -10.0], [30.0, 1.0, 10.0], [-30.0, 1.0, 10.0], [0.0, -20.0, 10.0]])
+    m = K.point_filter_in_image(rect, calib, 370, 1224)
+    assert m.tolist() == [True, False, False, False, False]       # behind the camera / left / right / above the image
+
+
+def test_prepare_frame_and_resample(calib, tmp_path):
+    K = pkg("dataset.kitti_input")
+    rng = np.random.default_rng(0)
+    n = 60000
+    scan = np.stack([rng.uniform(0, 80, n), rng.uniform(-40, 40, n), rng.uniform(-2.5, 1.0, n), rng.uniform(0, 1, n)], -1).astype(np.float32)
+    path = tmp_path / "000000.bin"
+    scan.tofile(str(path))
+    back = K.load_velo_scan(str(path))
+    assert back.shape == (n, 4) and np.array_equal(back, scan)
+    crop = K.crop_frame(back, calib, (370, 1224))
+    assert 1000 < crop.shape[0] < n
+    assert K.point_filter_extents(crop[:, :3], K.KITTI_POINT_CLOUD_RANGE).all() and (crop[:, 2] >= 0).all()
+    frame = K.prepare_frame(back, calib, (370, 1224), rng=np.random.default_rng(1))
+    assert frame.shape == (16384, 4) and frame.dtype == np.float32
+    assert 0.0 <= frame[:, 3].min() and frame[:, 3].max() <= 1.0
+    # enough points: a subset without repetition
+    big = np.arange(40000 * 4, dtype=np.float64).reshape(40000, 4)
+    s = K.resample(big, 16384, np.random.default_rng(2))
+    assert s.shape == (16384, 4) and len(np.unique(s[:, 0])) == 16384
+    # too few: every point at least once, the rest drawn with replacement (duplicates, like the real loader)
+    small = np.arange(5000 * 4, dtype=np.float64).reshape(5000, 4)
+    s = K.resample(small, 16384, np.random.default_rng(3))
+    assert s.shape == (16384, 4) and len(np.unique(s[:, 0])) == 5000
+    assert np.array_equal(np.sort(np.unique(s[:5000, 0])), small[:, 0])
+    with pytest.raises(ValueError):
+        K.resample(np.zeros((0, 4)), 16384)
+
+
+@pytest.mark.gpu
+def test_cropped_scan_through_the_backbone(gpu, calib):
+    # a synthetic velodyne sweep (ground plane + boxes) -> crop / resample -> SA backbone: shapes, finiteness,
+    # and (few points -> duplicated rows) the FPS tie-break path on real-loader-like input
+    import torch
+    K, cfgs, syn = pkg("dataset.kitti_input"), pkg("configs"), pkg("synthetic")
+    rng = np.random.default_rng(5)
+    n = 30000
+    az = rng.uniform(-0.7, 0.7, n); rr = rng.uniform(3, 70, n)
+    scan = np.stack([rr * np.cos(az), rr * np.sin(az), -1.7 + 0.02 * rng.standard_normal(n), rng.uniform(0, 1, n)], -1).astype(np.float32)
+    frame = K.prepare_frame(scan, calib, (370, 1224), rng=np.random.default_rng(6))
+    arch = cfgs.KITTI_3DSSD_ARCH
+    net = pkg("backbone").SABackbone(arch, syn.random_backbone_params(arch), gpu, cfgs.KITTI_MAX_TRANSLATE_RANGE)
+    xl, fl, il = net(torch.from_numpy(frame[None]).to(gpu))
+    torch.cuda.synchronize()
+    assert xl[-1].shape == (1, 256, 3) and fl[-1].shape == (1, 256, 512) and torch.isfinite(fl[-1]).all()
+    assert torch.unique(il[1][0]).numel() == 4096
