@@ -1,0 +1,109 @@
+// Feature-propagation operators of lib/utils/tf_ops/interpolation for gfx950: three_nn, three_interpolate,
+// k_interpolate (forward).  Not on the 3DSSD SA path (the PointRCNN configurations use them); part of the
+// reference's operator API surface.
+//
+// Arithmetic follows the reference's CPU implementations (tf_interpolate.cpp:86-156: threenn_cpu,
+// threeinterpolate_cpu), which oracle/_ref compiles and the golden vectors are generated from: every product and
+// sum a separate fp32 operation (this library is built with -ffp-contract=off), d = ((dx*dx + dy*dy) + dz*dz)
+// with dx = x2 - x1, three smallest by strict '<' insertion (equal distances keep index order), unfilled slots
+// (fewer than three known points) report inf / index 0; out = (p1*w1 + p2*w2) + p3*w3.
+// k_interpolate exists only as a CUDA kernel in the reference (tf_interpolate_g.cu:142-165): accumulated in index
+// order from 0 with one fused multiply-add per step (the nvcc contraction of `out += w * ci`).
+#include "sa_common.h"
+
+namespace {
+
+constexpr int kQT = 256;        // queries per workgroup (one per thread)
+constexpr int kKT = 2048;       // known points staged per LDS tile (24 KiB)
+
+__global__ __launch_bounds__(kQT) void three_nn_kernel(int n, int m, const float *__restrict__ xyz1,
+                                                       const float *__restrict__ xyz2, float *__restrict__ dist,
+                                                       int *__restrict__ idx) {
+    __shared__ float s_k[kKT * 3];
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * kQT + threadIdx.x;
+    const bool live = q < n;
+    const size_t qi = (size_t)b * n + (live ? q : n - 1);
+    const float x1 = xyz1[qi * 3 + 0], y1 = xyz1[qi * 3 + 1], z1 = xyz1[qi * 3 + 2];
+    const float *K = xyz2 + (size_t)b * m * 3;
+    const float kInf = __builtin_inff();                    // (float)1e40 of the reference's double 'best'
+    float b1 = kInf, b2 = kInf, b3 = kInf;
+    int i1 = 0, i2 = 0, i3 = 0;
+    for (int k0 = 0; k0 < m; k0 += kKT) {
+        const int nk = min(kKT, m - k0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < nk * 3; e += kQT) s_k[e] = K[(size_t)k0 * 3 + e];
+        __syncthreads();
+        for (int k = 0; k < nk; ++k) {
+            const float dx = s_k[k * 3 + 0] - x1, dy = s_k[k * 3 + 1] - y1, dz = s_k[k * 3 + 2] - z1;
+            const float d = (dx * dx + dy * dy) + dz * dz;
+            const int id = k0 + k;
+            if (d < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = id; }
+            else if (d < b2) { b3 = b2; i3 = i2; b2 = d; i2 = id; }
+            else if (d < b3) { b3 = d; i3 = id; }
+        }
+    }
+    if (live) {
+        dist[qi * 3 + 0] = b1; dist[qi * 3 + 1] = b2; dist[qi * 3 + 2] = b3;
+        idx[qi * 3 + 0] = i1; idx[qi * 3 + 1] = i2; idx[qi * 3 + 2] = i3;
+    }
+}
+
+// one thread per output element, consecutive threads = consecutive channels (coalesced in c)
+__global__ void three_interpolate_kernel(long total, int m, int c, int n, const float *__restrict__ points,
+                                         const int *__restrict__ idx, const float *__restrict__ weight,
+                                         float *__restrict__ out) {
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long j = e / c;                    // flat (batch, point)
+        const int l = (int)(e - j * c);
+        const float *P = points + (j / n) * (long)m * c;
+        const float w1 = weight[j * 3 + 0], w2 = weight[j * 3 + 1], w3 = weight[j * 3 + 2];
+        const float p1 = P[(long)idx[j * 3 + 0] * c + l], p2 = P[(long)idx[j * 3 + 1] * c + l],
+                    p3 = P[(long)idx[j * 3 + 2] * c + l];
+        out[e] = (p1 * w1 + p2 * w2) + p3 * w3;
+    }
+}
+
+__global__ void k_interpolate_kernel(long total, int m, int c, int n, int k, const float *__restrict__ points,
+                                     const int *__restrict__ idx, const float *__restrict__ weight,
+                                     float *__restrict__ out) {
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long j = e / c;
+        const int l = (int)(e - j * c);
+        const float *P = points + (j / n) * (long)m * c;
+        float acc = 0.0f;
+        for (int i = 0; i < k; ++i) acc = __builtin_fmaf(weight[j * k + i], P[(long)idx[j * k + i] * c + l], acc);
+        out[e] = acc;
+    }
+}
+
+}  // namespace
+
+// Reference launcher signatures (lib/utils/tf_ops/interpolation/tf_interpolate.cpp:215,285,407) + stream.
+extern "C" int sa_three_nn(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist, int *idx,
+                           hipStream_t stream) {
+    if (b <= 0 || n <= 0 || m <= 0 || !xyz1 || !xyz2 || !dist || !idx) return SA_ERR_INVALID;
+    hipLaunchKernelGGL(three_nn_kernel, dim3((n + kQT - 1) / kQT, b), dim3(kQT), 0, stream, n, m, xyz1, xyz2, dist, idx);
+    SA_CHECK_LAUNCH();
+    return SA_OK;
+}
+
+extern "C" int sa_three_interpolate(int b, int m, int c, int n, const float *points, const int *idx,
+                                    const float *weight, float *out, hipStream_t stream) {
+    if (b <= 0 || m <= 0 || c <= 0 || n <= 0 || !points || !idx || !weight || !out) return SA_ERR_INVALID;
+    const long total = (long)b * n * c;
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(three_interpolate_kernel, dim3(grid), dim3(256), 0, stream, total, m, c, n, points, idx, weight, out);
+    SA_CHECK_LAUNCH();
+    return SA_OK;
+}
+
+extern "C" int sa_k_interpolate(int b, int m, int c, int n, int k, const float *points, const int *idx,
+                                const float *weight, float *out, hipStream_t stream) {
+    if (b <= 0 || m <= 0 || c <= 0 || n <= 0 || k <= 0 || !points || !idx || !weight || !out) return SA_ERR_INVALID;
+    const long total = (long)b * n * c;
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(k_interpolate_kernel, dim3(grid), dim3(256), 0, stream, total, m, c, n, k, points, idx, weight, out);
+    SA_CHECK_LAUNCH();
+    return SA_OK;
+}

@@ -127,6 +127,18 @@ int sa_boxes_to_bev(long nboxes, const float *boxes, float *bev, sa_stream_t str
 int sa_nms_bev(int b, int n, int C, int max_out, float iou_threshold, const float *bev, const float *scores,
                int *idx, int *cnt, sa_stream_t stream);
 
+/* ---- lib/utils/tf_ops/interpolation (used by the PointRCNN configurations) ------------ */
+
+/* ThreeNNLauncher(b,n,m,xyz1,xyz2,dist,idx) -- tf_interpolate.cpp:215.  For each unknown point of xyz1 [b,n,3]
+ * the three nearest known points of xyz2 [b,m,3]: dist [b,n,3] SQUARED distances ascending, idx [b,n,3]. */
+int sa_three_nn(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist, int *idx, sa_stream_t stream);
+/* ThreeInterpolateLauncher(b,m,c,n,points,idx,weight,out) -- tf_interpolate.cpp:285.  out [b,n,c]. */
+int sa_three_interpolate(int b, int m, int c, int n, const float *points, const int *idx, const float *weight,
+                         float *out, sa_stream_t stream);
+/* KInterpolateLauncher(b,m,c,n,k,points,idx,weight,out) -- tf_interpolate.cpp:407. */
+int sa_k_interpolate(int b, int m, int c, int n, int k, const float *points, const int *idx, const float *weight,
+                     float *out, sa_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

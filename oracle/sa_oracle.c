@@ -312,3 +312,20 @@ void orc_group_mlp_max(int b, int n, int m, int ns, int c, const float *xyz, con
         free(buf1);
     }
 }
+
+/* ---- k_interpolate (lib/utils/tf_ops/interpolation/tf_interpolate_g.cu:142-165): GPU-only in the reference
+ * (three_nn / three_interpolate have CPU implementations there and are pinned against them through oracle/_ref,
+ * see oracle/interp_oracle.py).  out = sum_i w_i * p[idx_i] accumulated in index order starting from 0; the
+ * `out += w * ci` of the kernel contracts to one fused multiply-add per step under nvcc's default -fmad=true
+ * (same convention as decision A above). */
+void orc_k_interpolate(int b, int m, int c, int n, int k, const float *points, const int *idx,
+                       const float *weight, float *out) {
+    for (long j = 0; j < (long)b * n; ++j) {
+        const float *pts = points + (j / n) * (long)m * c;
+        for (int l = 0; l < c; ++l) {
+            float acc = 0.0f;
+            for (int i = 0; i < k; ++i) acc = fmaf(weight[j * k + i], pts[(long)idx[j * k + i] * c + l], acc);
+            out[j * c + l] = acc;
+        }
+    }
+}
