@@ -636,11 +636,14 @@ __device__ __forceinline__ int tile_ball_max(const f32x16 &a, int rp, float (&bm
         auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
         qm[q] = sa::fmax_nn(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
     }
-    if (rp == 8) { bm[0] = qm[0]; bm[1] = qm[1]; bm[2] = qm[2]; bm[3] = qm[3]; return 4; }
-    if (rp == 16) { bm[0] = sa::fmax_nn(qm[0], qm[1]); bm[1] = sa::fmax_nn(qm[2], qm[3]); bm[2] = bm[3] = 0.f; return 2; }
-    bm[0] = sa::fmax_nn(sa::fmax_nn(qm[0], qm[1]), sa::fmax_nn(qm[2], qm[3]));
-    bm[1] = bm[2] = bm[3] = 0.f;
-    return 1;
+    // selects, not branches: branches turn bm[] into a private-memory object
+    const float m01 = sa::fmax_nn(qm[0], qm[1]), m23 = sa::fmax_nn(qm[2], qm[3]);
+    const float mall = sa::fmax_nn(m01, m23);
+    bm[0] = rp == 8 ? qm[0] : (rp == 16 ? m01 : mall);
+    bm[1] = rp == 8 ? qm[1] : (rp == 16 ? m23 : 0.0f);
+    bm[2] = rp == 8 ? qm[2] : 0.0f;
+    bm[3] = rp == 8 ? qm[3] : 0.0f;
+    return rp == 8 ? 4 : (rp == 16 ? 2 : 1);
 }
 
 template <int TGL>
