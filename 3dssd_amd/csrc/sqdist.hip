@@ -219,6 +219,7 @@ __global__ __launch_bounds__(256) void sqdist_mfma_kernel(int n, int m, RowSrc A
 //     the first form);
 //   * epilogue: full tiles take a path without bounds checks, 32-bit element offsets from one 64-bit tile base,
 //     the 16 row norms of a lane fetched with 4 ds_read_b128 per row tile.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 constexpr int kKS2 = 36;            // channels per stage (two stages for the 67-channel layer-2 call; LDS 41 KB -> 3 workgroups per CU)
 constexpr int kPL = 20;             // floats per row in a parity plane (18 pairs + 2 padding; 80 B rows)
 
@@ -232,8 +233,8 @@ __global__ __launch_bounds__(256, 4) void sqdist_mfma2_kernel(int n, int m, RowS
     __shared__ __attribute__((aligned(16))) float s_pl[2][2][kMT][kPL];
     // the row norms live behind the four transpose patches in the same (by then dead) plane memory: 40 KiB of LDS
     // in total, four workgroups per CU
-    static_assert(4 * 64 * 33 + 2 * kMT <= 2 * 2 * kMT * kPL, "patches + norms must fit the operand planes");
-    float *sA = &s_pl[0][0][0][0] + 4 * 64 * 33, *sB = sA + kMT;
+    static_assert(4 * 32 * 68 + 2 * kMT <= 2 * 2 * kMT * kPL, "patches + norms must fit the operand planes");
+    float *sA = &s_pl[0][0][0][0] + 4 * 32 * 68, *sB = sA + kMT;
     const int b = blockIdx.z;
     int bi = blockIdx.y, bj = blockIdx.x;
     if (SYM) {                                    // linear id over the upper triangle (row-major)
@@ -339,9 +340,13 @@ __global__ __launch_bounds__(256, 4) void sqdist_mfma2_kernel(int n, int m, RowS
     if (tid < kMT) sA[tid] = nrm; else sB[tid - kMT] = nrm;
     __syncthreads();
 
-    float (*sT)[33] = (float (*)[33])(&s_pl[0][0][0][0] + w * (64 * 33));     // this wave's 64 x 33 patch
+    // Stores go through a per-wave LDS patch so that every lane writes 16 bytes: a (ti) strip of the wave's tile is
+    // 32 rows x 64 columns; row-major in the patch it leaves as 4 rows x 256 B per store instruction, transposed
+    // (64 patch rows x 32 columns) as 8 rows x 128 B for the mirrored tile.  (Straight from the accumulator layout
+    // the stores are dword stores of 2 rows x 128 B.)  Edge tiles (n not a multiple of 128) take the scalar path.
+    float *patch = &s_pl[0][0][0][0] + w * (32 * 68);                            // 32 x 68 floats, also viewed 64 x 34
     const bool mirror = SYM && bi != bj;
-    const bool full = i0 + kMT <= n && j0 + kMT <= m;
+    const bool full = i0 + kMT <= n && j0 + kMT <= m && (m & 3) == 0 && (!SYM || (n & 3) == 0);
     float *tile = out + ((size_t)b * n + i0) * m + j0;                           // (i0, j0) of this frame
     float *tileT = SYM ? out + ((size_t)b * n + j0) * n + i0 : nullptr;          // (j0, i0): the mirrored tile
 #pragma unroll
@@ -352,30 +357,69 @@ __global__ __launch_bounds__(256, 4) void sqdist_mfma2_kernel(int n, int m, RowS
             const float4 v = *(const float4 *)(sA + wr * 64 + ti * 32 + 8 * q + 4 * half);
             sa[4 * q + 0] = v.x; sa[4 * q + 1] = v.y; sa[4 * q + 2] = v.z; sa[4 * q + 3] = v.w;
         }
+        float vv[2][16];
 #pragma unroll
         for (int tj = 0; tj < 2; ++tj) {
-            const int jl = wc * 64 + tj * 32 + col;
-            const float sb = sB[jl];
+            const float sb = sB[wc * 64 + tj * 32 + col];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ir = (r & 3) + 8 * (r >> 2) + 4 * half;        // row inside the 32-row tile
-                const int il = wr * 64 + ti * 32 + ir;
-                const float v = (sa[r] + sb) - 2.0f * acc[ti][tj][r];
-                if (full || (i0 + il < n && j0 + jl < m)) {
-                    if (NT) __builtin_nontemporal_store(v, &tile[(unsigned)(il * m + jl)]);
-                    else tile[(unsigned)(il * m + jl)] = v;
-                }
-                if (SYM) sT[tj * 32 + col][ir] = v;
-            }
+            for (int r = 0; r < 16; ++r) vv[tj][r] = (sa[r] + sb) - 2.0f * acc[ti][tj][r];
         }
-        if (mirror) {                              // out[j][i] for rows j of this wave's patch, 32 columns i
-            for (int r2 = 0; r2 < 32; ++r2) {
-                const int r = r2 * 2 + half;       // two patch rows per step, 32 lanes (128 B) each
-                const int jl = wc * 64 + r, il = wr * 64 + ti * 32 + col;
-                if (full || (j0 + jl < n && i0 + il < n)) {
-                    if (NT) __builtin_nontemporal_store(sT[r][col], &tileT[(unsigned)(jl * n + il)]);
-                    else tileT[(unsigned)(jl * n + il)] = sT[r][col];
+        if (full) {
+            // ---- direct tile: patch[ir][tj*32 + col], read back as float4 rows
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * half) * 68 + tj * 32 + col] = vv[tj][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int pr = it * 4 + (lane >> 4), pc = (lane & 15) * 4;       // 4 rows x 16 lanes x 16 B
+                const float4 q4 = *(const float4 *)(patch + pr * 68 + pc);
+                f32x4v *dst = (f32x4v *)(tile + (unsigned)((wr * 64 + ti * 32 + pr) * m + wc * 64 + pc));
+                const f32x4v qv = {q4.x, q4.y, q4.z, q4.w};
+                if (NT) __builtin_nontemporal_store(qv, dst); else *dst = qv;
+            }
+            if (mirror) {
+                // ---- mirrored tile: patch viewed as [64 columns j][34]: patchT[tj*32 + col][ir]
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) patch[(tj * 32 + col) * 34 + (r & 3) + 8 * (r >> 2) + 4 * half] = vv[tj][r];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int pj = it * 8 + (lane >> 3), pi = (lane & 7) * 4;    // 8 rows x 8 lanes x 16 B
+                    const float *src = patch + pj * 34 + pi;                     // 8-byte aligned rows: two float2 reads
+                    const float2 lo2 = *(const float2 *)src, hi2 = *(const float2 *)(src + 2);
+                    const float4 q4 = make_float4(lo2.x, lo2.y, hi2.x, hi2.y);
+                    f32x4v *dst = (f32x4v *)(tileT + (unsigned)((wc * 64 + pj) * n + wr * 64 + ti * 32 + pi));
+                    const f32x4v qv = {q4.x, q4.y, q4.z, q4.w};
+                    if (NT) __builtin_nontemporal_store(qv, dst); else *dst = qv;
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        } else {
+            float (*sT)[34] = (float (*)[34])patch;
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) {
+                const int jl = wc * 64 + tj * 32 + col;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ir = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int il = wr * 64 + ti * 32 + ir;
+                    if (i0 + il < n && j0 + jl < m) tile[(unsigned)(il * m + jl)] = vv[tj][r];
+                    if (SYM) sT[tj * 32 + col][ir] = vv[tj][r];
+                }
+            }
+            if (mirror) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int r2 = 0; r2 < 32; ++r2) {
+                    const int r = r2 * 2 + half;
+                    const int jl = wc * 64 + r, il = wr * 64 + ti * 32 + col;
+                    if (j0 + jl < n && i0 + il < n) tileT[(unsigned)(jl * n + il)] = sT[r][col];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
         }
     }
