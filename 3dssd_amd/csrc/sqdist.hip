@@ -220,6 +220,17 @@ __global__ __launch_bounds__(256) void sqdist_mfma_kernel(int n, int m, RowSrc A
 //   * epilogue: full tiles take a path without bounds checks, 32-bit element offsets from one 64-bit tile base,
 //     the 16 row norms of a lane fetched with 4 ds_read_b128 per row tile.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+#ifdef SA_SQ_TIMING
+// debug build only (tools/sqdist_ab.py): phase clocks of wave 0 of every workgroup, summed
+__device__ unsigned long long g_sq_prof[8];
+#define SQ_T0() unsigned long long t__ = __builtin_readcyclecounter(), acc__[6] = {0, 0, 0, 0, 0, 0}
+#define SQ_TICK(i) { const unsigned long long n__ = __builtin_readcyclecounter(); acc__[i] += n__ - t__; t__ = n__; }
+#define SQ_FLUSH() if (tid == 0) { for (int i__ = 0; i__ < 6; ++i__) atomicAdd(&g_sq_prof[i__], acc__[i__]); atomicAdd(&g_sq_prof[7], 1ull); }
+#else
+#define SQ_T0()
+#define SQ_TICK(i)
+#define SQ_FLUSH()
+#endif
 constexpr int kKS2 = 36;            // channels per stage (two stages for the 67-channel layer-2 call; LDS 41 KB -> 3 workgroups per CU)
 constexpr int kPL = 20;             // floats per row in a parity plane (18 pairs + 2 padding; 80 B rows)
 
@@ -259,6 +270,7 @@ __global__ __launch_bounds__(256, 4) void sqdist_mfma2_kernel(int n, int m, RowS
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.0f;
     float nrm = 0.0f;   // |a_i|^2 (threads 0..127) or |b_j|^2 (threads 128..255), channel-ascending chain
+    SQ_T0();
 
     for (int k0 = 0; k0 < c; k0 += kKS2) {
         const int cnt = min(kKS2, c - k0);                 // channels of this stage
@@ -282,16 +294,31 @@ __global__ __launch_bounds__(256, 4) void sqdist_mfma2_kernel(int n, int m, RowS
             if (c1 > 0) {                                  // piece 1: float4 q of a row covers channels c0+4q .. c0+4q+3
                 const int Q = c1 >> 2;                     // (c1 % 4 == 0 checked on the host)
                 const int q_lo = max(0, (k0 - c0) >> 2), q_hi = min(Q, (k0 + cnt - c0 + 3) >> 2);
-                const int nq = q_hi - q_lo;
-                for (int e = tid; e < kMT * nq; e += 256) {
-                    const int row = e / nq, q = q_lo + (e - row * nq);
-                    const long g = (long)b * nr + min(r0 + row, nr - 1);
-                    const float4 v4 = *(const float4 *)(S.p1 + g * c1 + 4 * q);
-                    const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+                const int nq = q_hi - q_lo;                // <= 10 float4 per row and stage
+                // all loads of the stage first, then the LDS stores: a rolled load -> store loop pays one full
+                // memory round trip per iteration (measured: 145k of a tile's 230k cycles)
+                constexpr int kMaxIt = (kMT * 10 + 255) / 256;
+                float4 v4[kMaxIt];
+                int rowv[kMaxIt], qv[kMaxIt];
 #pragma unroll
-                    for (int x = 0; x < 4; ++x) {
-                        const int kk = c0 + 4 * q + x - k0;
-                        if (kk >= 0 && kk < cnt) ((kk & 1) ? P1 : P0)[row][kk >> 1] = v[x];
+                for (int it = 0; it < kMaxIt; ++it) {
+                    const int e = tid + it * 256;
+                    const bool in = e < kMT * nq;
+                    const int row = in ? e / nq : 0, q = in ? q_lo + (e - row * nq) : q_lo;
+                    rowv[it] = in ? row : -1;
+                    qv[it] = q;
+                    const long g = (long)b * nr + min(r0 + row, nr - 1);
+                    v4[it] = *(const float4 *)(S.p1 + g * c1 + 4 * q);
+                }
+#pragma unroll
+                for (int it = 0; it < kMaxIt; ++it) {
+                    if (rowv[it] >= 0) {
+                        const float v[4] = {v4[it].x, v4[it].y, v4[it].z, v4[it].w};
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) {
+                            const int kk = c0 + 4 * qv[it] + x - k0;
+                            if (kk >= 0 && kk < cnt) ((kk & 1) ? P1 : P0)[rowv[it]][kk >> 1] = v[x];
+                        }
                     }
                 }
             }
@@ -299,7 +326,9 @@ __global__ __launch_bounds__(256, 4) void sqdist_mfma2_kernel(int n, int m, RowS
                 for (int row = tid; row < kMT; row += 256) P1[row][cnt >> 1] = 0.0f;
             }
         }
+        SQ_TICK(0)
         __syncthreads();
+        SQ_TICK(1)
         // ---- squared norms: one row per thread, channels ascending (even from plane 0, odd from plane 1)
         {
             const int op = tid >> 7, t = tid & (kMT - 1);
@@ -316,6 +345,7 @@ __global__ __launch_bounds__(256, 4) void sqdist_mfma2_kernel(int n, int m, RowS
                 }
             }
         }
+        SQ_TICK(2)
         // ---- matrix work: four k-pairs per LDS round (one ds_read_b128 per 32-row / 32-column tile)
         const float *pa0 = s_pl[0][half][wr * 64 + col], *pa1 = s_pl[0][half][wr * 64 + 32 + col];
         const float *pb0 = s_pl[1][half][wc * 64 + col], *pb1 = s_pl[1][half][wc * 64 + 32 + col];
@@ -336,6 +366,7 @@ __global__ __launch_bounds__(256, 4) void sqdist_mfma2_kernel(int n, int m, RowS
             }
         }
     }
+    SQ_TICK(3)
     __syncthreads();                               // operand planes dead -> norms and transpose patches
     if (tid < kMT) sA[tid] = nrm; else sB[tid - kMT] = nrm;
     __syncthreads();
@@ -423,7 +454,23 @@ __global__ __launch_bounds__(256, 4) void sqdist_mfma2_kernel(int n, int m, RowS
             }
         }
     }
+    SQ_TICK(4)
+    SQ_FLUSH()
 }
+
+#ifdef SA_SQ_TIMING
+}  // namespace
+extern "C" int sa_debug_sq_prof(unsigned long long *host8, int reset) {
+    if (host8 && hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_sq_prof), sizeof(g_sq_prof)) != hipSuccess) return SA_ERR_LAUNCH;
+    if (reset) {
+        void *d = nullptr;
+        if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_sq_prof)) != hipSuccess) return SA_ERR_LAUNCH;
+        if (hipMemset(d, 0, sizeof(g_sq_prof)) != hipSuccess) return SA_ERR_LAUNCH;
+    }
+    return SA_OK;
+}
+namespace {
+#endif
 
 }  // namespace
 

@@ -20,3 +20,10 @@ for path in sys.argv[1:]:
     for _ in range(10): run()
     e.record(); torch.cuda.synchronize()
     print("%-40s %.3f ms" % (os.path.basename(path), s.elapsed_time(e) / 10))
+    if hasattr(lib, "sa_debug_sq_prof"):
+        h = (ctypes.c_ulonglong * 8)()
+        lib.sa_debug_sq_prof.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.sa_debug_sq_prof(None, 1); run(); torch.cuda.synchronize(); lib.sa_debug_sq_prof(h, 0)
+        v = list(h); wg = max(v[7], 1)
+        print("   per workgroup (thread 0) cycles: stage loads+LDS %d | barrier %d | norms %d | k-loop %d | barrier+ %d... epilogue %d  (workgroups %d)" % (
+            v[0] // wg, v[1] // wg, v[2] // wg, v[3] // wg, 0, v[4] // wg, wg))
