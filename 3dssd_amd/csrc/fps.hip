@@ -308,6 +308,9 @@ int ppt_for(int n) {
 extern "C" int sa_fps_bucket_ex(int b, int n, int m, const float *inp, int *out, int out_stride, int idx_off,
                                 hipStream_t stream);
 
+extern "C" int sa_fps_coop_ex(int b, int n, int c, int m, const float *inp, float *temp, int *out, int out_stride,
+                              int idx_off, hipStream_t stream);
+
 extern "C" int sa_fps_ex(int b, int n, int c, int m, const float *inp, float *temp, int *out,
                          int out_stride, int idx_off, hipStream_t stream) {
     if (b <= 0 || n <= 0 || c <= 0 || m <= 0 || !inp || !out || out_stride < m) return SA_ERR_INVALID;
@@ -325,6 +328,9 @@ extern "C" int sa_fps_ex(int b, int n, int c, int m, const float *inp, float *te
         }
     } else {
         if (!temp) return SA_ERR_INVALID;
+        // frames too large for one CU's registers/LDS: several cooperating workgroups per frame (fps_coop.hip)
+        const int rc = sa_fps_coop_ex(b, n, c, m, inp, temp, out, out_stride, idx_off, stream);
+        if (rc != SA_ERR_UNSUPPORTED) return rc;
         if (!launch_points_tiled(b, n, c, m, inp, temp, out, out_stride, idx_off, stream))
             hipLaunchKernelGGL(fps_generic_kernel<0>, dim3(b), dim3(kBlock), 0, stream, n, c, m, inp, temp,
                                out, out_stride, idx_off);

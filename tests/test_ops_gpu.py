@@ -71,6 +71,32 @@ def test_fps_generic_channels_and_large_n(gpu, oracle, b, n, c, m):
     assert np.array_equal(got, oracle.farthest_point_sample(m, p))
 
 
+@pytest.mark.parametrize("b,n,c,m,dup", [(2, 5000, 67, 300, 1500), (2, 40000, 3, 200, 8000), (1, 65536, 3, 96, 0),
+                                         (20, 8200, 67, 24, 100), (3, 1500, 67, 64, 700)])
+def test_fps_cooperative_kernel_matches_oracle(gpu, oracle, b, n, c, m, dup):
+    # several workgroups per frame (fps_coop.hip): duplicated rows put equal maxima into DIFFERENT workgroups, so
+    # the explicit (k mod 1024, k div 1024) key decides; b = 20 needs two cooperative launches at 16 WGs/frame
+    S = pkg("utils.tf_ops.sampling.tf_sampling")
+    rng = np.random.default_rng(n + c + m)
+    p = rng.normal(0, 1, (b, n, c)).astype(np.float32)
+    if dup:
+        for i in range(b):
+            p[i, rng.integers(0, n, dup)] = p[i, rng.integers(0, n, dup)]
+    got = S.farthest_point_sample(m, _t(p, gpu)).cpu().numpy()
+    assert np.array_equal(got, oracle.farthest_point_sample(m, p))
+
+
+def test_fps_cooperative_kernel_all_identical_and_two_values(gpu, oracle):
+    S = pkg("utils.tf_ops.sampling.tf_sampling")
+    p = np.ones((2, 20000, 3), np.float32)
+    assert (S.farthest_point_sample(40, _t(p, gpu)).cpu().numpy() == 0).all()
+    # two distinct locations only: every pick after the second is a pure tie-break over thousands of candidates
+    q = np.zeros((1, 9000, 67), np.float32)
+    q[0, 1::2] = 1.0
+    got = S.farthest_point_sample(12, _t(q, gpu)).cpu().numpy()
+    assert np.array_equal(got, oracle.farthest_point_sample(12, q))
+
+
 def test_fps_forced_generic_kernel_equals_register_kernel(gpu, oracle):
     N = pkg("utils._native")
     rng = np.random.default_rng(5)

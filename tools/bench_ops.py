@@ -63,22 +63,22 @@ out.append(dict(op="query_ball_point_dilated x3 (API, one band per call)", case=
                 gbs=round(by / ms3 / 1e6, 1), hbm_frac=round(by / ms3 / 1e6 / HBM, 5), pair_evals=B * 3 * 16384 * 4096))
 ms = timeit(lambda: S.gather_point(torch.randn(1, 1, 1, device=dev).expand(B, 512, 256).contiguous(), fidx[:, :256] % 512), iters=5)
 # BASELINE.json configs[2]: F-FPS isolated, 16384 -> 4096 on 3 + 64 channels, batch 32, through the reference API
-# (farthest_point_sample on a c-channel tensor: the generic global-scratch kernel -- the matrix form of the
-# backbone would need a 1.07 GB matrix per frame).  One shot: ~4 095 x 4.4 MB of L2 reads per frame.
-pf = torch.randn(32, 16384, 67, device=dev)
+# (farthest_point_sample on a c-channel tensor -- the matrix form of the backbone would need a 1.07 GB matrix per
+# frame): fps_coop.hip, 16 cooperating workgroups per frame, 16 frames per launch.
+pf = torch.randn(32, 16384, 67, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
 S.farthest_point_sample(8, pf); torch.cuda.synchronize()
 t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 t0.record(); S.farthest_point_sample(4096, pf); t1.record(); torch.cuda.synchronize()
 ms = t0.elapsed_time(t1)
 out.append(dict(op="farthest_point_sample c=67 (configs[2])", case="32 x 16384 -> 4096", ms=round(ms, 2),
-                frames_per_s=round(32 / ms * 1e3, 1), pair_evals=32 * 16384 * 4095, note="generic kernel, one CU per frame"))
-# BASELINE.json configs[4]: 65536-point frames, batch 16: layer-1 D-FPS (global-scratch kernel) and ball query
+                frames_per_s=round(32 / ms * 1e3, 1), pair_evals=32 * 16384 * 4095, note="fps_coop.hip: 16 workgroups per frame, points in registers (single-workgroup tiled kernel: 1117 ms)"))
+# BASELINE.json configs[4]: 65536-point frames, batch 16: layer-1 D-FPS (cooperative kernel) and ball query
 p64 = torch.from_numpy(syn.kitti_like_batch(16, n=65536)).to(dev)[:, :, :3].contiguous()
 S.farthest_point_sample(8, p64); torch.cuda.synchronize()
 t0.record(); f64 = S.farthest_point_sample(4096, p64); t1.record(); torch.cuda.synchronize()
 ms = t0.elapsed_time(t1)
 out.append(dict(op="farthest_point_sample c=3 (configs[4])", case="16 x 65536 -> 4096", ms=round(ms, 2),
-                frames_per_s=round(16 / ms * 1e3, 1), note="generic kernel (n > 16384)"))
+                frames_per_s=round(16 / ms * 1e3, 1), note="fps_coop.hip: 16 workgroups per frame (single-workgroup global-scratch kernel: 135 ms)"))
 c64 = S.gather_point(p64, f64)
 ms = timeit(lambda: G.query_ball_point_dilated(0.4, 0.8, 64, p64, c64), iters=5)
 by = 16 * (65536 * 12 + 4096 * 12 + 4096 * 65 * 4)

@@ -1,0 +1,7 @@
+#!/bin/bash
+OUT=gpurun_out/coop; mkdir -p $OUT
+export TMPDIR=/tmp PYTHONUNBUFFERED=1
+python -c "import __graft_entry__ as g; g.build()" 2>&1 | tail -1
+timeout 600 python -m pytest tests/test_ops_gpu.py -x -q -m gpu -k "fps" 2>&1 | tail -5
+timeout 300 python tools/fps_coop_bench.py 2>&1 | grep -v amdgpu.ids | tee $OUT/coop.jsonl
+SA_FPS_COOP_PLAIN=1 timeout 300 python tools/fps_coop_bench.py 2>&1 | grep -v amdgpu.ids | tee $OUT/plain.jsonl
