@@ -7,6 +7,8 @@ implementation of the reference operators and that a wrong kernel would almost s
   * ball query: the first cnt entries of a row are strictly increasing point indices (the reference's scan
     order), every one of them lies in the band, the padding repeats the first hit, cnt <= nsample, and a row with
     cnt < nsample holds ALL points of the band (torch brute force on a sample of queries);
+  * cooperative FPS (configs[2] c = 67 and configs[4] n = 65536, full size): the same FPS properties, and its
+    first picks equal those of the independent single-workgroup kernel;
   * distance matrix: bitwise symmetric;
   * fused grouped MLP: invariant (bit for bit) under any permutation of the samples inside a ball;
   * backbone: batched == frame by frame, bit for bit (no cross-frame coupling, SURVEY.md 8e);
@@ -51,6 +53,49 @@ def test_dfps_full_size_properties(gpu, frames):
         seq = mind[1:]
         assert (seq[1:] <= seq[:-1] * (1 + 1e-6)).all(), "FPS pick distances must be non-increasing"
         assert seq[-1] > 0
+
+
+def _fps_sequence_is_farthest_first(xyz_b, idx_b, gpu):
+    """distance of pick i to picks 0..i-1 is non-increasing in i (fp64 on the GPU); returns the last distance"""
+    m = idx_b.numel()
+    p = xyz_b[idx_b.long()].double()
+    mind = torch.full((m,), float("inf"), dtype=torch.float64, device=gpu)
+    for s in range(0, m, 512):
+        d = torch.cdist(p[s:s + 512], p)
+        j = torch.arange(m, device=gpu)[None, :]
+        i = torch.arange(s, min(s + 512, m), device=gpu)[:, None]
+        mind[s:s + 512] = torch.where(j < i, d, torch.full_like(d, float("inf"))).min(1).values
+    seq = mind[1:]
+    assert (seq[1:] <= seq[:-1] * (1 + 1e-6)).all(), "FPS pick distances must be non-increasing"
+    return float(seq[-1])
+
+
+@pytest.mark.parametrize("b,n,c,m", [(32, 16384, 67, 4096),     # BASELINE.json configs[2]: F-FPS isolated, 3 + 64 channels
+                                     (16, 65536, 3, 4096)])     # configs[4]: 65536-point frames
+def test_cooperative_fps_full_size_properties(gpu, b, n, c, m):
+    """fps_coop.hip at the full sizes of configs[2] / configs[4]: FPS properties, and the first picks equal the
+    single-workgroup global-scratch kernel's (an independent implementation; all m picks would take it seconds)."""
+    import ctypes
+    S, N = pkg("utils.tf_ops.sampling.tf_sampling"), pkg("utils._native")
+    if c == 3:
+        x = torch.from_numpy(pkg("synthetic").kitti_like_batch(b, n=n)).to(gpu)[:, :, :3].contiguous()
+    else:
+        x = torch.randn(b, n, c, device=gpu, generator=torch.Generator(device=gpu).manual_seed(5))
+    idx = S.farthest_point_sample(m, x)
+    torch.cuda.synchronize()
+    assert idx.shape == (b, m) and (idx[:, 0] == 0).all()
+    assert int(idx.min()) >= 0 and int(idx.max()) < n
+    for f in range(b):
+        assert torch.unique(idx[f]).numel() == m
+    for f in (0, b - 1):
+        assert _fps_sequence_is_farthest_first(x[f], idx[f], gpu) > 0
+    k = 48
+    sub = x[b - 2:].contiguous()
+    temp = torch.empty((2, n), dtype=torch.float32, device=gpu)
+    out = torch.empty((2, k), dtype=torch.int32, device=gpu)
+    assert N.lib().sa_fps_generic(2, n, c, k, sub.data_ptr(), temp.data_ptr(), out.data_ptr(), 0, N.current_stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, idx[b - 2:, :k])
 
 
 def test_ball_query_full_size_properties(gpu, frames):
