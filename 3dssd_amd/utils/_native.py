@@ -62,6 +62,8 @@ def lib():
             fn.restype = _c_int
         h.sa_query_ball_point_grid_ws_bytes.argtypes = [_c_int, _c_int, _c_int]     # the one non-status function
         h.sa_query_ball_point_grid_ws_bytes.restype = ctypes.c_size_t
+        h.sa_host_crc32c.argtypes = [_vp, ctypes.c_size_t, ctypes.c_uint32]          # host helper: returns the CRC
+        h.sa_host_crc32c.restype = ctypes.c_uint32
         _LIB = h
     return _LIB
 

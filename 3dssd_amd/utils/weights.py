@@ -94,6 +94,21 @@ class VariableStore:
         self.device = torch.device(device)
         self._cache = {}
 
+    @classmethod
+    def from_checkpoint(cls, path, device, verify=True):
+        """Variables of a TensorFlow checkpoint written by the reference's trainer (`tf.train.Saver`,
+        lib/core/trainer.py:157-174): `path` is a checkpoint prefix (`.../model-80000`) or a directory holding a
+        `checkpoint` state file.  Read without TensorFlow (tf_checkpoint.py); optimizer slots are dropped."""
+        import os
+        from . import tf_checkpoint
+        if os.path.isdir(path):
+            prefix = tf_checkpoint.latest_checkpoint(path)
+            if prefix is None:
+                raise FileNotFoundError("no `checkpoint` state file in %s" % path)
+        else:
+            prefix = path
+        return cls(tf_checkpoint.load_checkpoint(prefix, verify=verify), device)
+
     def layer(self, scope, bn=True):
         key = (scope, bool(bn))
         if key not in self._cache:

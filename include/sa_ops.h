@@ -18,6 +18,8 @@
 #ifndef SA_OPS_H
 #define SA_OPS_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -138,6 +140,12 @@ int sa_three_interpolate(int b, int m, int c, int n, const float *points, const 
 /* KInterpolateLauncher(b,m,c,n,k,points,idx,weight,out) -- tf_interpolate.cpp:407. */
 int sa_k_interpolate(int b, int m, int c, int n, int k, const float *points, const int *idx, const float *weight,
                      float *out, sa_stream_t stream);
+
+/* ---- host-side helper (no device work) --------------------------------------------------------------------- */
+/* CRC-32C of `len` bytes continuing from `crc` (0 to start): the checksum of TensorFlow tensor-bundle checkpoints
+ * (tensorflow/core/lib/hash/crc32c.h), used by 3dssd_amd/utils/tf_checkpoint.py when importing the reference's
+ * saved weights (lib/core/trainer.py:157-174).  Returns the checksum, not a status. */
+unsigned int sa_host_crc32c(const void *data, size_t len, unsigned int crc);
 
 #ifdef __cplusplus
 }
