@@ -66,3 +66,112 @@ extern "C" int sa_group_point(int b, int n, int c, int m, int nsample, const flo
         return SA_ERR_INVALID;
     return launch_gather<true>(b, n, c, (long)m * nsample, points, idx, out, stream);
 }
+
+// ---- the gradients of the two gathers and gather_by_mask ---------------------------------
+namespace {
+
+// dst[batch(r), idx[r], :] += g[r, :]  (idx == -1 rows skipped when NEG1_SKIP).  Float atomics like the reference
+// (tf_sampling_g.cu:339-351, tf_grouping_g.cu:384-400): the summation order of rows that hit the same point is not
+// defined there either.
+template <bool NEG1_SKIP>
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(long total, int c, int n, long rows_per_batch,
+                                                               const float *__restrict__ g,
+                                                               const int *__restrict__ idx, float *dst) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / c;
+        const int ch = (int)(i - r * c);
+        const long bi = r / rows_per_batch;
+        const int a = idx[r];
+        if (NEG1_SKIP && a == -1) continue;
+        atomicAdd(dst + ((size_t)bi * n + a) * c + ch, g[i]);
+    }
+}
+
+template <bool NEG1_SKIP>
+int launch_scatter(int b, int n, int c, long rows_per_batch, const float *g, const int *idx, float *dst,
+                   hipStream_t stream) {
+    if (hipMemsetAsync(dst, 0, (size_t)b * n * c * sizeof(float), stream) != hipSuccess) return SA_ERR_LAUNCH;
+    const long total = (long)b * rows_per_batch * c;
+    long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(scatter_add_rows_kernel<NEG1_SKIP>, dim3((unsigned)blocks), dim3(256), 0, stream, total, c, n,
+                       rows_per_batch, g, idx, dst);
+    SA_CHECK_LAUNCH();
+    return SA_OK;
+}
+
+constexpr int kMaskBlock = 256;
+
+// One workgroup per frame: the first proposal_num points with int(mask) != 0, in point order; rows past the number
+// found repeat the first one (tf_sampling_g.cu:356-384).  No selected point at all: zero rows (the reference leaves
+// the output uninitialised).
+__global__ __launch_bounds__(kMaskBlock) void gather_by_mask_kernel(int n, int c, int proposal_num,
+                                                                    const float *__restrict__ inp,
+                                                                    const float *__restrict__ mask,
+                                                                    float *__restrict__ out, int *__restrict__ sel) {
+    __shared__ int s_wave[kMaskBlock / 64];
+    __shared__ int s_total;
+    const int bi = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const float *mk = mask + (size_t)bi * n;
+    int *sl = sel + (size_t)bi * proposal_num;
+    if (t == 0) s_total = 0;
+    __syncthreads();
+    for (int k0 = 0; k0 < n; k0 += kMaskBlock) {
+        const int base = s_total;
+        if (base >= proposal_num) break;                         // uniform: s_total is read after a barrier
+        const int k = k0 + t;
+        const bool on = k < n && (int)mk[k] != 0;                // tf_sampling_g.cu:366
+        const unsigned long long hit = __ballot(on);
+        if (lane == 0) s_wave[w] = __builtin_popcountll(hit);
+        __syncthreads();
+        int before = base, all = 0;
+        for (int i = 0; i < kMaskBlock / 64; ++i) {
+            before += i < w ? s_wave[i] : 0;
+            all += s_wave[i];
+        }
+        const int pos = before + __builtin_popcountll(hit & ((1ull << lane) - 1ull));
+        if (on && pos < proposal_num) sl[pos] = k;
+        __syncthreads();
+        if (t == 0) s_total = base + all;
+        __syncthreads();
+    }
+    const int cnt = s_total < proposal_num ? s_total : proposal_num;
+    __threadfence_block();
+    const float *src = inp + (size_t)bi * n * c;
+    float *dst = out + (size_t)bi * proposal_num * c;
+    const long total = (long)proposal_num * c;
+    for (long i = t; i < total; i += kMaskBlock) {
+        const int r = (int)(i / c);
+        const int ch = (int)(i - (long)r * c);
+        dst[i] = cnt == 0 ? 0.0f : src[(size_t)sl[r < cnt ? r : 0] * c + ch];
+    }
+}
+
+}  // namespace
+
+// scatteraddpointLauncher(b,n,m,c,out_g,idx,inp_g) -- tf_sampling.cpp:261; inp_g is zeroed here (the op's cudaMemset,
+// tf_sampling.cpp:285)
+extern "C" int sa_gather_point_grad(int b, int n, int m, int c, const float *out_g, const int *idx, float *inp_g,
+                                    hipStream_t stream) {
+    if (b <= 0 || n <= 0 || m <= 0 || c <= 0 || !out_g || !idx || !inp_g) return SA_ERR_INVALID;
+    return launch_scatter<false>(b, n, c, m, out_g, idx, inp_g, stream);
+}
+
+// groupPointGradLauncher(b,n,c,m,nsample,grad_out,idx,grad_points) -- tf_grouping.cpp:479 (+ the memset of :509)
+extern "C" int sa_group_point_grad(int b, int n, int c, int m, int nsample, const float *grad_out, const int *idx,
+                                   float *grad_points, hipStream_t stream) {
+    if (b <= 0 || n <= 0 || m <= 0 || c <= 0 || nsample <= 0 || !grad_out || !idx || !grad_points)
+        return SA_ERR_INVALID;
+    return launch_scatter<true>(b, n, c, (long)m * nsample, grad_out, idx, grad_points, stream);
+}
+
+// GatherByMaskLauncher(b,n,c,proposal_num,inp,mask,out) -- tf_sampling.cpp:293.  `sel` [b,proposal_num] int scratch
+// (receives the selected point indices).
+extern "C" int sa_gather_by_mask(int b, int n, int c, int proposal_num, const float *inp, const float *mask,
+                                 float *out, int *sel, hipStream_t stream) {
+    if (b <= 0 || n <= 0 || c <= 0 || proposal_num <= 0 || !inp || !mask || !out || !sel) return SA_ERR_INVALID;
+    hipLaunchKernelGGL(gather_by_mask_kernel, dim3(b), dim3(kMaskBlock), 0, stream, n, c, proposal_num, inp, mask, out,
+                       sel);
+    SA_CHECK_LAUNCH();
+    return SA_OK;
+}

@@ -37,6 +37,12 @@ SIGNATURES = {
     "sa_three_nn": [_c_int] * 3 + [_vp, _vp, _vp, _vp, _vp],
     "sa_three_interpolate": [_c_int] * 4 + [_vp, _vp, _vp, _vp, _vp],
     "sa_k_interpolate": [_c_int] * 5 + [_vp, _vp, _vp, _vp, _vp],
+    "sa_query_boxes_3d_points": [_c_int] * 4 + [_vp, _vp, _vp, _vp, _vp],
+    "sa_query_boxes_3d_mask": [_c_int] * 3 + [_vp, _vp, _vp, _vp],
+    "sa_query_points_iou": [_c_int] * 4 + [_vp, _vp, _vp, _vp, _vp, _vp],
+    "sa_gather_point_grad": [_c_int] * 4 + [_vp, _vp, _vp, _vp],
+    "sa_group_point_grad": [_c_int] * 5 + [_vp, _vp, _vp, _vp],
+    "sa_gather_by_mask": [_c_int] * 4 + [_vp, _vp, _vp, _vp, _vp],
 }
 
 _ERRORS = {-1: "invalid argument", -2: "kernel launch failed (hipGetLastError)", -3: "unsupported size"}

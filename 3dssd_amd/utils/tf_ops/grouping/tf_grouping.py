@@ -1,9 +1,9 @@
 """Grouping operators with the reference's Python API (lib/utils/tf_ops/grouping/tf_grouping.py),
 on torch-ROCm tensors, backed by csrc/ballquery.hip and csrc/gather.hip through include/sa_ops.h.
 
-Same names, positional order (scalars first), return arity/dtypes/shapes.  Forward only
-(query ops are NoGradient in the reference, tf_grouping.py:66,83; GroupPoint's gradient,
-tf_grouping.py:123-128, is out of scope).  Errors: ValueError with the reference's OP_REQUIRES
+Same names, positional order (scalars first), return arity/dtypes/shapes.  Query ops are NoGradient in the
+reference (tf_grouping.py:24,37,50,66,83); GroupPoint's gradient (tf_grouping.py:123-128) is exported as the plain
+function `group_point_grad(points, idx, grad_out)` -- no autograd registration.  Errors: ValueError with the reference's OP_REQUIRES
 messages (lib/utils/tf_ops/grouping/tf_grouping.cpp:275-288,368-384,453-459).
 Rows of empty balls are zero-filled (the reference leaves them unwritten).
 """
@@ -69,4 +69,73 @@ def group_point(points, idx):
     st = N.lib().sa_group_point(b, n, c, m, ns, points.data_ptr(), idx.data_ptr(), out.data_ptr(),
                                 N.current_stream())
     N.check(st, "group_point")
+    return out
+
+
+def _check_boxes(op, xyz, boxes, what):
+    T.require(xyz.dim() == 3 and xyz.shape[2] == 3, "%s expects (batch_size, ndataset, 3) xyz shape." % op)
+    T.require(boxes.dim() == 3 and boxes.shape[2] == 7 and boxes.shape[0] == xyz.shape[0],
+              "%s expects (batch_size, %s, 7) %s shape." % (op, what[0], what[1]))
+
+
+def query_boxes_3d_mask(xyz, boxes_3d):
+    """xyz [b,n,3], boxes_3d [b,m,7] (cx, bottom y, cz, l, h, w, ry) -> mask [b,m,n] int32, 1 where the point lies
+    inside the box.   tf_grouping.py:15-24"""
+    xyz, boxes_3d = T.f32_cuda(xyz, "xyz"), T.f32_cuda(boxes_3d, "boxes_3d")
+    _check_boxes("QueryBoxes3dMask", xyz, boxes_3d, ("box_num", "boxes"))
+    b, n, _ = xyz.shape
+    m = boxes_3d.shape[1]
+    mask = torch.empty((b, m, n), dtype=torch.int32, device=xyz.device)
+    N.check(N.lib().sa_query_boxes_3d_mask(b, n, m, xyz.data_ptr(), boxes_3d.data_ptr(), mask.data_ptr(),
+                                           N.current_stream()), "query_boxes_3d_mask")
+    return mask
+
+
+def query_points_iou(xyz, anchors_3d, gt_boxes_3d, iou_matrix):
+    """PointsIoU of every (anchor, gt) pair whose box IoU is >= 1e-3: points inside both / points inside either.
+    xyz [b,n,3], anchors_3d [b,A,7], gt_boxes_3d [b,G,7], iou_matrix [b,A,G] -> [b,A,G].   tf_grouping.py:26-37"""
+    xyz, anchors_3d = T.f32_cuda(xyz, "xyz"), T.f32_cuda(anchors_3d, "anchors_3d")
+    gt_boxes_3d, iou_matrix = T.f32_cuda(gt_boxes_3d, "gt_boxes_3d"), T.f32_cuda(iou_matrix, "iou_matrix")
+    _check_boxes("QueryPointsIou", xyz, anchors_3d, ("anchors_num", "anchors"))
+    _check_boxes("QueryPointsIou", xyz, gt_boxes_3d, ("gt_num", "gt_boxes_3d"))
+    b, n, _ = xyz.shape
+    a, g = anchors_3d.shape[1], gt_boxes_3d.shape[1]
+    T.require(tuple(iou_matrix.shape) == (b, a, g),
+              "QueryPointsIou expects (batch_size, anchors_num, gt_num) iou_matrix_tensor shape.")
+    out = torch.empty((b, a, g), dtype=torch.float32, device=xyz.device)
+    N.check(N.lib().sa_query_points_iou(b, n, a, g, xyz.data_ptr(), anchors_3d.data_ptr(), gt_boxes_3d.data_ptr(),
+                                        iou_matrix.data_ptr(), out.data_ptr(), N.current_stream()), "query_points_iou")
+    return out
+
+
+def query_boxes_3d_points(nsample, xyz, proposals):
+    """The first nsample points inside each proposal, in point order; shorter rows repeat their first point, empty
+    boxes give zero rows.  -> (idx [b,m,nsample] int32, pts_cnt [b,m] int32).   tf_grouping.py:39-50"""
+    T.require(int(nsample) > 0, "QueryBoxes3dPoints expects positive nsample")
+    xyz, proposals = T.f32_cuda(xyz, "xyz"), T.f32_cuda(proposals, "proposals")
+    _check_boxes("QueryBoxes3dPoints", xyz, proposals, ("proposal_num", "proposal"))
+    b, n, _ = xyz.shape
+    m = proposals.shape[1]
+    idx = torch.empty((b, m, int(nsample)), dtype=torch.int32, device=xyz.device)
+    cnt = torch.empty((b, m), dtype=torch.int32, device=xyz.device)
+    N.check(N.lib().sa_query_boxes_3d_points(b, n, m, int(nsample), xyz.data_ptr(), proposals.data_ptr(),
+                                             idx.data_ptr(), cnt.data_ptr(), N.current_stream()),
+            "query_boxes_3d_points")
+    return idx, cnt
+
+
+def group_point_grad(points, idx, grad_out):
+    """Gradient of group_point w.r.t. points: grad_out [b,m,ns,c] scattered (summed) back to [b,n,c]; idx == -1 rows
+    contribute nothing.  Float atomics: rows that hit the same point are summed in no defined order, as in the
+    reference (tf_grouping_g.cu:384-400).   tf_grouping.py:125-128 / GroupPointGrad"""
+    points, idx, grad_out = T.f32_cuda(points, "points"), T.i32_cuda(idx, "idx"), T.f32_cuda(grad_out, "grad_out")
+    T.require(points.dim() == 3, "GroupPointGrad expects (batch_size, num_points, channel) points shape")
+    b, n, c = points.shape
+    T.require(idx.dim() == 3 and idx.shape[0] == b, "GroupPointGrad expects (batch_size, npoints, nsample) idx shape")
+    _, m, ns = idx.shape
+    T.require(tuple(grad_out.shape) == (b, m, ns, c),
+              "GroupPointGrad expects (batch_size, npoints, nsample, channel) grad_out shape")
+    out = torch.empty((b, n, c), dtype=torch.float32, device=points.device)
+    N.check(N.lib().sa_group_point_grad(b, n, c, m, ns, grad_out.data_ptr(), idx.data_ptr(), out.data_ptr(),
+                                        N.current_stream()), "group_point_grad")
     return out

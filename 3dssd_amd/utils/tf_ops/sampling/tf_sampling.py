@@ -59,3 +59,34 @@ def gather_point(inp, idx):
                                  N.current_stream())
     N.check(st, "gather_point")
     return out
+
+
+def gather_point_grad(inp, idx, out_g):
+    """Gradient of gather_point w.r.t. inp: out_g [b,m,c] scatter-added to [b,n,c] (float atomics, like
+    scatteraddpointKernel, tf_sampling_g.cu:339-351).   tf_sampling.py:38-42 / GatherPointGrad"""
+    inp, idx, out_g = T.f32_cuda(inp, "inp"), T.i32_cuda(idx, "idx"), T.f32_cuda(out_g, "out_g")
+    T.require(inp.dim() == 3, "GatherPointGradGpuOp expects (batch_size,num_points,c) inp")
+    b, n, c = inp.shape
+    T.require(idx.dim() == 2 and idx.shape[0] == b, "GatherPointGradGpuOp expects (batch_size,num_result) idx shape")
+    m = idx.shape[1]
+    T.require(tuple(out_g.shape) == (b, m, c), "GatherPointGradGpuOp expects (batch_size,num_result,c) out_g shape")
+    inp_g = torch.empty((b, n, c), dtype=torch.float32, device=inp.device)
+    N.check(N.lib().sa_gather_point_grad(b, n, m, c, out_g.data_ptr(), idx.data_ptr(), inp_g.data_ptr(),
+                                         N.current_stream()), "gather_point_grad")
+    return inp_g
+
+
+def gather_by_mask(proposal_num, inp, mask):
+    """The first proposal_num rows of inp [b,n,c] whose mask [b,n] (float) truncates to non-zero, in point order;
+    missing rows repeat the first selected one; a frame with no selected row gives zeros.  -> [b,proposal_num,c].
+    tf_sampling.py:76-85"""
+    T.require(int(proposal_num) > 0, "GatherByMask expects positive proposal number")
+    inp, mask = T.f32_cuda(inp, "inp"), T.f32_cuda(mask, "mask")
+    T.require(inp.dim() == 3, "GatherByMask expects (bs,num_points,c) inp shape")
+    b, n, c = inp.shape
+    T.require(tuple(mask.shape) == (b, n), "GatherByMask expects (bs,num_points) mask shape")
+    out = torch.empty((b, int(proposal_num), c), dtype=torch.float32, device=inp.device)
+    sel = torch.empty((b, int(proposal_num)), dtype=torch.int32, device=inp.device)
+    N.check(N.lib().sa_gather_by_mask(b, n, c, int(proposal_num), inp.data_ptr(), mask.data_ptr(), out.data_ptr(),
+                                      sel.data_ptr(), N.current_stream()), "gather_by_mask")
+    return out

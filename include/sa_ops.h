@@ -141,6 +141,32 @@ int sa_three_interpolate(int b, int m, int c, int n, const float *points, const 
 int sa_k_interpolate(int b, int m, int c, int n, int k, const float *points, const int *idx, const float *weight,
                      float *out, sa_stream_t stream);
 
+/* ---- lib/utils/tf_ops/grouping + sampling, remaining operators used by the second stage / training graph --------- */
+
+/* queryBoxes3dPointsLauncher(b,n,m,nsample,xyz,proposals,idx,pts_cnt) -- tf_grouping.cpp:228.  proposals [b,m,7] =
+ * (cx, bottom y, cz, l, h, w, ry); idx [b,m,nsample] first points inside each box (short rows repeat the first,
+ * empty boxes: zeros), pts_cnt [b,m]. */
+int sa_query_boxes_3d_points(int b, int n, int m, int nsample, const float *xyz, const float *proposals, int *idx,
+                             int *pts_cnt, sa_stream_t stream);
+/* queryBoxes3dMaskLauncher(b,n,m,xyz,boxes_3d,mask) -- tf_grouping.cpp:151.  mask [b,m,n] int. */
+int sa_query_boxes_3d_mask(int b, int n, int m, const float *xyz, const float *boxes_3d, int *mask,
+                           sa_stream_t stream);
+/* queryPointsIouLauncher(b,n,anchors_num,gt_num,xyz,anchors_3d,gt_boxes_3d,iou_matrix,iou_points) --
+ * tf_grouping.cpp:182. */
+int sa_query_points_iou(int b, int n, int anchors_num, int gt_num, const float *xyz, const float *anchors_3d,
+                        const float *gt_boxes_3d, const float *iou_matrix, float *iou_points, sa_stream_t stream);
+/* scatteraddpointLauncher(b,n,m,c,out_g,idx,inp_g) -- tf_sampling.cpp:261; inp_g [b,n,c] is zeroed first (the
+ * cudaMemset of tf_sampling.cpp:285). */
+int sa_gather_point_grad(int b, int n, int m, int c, const float *out_g, const int *idx, float *inp_g,
+                         sa_stream_t stream);
+/* groupPointGradLauncher(b,n,c,m,nsample,grad_out,idx,grad_points) -- tf_grouping.cpp:479 (+ memset of :509). */
+int sa_group_point_grad(int b, int n, int c, int m, int nsample, const float *grad_out, const int *idx,
+                        float *grad_points, sa_stream_t stream);
+/* GatherByMaskLauncher(b,n,c,proposal_num,inp,mask,out) -- tf_sampling.cpp:293, plus `sel` [b,proposal_num] int
+ * scratch that receives the selected point indices. */
+int sa_gather_by_mask(int b, int n, int c, int proposal_num, const float *inp, const float *mask, float *out,
+                      int *sel, sa_stream_t stream);
+
 /* ---- host-side helper (no device work) --------------------------------------------------------------------- */
 /* CRC-32C of `len` bytes continuing from `crc` (0 to start): the checksum of TensorFlow tensor-bundle checkpoints
  * (tensorflow/core/lib/hash/crc32c.h), used by 3dssd_amd/utils/tf_checkpoint.py when importing the reference's

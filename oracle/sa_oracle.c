@@ -329,3 +329,126 @@ void orc_k_interpolate(int b, int m, int c, int n, int k, const float *points, c
         }
     }
 }
+
+/* ==== SURVEY.md 8f rank 4: point-in-box operators, gather_by_mask, gradients of the gathers ================== */
+/* G. point_inside_box_3d (tf_grouping_g.cu:27-41).  max_distance is evaluated in double up to the sqrtf argument
+ *    ((l / 2.) promotes), cos(ry)/sin(ry) on a float argument are CUDA's float overloads: taken here as the
+ *    correctly rounded float values (computed in double and rounded).  The rotation
+ *    (x-cx)*cos - (z-cz)*sin / (x-cx)*sin + (z-cz)*cos contracts like decision B: the left product is fused. */
+typedef struct { float cx, by, cz, h, hl, hw, md, cosr, sinr; } orc_box;
+
+static orc_box load_box(const float *q) {
+    orc_box bx;
+    float l = q[3], w = q[5], ry = q[6];
+    double hl = (double)l / 2.0, hw = (double)w / 2.0;
+    bx.cx = q[0]; bx.by = q[1]; bx.cz = q[2]; bx.h = q[4];
+    bx.md = fmaxf(sqrtf((float)(hl * hl + hw * hw)), 1e-20f);      /* :59 */
+    bx.hl = l * 0.5f; bx.hw = w * 0.5f;
+    bx.cosr = (float)cos((double)ry);
+    bx.sinr = (float)sin((double)ry);
+    return bx;
+}
+
+static int inside_box(const orc_box *bx, float x, float y, float z) {
+    float dx = x - bx->cx, dz = z - bx->cz;
+    if (fabsf(dx) > bx->md || y > bx->by || (bx->by - y) > bx->h || fabsf(dz) > bx->md) return 0; /* :31-33 */
+    float u = fmaf(dx, bx->cosr, -(dz * bx->sinr));                /* :35 */
+    float v = fmaf(dx, bx->sinr, dz * bx->cosr);                   /* :36 */
+    return u >= -bx->hl && u <= bx->hl && v >= -bx->hw && v <= bx->hw; /* :38 */
+}
+
+/* tf_grouping_g.cu:44-95; empty box: zero row (decision D) */
+void orc_query_boxes_3d_points(int b, int n, int m, int nsample, const float *xyz, const float *proposals, int *idx,
+                               int *pts_cnt) {
+#pragma omp parallel for schedule(static)
+    for (long q = 0; q < (long)b * m; ++q) {
+        const float *P = xyz + (size_t)(q / m) * n * 3;
+        orc_box bx = load_box(proposals + (size_t)q * 7);
+        int *ci = idx + (size_t)q * nsample;
+        int cnt = 0;
+        for (int l = 0; l < nsample; ++l) ci[l] = 0;
+        for (int k = 0; k < n; ++k) {
+            if (cnt == nsample) break;
+            if (inside_box(&bx, P[k * 3], P[k * 3 + 1], P[k * 3 + 2])) {
+                if (cnt == 0)
+                    for (int l = 0; l < nsample; ++l) ci[l] = k;
+                ci[cnt] = k;
+                cnt += 1;
+            }
+        }
+        pts_cnt[q] = cnt;
+    }
+}
+
+/* tf_grouping_g.cu:98-134 */
+void orc_query_boxes_3d_mask(int b, int n, int m, const float *xyz, const float *boxes_3d, int *mask) {
+#pragma omp parallel for schedule(static)
+    for (long q = 0; q < (long)b * m; ++q) {
+        const float *P = xyz + (size_t)(q / m) * n * 3;
+        orc_box bx = load_box(boxes_3d + (size_t)q * 7);
+        for (int k = 0; k < n; ++k) mask[(size_t)q * n + k] = inside_box(&bx, P[k * 3], P[k * 3 + 1], P[k * 3 + 2]);
+    }
+}
+
+/* tf_grouping_g.cu:137-209 */
+void orc_query_points_iou(int b, int n, int anchors_num, int gt_num, const float *xyz, const float *anchors_3d,
+                          const float *gt_boxes_3d, const float *iou_matrix, float *iou_points) {
+#pragma omp parallel for schedule(dynamic, 16)
+    for (long q = 0; q < (long)b * anchors_num * gt_num; ++q) {
+        if (iou_matrix[q] < 1e-3f) { iou_points[q] = 0.0f; continue; }   /* :146-150 */
+        long bi = q / ((long)anchors_num * gt_num), ai = q / gt_num;
+        int gi = (int)(q % gt_num);
+        const float *P = xyz + (size_t)bi * n * 3;
+        orc_box ba = load_box(anchors_3d + (size_t)ai * 7);
+        orc_box bg = load_box(gt_boxes_3d + ((size_t)bi * gt_num + gi) * 7);
+        int in = 0, un = 0;
+        for (int k = 0; k < n; ++k) {
+            int a = inside_box(&ba, P[k * 3], P[k * 3 + 1], P[k * 3 + 2]);
+            int g = inside_box(&bg, P[k * 3], P[k * 3 + 1], P[k * 3 + 2]);
+            un += (g | a);
+            in += (g & a);
+        }
+        if (un < 1) un = 1;                                        /* :206 */
+        iou_points[q] = (float)in / (float)un;
+    }
+}
+
+/* tf_sampling_g.cu:356-384; no selected point: zero rows (the reference leaves the output unwritten) */
+void orc_gather_by_mask(int b, int n, int c, int proposal_num, const float *inp, const float *mask, float *out) {
+    for (int bi = 0; bi < b; ++bi) {
+        const float *src = inp + (size_t)bi * n * c, *mk = mask + (size_t)bi * n;
+        float *dst = out + (size_t)bi * proposal_num * c;
+        int cnt = 0;
+        memset(dst, 0, sizeof(float) * (size_t)proposal_num * c);
+        for (int k = 0; k < n; ++k) {
+            if ((int)mk[k] == 0) continue;                         /* :366 */
+            if (cnt == proposal_num) break;
+            if (cnt == 0) {
+                for (int r = 0; r < proposal_num; ++r) memcpy(dst + (size_t)r * c, src + (size_t)k * c, sizeof(float) * c);
+            } else {
+                memcpy(dst + (size_t)cnt * c, src + (size_t)k * c, sizeof(float) * c);
+            }
+            cnt += 1;
+        }
+    }
+}
+
+/* tf_sampling_g.cu:339-351 (rows in m order: ONE of the orders the reference's atomics may take) */
+void orc_gather_point_grad(int b, int n, int m, int c, const float *out_g, const int *idx, float *inp_g) {
+    memset(inp_g, 0, sizeof(float) * (size_t)b * n * c);
+    for (long r = 0; r < (long)b * m; ++r) {
+        float *d = inp_g + ((size_t)(r / m) * n + idx[r]) * c;
+        for (int l = 0; l < c; ++l) d[l] += out_g[(size_t)r * c + l];
+    }
+}
+
+/* tf_grouping_g.cu:384-400 */
+void orc_group_point_grad(int b, int n, int c, int m, int nsample, const float *grad_out, const int *idx,
+                          float *grad_points) {
+    memset(grad_points, 0, sizeof(float) * (size_t)b * n * c);
+    for (long r = 0; r < (long)b * m * nsample; ++r) {
+        if (idx[r] == -1) continue;
+        float *d = grad_points + ((size_t)(r / ((long)m * nsample)) * n + idx[r]) * c;
+        for (int l = 0; l < c; ++l) d[l] += grad_out[(size_t)r * c + l];
+    }
+}

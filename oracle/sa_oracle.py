@@ -140,6 +140,75 @@ def group_point(points, idx):
     return out
 
 
+# --------------------------------------------------------------------------- rank-4 operators
+def query_boxes_3d_points(nsample, xyz, proposals):
+    """tf_grouping.py:39-50 -> tf_grouping_g.cu:44-95."""
+    xyz, px = _f(xyz)
+    proposals, pp = _f(proposals)
+    b, n, _ = xyz.shape
+    m = proposals.shape[1]
+    idx = np.empty((b, m, nsample), np.int32)
+    cnt = np.empty((b, m), np.int32)
+    lib().orc_query_boxes_3d_points(b, n, m, int(nsample), px, pp, idx.ctypes.data_as(_i32p), cnt.ctypes.data_as(_i32p))
+    return idx, cnt
+
+
+def query_boxes_3d_mask(xyz, boxes_3d):
+    """tf_grouping.py:15-24 -> tf_grouping_g.cu:98-134."""
+    xyz, px = _f(xyz)
+    boxes_3d, pb = _f(boxes_3d)
+    b, n, _ = xyz.shape
+    m = boxes_3d.shape[1]
+    mask = np.empty((b, m, n), np.int32)
+    lib().orc_query_boxes_3d_mask(b, n, m, px, pb, mask.ctypes.data_as(_i32p))
+    return mask
+
+
+def query_points_iou(xyz, anchors_3d, gt_boxes_3d, iou_matrix):
+    """tf_grouping.py:26-37 -> tf_grouping_g.cu:137-209."""
+    xyz, px = _f(xyz)
+    anchors_3d, pa = _f(anchors_3d)
+    gt_boxes_3d, pg = _f(gt_boxes_3d)
+    iou_matrix, pi = _f(iou_matrix)
+    b, n, _ = xyz.shape
+    a, g = anchors_3d.shape[1], gt_boxes_3d.shape[1]
+    out = np.empty((b, a, g), np.float32)
+    lib().orc_query_points_iou(b, n, a, g, px, pa, pg, pi, out.ctypes.data_as(_f32p))
+    return out
+
+
+def gather_by_mask(proposal_num, inp, mask):
+    """tf_sampling.py:76-85 -> tf_sampling_g.cu:356-384."""
+    inp, pi = _f(inp)
+    mask, pm = _f(mask)
+    b, n, c = inp.shape
+    out = np.empty((b, proposal_num, c), np.float32)
+    lib().orc_gather_by_mask(b, n, c, int(proposal_num), pi, pm, out.ctypes.data_as(_f32p))
+    return out
+
+
+def gather_point_grad(inp, idx, out_g):
+    """tf_sampling.py:38-42 -> tf_sampling_g.cu:339-351."""
+    idx, px = _i(idx)
+    out_g, pg = _f(out_g)
+    b, n, c = np.shape(inp)
+    m = idx.shape[1]
+    inp_g = np.empty((b, n, c), np.float32)
+    lib().orc_gather_point_grad(b, n, m, c, pg, px, inp_g.ctypes.data_as(_f32p))
+    return inp_g
+
+
+def group_point_grad(points, idx, grad_out):
+    """tf_grouping.py:125-128 -> tf_grouping_g.cu:384-400."""
+    idx, px = _i(idx)
+    grad_out, pg = _f(grad_out)
+    b, n, c = np.shape(points)
+    _, m, ns = idx.shape
+    out = np.empty((b, n, c), np.float32)
+    lib().orc_group_point_grad(b, n, c, m, ns, pg, px, out.ctypes.data_as(_f32p))
+    return out
+
+
 # --------------------------------------------------------------------------- MLP pieces
 BN_EPS = 1e-3  # tf.contrib.layers.batch_norm default, tf_util.py:424-444
 
