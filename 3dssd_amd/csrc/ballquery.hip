@@ -185,6 +185,43 @@ __global__ void ball_query_serial_kernel(int b, int n, int m, float tlo, float t
     }
 }
 
+// query_ball_point_withidx (tf_grouping_g.cu:259-304): the scan visits the points in the order sort_idx[q, :]
+// gives (an argsort from the caller) instead of index order.  One wave per query, 64 candidates per step.
+__global__ __launch_bounds__(256) void ball_query_withidx_kernel(int n, int m, long total, float thi, int nsample,
+                                                                 const float *__restrict__ xyz1,
+                                                                 const float *__restrict__ xyz2,
+                                                                 const int *__restrict__ sort_idx,
+                                                                 int *__restrict__ idx, int *__restrict__ pts_cnt) {
+    const int lane = threadIdx.x & 63;
+    const long q = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= total) return;
+    const float *P = xyz1 + (size_t)(q / m) * n * 3;
+    const int *order = sort_idx + (size_t)q * n;
+    const float cx = xyz2[q * 3 + 0], cy = xyz2[q * 3 + 1], cz = xyz2[q * 3 + 2];
+    int *o = idx + (size_t)q * nsample;
+    int cnt = 0, first = 0;
+    for (int i0 = 0; i0 < n && cnt < nsample; i0 += 64) {
+        const int i = i0 + lane;
+        bool in = false;
+        int k = 0;
+        if (i < n) {
+            k = order[i];
+            const float dx = cx - P[k * 3 + 0], dy = cy - P[k * 3 + 1], dz = cz - P[k * 3 + 2];
+            in = __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy)) < thi;      // decision B; d < radius
+        }
+        const unsigned long long hit = __ballot(in);
+        if (hit) {
+            if (cnt == 0) first = __builtin_amdgcn_readlane(k, __builtin_ctzll(hit));
+            const int pos = cnt + __builtin_popcountll(hit & ((1ull << lane) - 1ull));
+            if (in && pos < nsample) o[pos] = k;
+            cnt += __builtin_popcountll(hit);
+        }
+    }
+    cnt = cnt < nsample ? cnt : nsample;
+    for (int s = cnt + lane; s < nsample; s += 64) o[s] = first;    // empty ball: zeros (decision D)
+    if (lane == 0) pts_cnt[q] = cnt;
+}
+
 // T(r) = min{x >= 0 : sqrtf(x) >= r}; +inf if no float qualifies.
 float sqrt_ge_threshold(float r) {
     if (!(r > 0.0f)) return 0.0f;
@@ -256,4 +293,21 @@ extern "C" int sa_query_ball_point_dilated(int b, int n, int m, float min_radius
                                            int *pts_cnt, hipStream_t stream) {
     return sa_query_ball_point_multi(b, n, m, 1, &min_radius, &max_radius, &nsample, 1, xyz1, xyz2, &idx,
                                      &pts_cnt, stream);
+}
+
+// queryBallPointWithidxLauncher(b,n,m,radius,nsample,xyz1,xyz2,sort_idx,idx,pts_cnt) -- tf_grouping.cpp:314.
+// sort_idx [b,m,n]: visiting order of the n points for every query.
+extern "C" int sa_query_ball_point_withidx(int b, int n, int m, float radius, int nsample, const float *xyz1,
+                                           const float *xyz2, const int *sort_idx, int *idx, int *pts_cnt,
+                                           hipStream_t stream) {
+    if (b <= 0 || n <= 0 || m <= 0 || nsample <= 0 || !(radius > 0.0f) || !xyz1 || !xyz2 || !sort_idx || !idx || !pts_cnt)
+        return SA_ERR_INVALID;
+    const long total = (long)b * m;
+    if ((total + 3) / 4 > 0x7FFFFFFF || (long)n * 3 > 0x7FFFFFFF) return SA_ERR_UNSUPPORTED;
+    // hit iff max(sqrtf(d2), 1e-20f) < radius  <=>  d2 < T(radius) for radius > 1e-20 (never otherwise)
+    const float thi = radius <= 1e-20f ? 0.0f : sqrt_ge_threshold(radius);
+    hipLaunchKernelGGL(ball_query_withidx_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, stream, n, m, total,
+                       thi, nsample, xyz1, xyz2, sort_idx, idx, pts_cnt);
+    SA_CHECK_LAUNCH();
+    return SA_OK;
 }

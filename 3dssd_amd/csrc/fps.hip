@@ -211,6 +211,91 @@ __global__ __launch_bounds__(kBlock) void fps_generic_kernel(int n, int c, int m
     }
 }
 
+// ---- farthest_point_sample_with_preidx (tf_sampling_g.cu:232-318): FPS continued from an already chosen set ------
+// The running minimum starts as the distance to the nearest of the m1 points preidx[b, :] (not at 1e38), the first
+// output is the arg-max of that field -- found by a SERIAL ascending scan in the reference (:262-269), i.e. the lowest
+// index among equal maxima, unlike the (k mod 1024, k) order of the iterations that follow -- and the remaining m-1
+// picks are ordinary FPS iterations on the same field.  Same fmaf chains as the other kernels (decision A).
+__global__ __launch_bounds__(kBlock) void fps_preidx_kernel(int n, int c, int m, int m1,
+                                                            const float *__restrict__ inp,
+                                                            const int *__restrict__ preidx,
+                                                            float *__restrict__ temp, int *__restrict__ out) {
+    __shared__ float s_val[2][kWaves];
+    __shared__ float4 s_pt[2][kWaves];
+    __shared__ unsigned s_first[kWaves];
+    const int b = blockIdx.x;
+    const float *p = inp + (size_t)b * n * c;
+    const int *pre = preidx + (size_t)b * m1;
+    float *td = temp + (size_t)b * n;
+    int *o = out + (size_t)b * m;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+
+    float fbest = -1.0f;                               // :261
+    unsigned fj = 0xFFFFFFFFu;
+    for (int j = t; j < n; j += kBlock) {
+        float best = kInit;                            // :247
+        for (int k = 0; k < m1; ++k) {
+            const float *pp = p + (size_t)pre[k] * c;
+            float d = 0.0f;
+            for (int l = 0; l < c; ++l) {
+                const float diff = p[(size_t)j * c + l] - pp[l];
+                d = __builtin_fmaf(diff, diff, d);
+            }
+            best = sa::fmin_nn(best, d);
+        }
+        td[j] = best;
+        if (best > fbest) { fbest = best; fj = (unsigned)j; }      // ascending j per thread: first maximum
+    }
+    {
+        const float wmax = sa::wave_allmax(fbest);
+        const unsigned wj = sa::wave_allmin_u32(fbest == wmax ? fj : 0xFFFFFFFFu);
+        if (lane == 0) { s_val[0][w] = wmax; s_first[w] = wj; }
+    }
+    __syncthreads();
+    int old = 0;                                       // :260 (kept when no entry exceeds -1, e.g. NaN-free empty case)
+    {
+        float mv = -1.0f;
+        unsigned mj = 0xFFFFFFFFu;
+        for (int i = 0; i < kWaves; ++i) {
+            const float v = s_val[0][i];
+            const unsigned j = s_first[i];
+            if (j != 0xFFFFFFFFu && (v > mv || (v == mv && j < mj))) { mv = v; mj = j; }
+        }
+        if (mj != 0xFFFFFFFFu) old = (int)mj;
+    }
+    if (t == 0) o[0] = old;
+    __syncthreads();                                   // s_val[0] is reused by iteration 2
+
+    for (int it = 1; it < m; ++it) {
+        float best = -1.0f;
+        int bk = 0;
+        const float *po = p + (size_t)old * c;
+        for (int k = t; k < n; k += kBlock) {
+            const float *pk = p + (size_t)k * c;
+            float d = 0.0f;
+            for (int l = 0; l < c; ++l) {
+                const float diff = pk[l] - po[l];
+                d = __builtin_fmaf(diff, diff, d);
+            }
+            const float t2 = sa::fmin_nn(d, td[k]);
+            td[k] = t2;
+            if (t2 > best) { best = t2; bk = k; }
+        }
+        const float wmax = sa::wave_allmax(best);
+        const unsigned long long cand = __ballot(best == wmax);
+        const int first = __builtin_ctzll(cand);
+        const int par = it & 1;
+        if (lane == first) {
+            s_val[par][w] = wmax;
+            s_pt[par][w] = make_float4(0.f, 0.f, 0.f, __int_as_float(bk));
+        }
+        __syncthreads();
+        const float4 wp = cross_wave_pick<true>(s_val, s_pt, par, lane);
+        old = __builtin_amdgcn_readfirstlane(__float_as_int(wp.w));
+        if (t == 0) o[it] = old;
+    }
+}
+
 // ---- c-channel points, any n: the frame is walked in TILE-point tiles staged through LDS ------------------
 // The generic kernel above reads channel l of point k as p[k*c + l] from every lane: a 4-byte access with a
 // stride of c floats, i.e. one cache line per lane and instruction (0.8 ms per iteration at n = 16384, c = 67).
@@ -378,4 +463,14 @@ extern "C" int sa_farthest_point_sample(int b, int n, int c, int m, const float 
 extern "C" int sa_farthest_point_sample_with_distance(int b, int n, int m, const float *dist,
                                                       float *temp, int *out, hipStream_t stream) {
     return sa_fps_with_distance_ex(b, n, m, dist, temp, out, m, 0, stream);
+}
+
+// farthestpointsamplingwithpreidxLauncher(b,n,c,m,m1,inp,preidx,temp,out) -- tf_sampling.cpp:195
+extern "C" int sa_farthest_point_sample_with_preidx(int b, int n, int c, int m, int m1, const float *inp,
+                                                    const int *preidx, float *temp, int *out, hipStream_t stream) {
+    if (b <= 0 || n <= 0 || c <= 0 || m <= 0 || m1 < 0 || !inp || (m1 > 0 && !preidx) || !temp || !out)
+        return SA_ERR_INVALID;
+    hipLaunchKernelGGL(fps_preidx_kernel, dim3(b), dim3(kBlock), 0, stream, n, c, m, m1, inp, preidx, temp, out);
+    SA_CHECK_LAUNCH();
+    return SA_OK;
 }

@@ -77,6 +77,20 @@ __global__ void k_interpolate_kernel(long total, int m, int c, int n, int k, con
     }
 }
 
+// grad_points[b, idx[b,j,i], l] += grad_out[b,j,l] * weight[b,j,i]  (tf_interpolate_g.cu:115-140,167-189): float atomics,
+// the order in which contributions to one known point are summed is undefined there as well
+__global__ void interpolate_grad_kernel(long total, int m, int c, int n, int k, const float *__restrict__ grad_out,
+                                        const int *__restrict__ idx, const float *__restrict__ weight,
+                                        float *grad_points) {
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long j = e / c;
+        const int l = (int)(e - j * c);
+        float *G = grad_points + (j / n) * (long)m * c;
+        const float g = grad_out[e];
+        for (int i = 0; i < k; ++i) atomicAdd(G + (long)idx[j * k + i] * c + l, g * weight[j * k + i]);
+    }
+}
+
 }  // namespace
 
 // Reference launcher signatures (lib/utils/tf_ops/interpolation/tf_interpolate.cpp:215,285,407) + stream.
@@ -106,4 +120,23 @@ extern "C" int sa_k_interpolate(int b, int m, int c, int n, int k, const float *
     hipLaunchKernelGGL(k_interpolate_kernel, dim3(grid), dim3(256), 0, stream, total, m, c, n, k, points, idx, weight, out);
     SA_CHECK_LAUNCH();
     return SA_OK;
+}
+
+// ThreeInterpolateGradLauncher(b,n,c,m,grad_out,idx,weight,grad_points) -- tf_interpolate.cpp:363; grad_points [b,m,c]
+// is zeroed here (the op's memset, tf_interpolate.cpp:356,398,481).
+extern "C" int sa_k_interpolate_grad(int b, int n, int c, int m, int k, const float *grad_out, const int *idx,
+                                     const float *weight, float *grad_points, hipStream_t stream) {
+    if (b <= 0 || m <= 0 || c <= 0 || n <= 0 || k <= 0 || !grad_out || !idx || !weight || !grad_points) return SA_ERR_INVALID;
+    if (hipMemsetAsync(grad_points, 0, (size_t)b * m * c * sizeof(float), stream) != hipSuccess) return SA_ERR_LAUNCH;
+    const long total = (long)b * n * c;
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(interpolate_grad_kernel, dim3(grid), dim3(256), 0, stream, total, m, c, n, k, grad_out, idx, weight,
+                       grad_points);
+    SA_CHECK_LAUNCH();
+    return SA_OK;
+}
+// KInterpolateGradLauncher(b,n,c,m,k,...) -- tf_interpolate.cpp:445 is the general form; three = k == 3.
+extern "C" int sa_three_interpolate_grad(int b, int n, int c, int m, const float *grad_out, const int *idx,
+                                         const float *weight, float *grad_points, hipStream_t stream) {
+    return sa_k_interpolate_grad(b, n, c, m, 3, grad_out, idx, weight, grad_points, stream);
 }

@@ -43,6 +43,12 @@ SIGNATURES = {
     "sa_gather_point_grad": [_c_int] * 4 + [_vp, _vp, _vp, _vp],
     "sa_group_point_grad": [_c_int] * 5 + [_vp, _vp, _vp, _vp],
     "sa_gather_by_mask": [_c_int] * 4 + [_vp, _vp, _vp, _vp, _vp],
+    "sa_query_ball_point_withidx": [_c_int] * 3 + [_c_float, _c_int, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sa_selection_sort": [_c_int] * 4 + [_vp, _vp, _vp, _vp],
+    "sa_pairwise_sqdist": [_c_int] * 4 + [_vp, _vp, _vp, _vp],
+    "sa_farthest_point_sample_with_preidx": [_c_int] * 5 + [_vp, _vp, _vp, _vp, _vp],
+    "sa_three_interpolate_grad": [_c_int] * 4 + [_vp, _vp, _vp, _vp, _vp],
+    "sa_k_interpolate_grad": [_c_int] * 5 + [_vp, _vp, _vp, _vp, _vp],
 }
 
 _ERRORS = {-1: "invalid argument", -2: "kernel launch failed (hipGetLastError)", -3: "unsupported size"}

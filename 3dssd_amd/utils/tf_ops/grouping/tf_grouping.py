@@ -139,3 +139,52 @@ def group_point_grad(points, idx, grad_out):
     N.check(N.lib().sa_group_point_grad(b, n, c, m, ns, grad_out.data_ptr(), idx.data_ptr(), out.data_ptr(),
                                         N.current_stream()), "group_point_grad")
     return out
+
+
+def query_ball_point_withidx(radius, nsample, xyz1, xyz2, sort_idx):
+    """Ball query that visits the dataset points of every query in the order sort_idx [b,m,n] gives (an argsort of
+    the caller) instead of index order.  -> (idx [b,m,nsample], pts_cnt [b,m]).   tf_grouping.py:85-100"""
+    T.require(float(radius) > 0, "QueryBallPointWithidx expects positive radius")
+    T.require(int(nsample) > 0, "QueryBallPointWithidx expects positive nsample")
+    xyz1, xyz2 = T.f32_cuda(xyz1, "xyz1"), T.f32_cuda(xyz2, "xyz2")
+    sort_idx = T.i32_cuda(sort_idx, "sort_idx")
+    _check_xyz("QueryBallPointWithidx", xyz1, xyz2)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    T.require(tuple(sort_idx.shape) == (b, m, n), "QueryBallPointWithidx expects (batch_size, npoint, ndataset) sort_idx shape.")
+    idx = torch.empty((b, m, int(nsample)), dtype=torch.int32, device=xyz1.device)
+    cnt = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
+    N.check(N.lib().sa_query_ball_point_withidx(b, n, m, float(radius), int(nsample), xyz1.data_ptr(), xyz2.data_ptr(),
+                                                sort_idx.data_ptr(), idx.data_ptr(), cnt.data_ptr(), N.current_stream()),
+            "query_ball_point_withidx")
+    return idx, cnt
+
+
+def select_top_k(k, dist):
+    """dist [b,m,n] -> (idx [b,m,n] int32, dist_out [b,m,n]): k steps of selection sort per row, so the first k
+    entries are the k smallest in ascending order (ties: lowest position first) and the rest is the permuted
+    remainder, exactly as the reference leaves it.   tf_grouping.py:103-113"""
+    T.require(int(k) > 0, "SelectionSort expects positive k")
+    dist = T.f32_cuda(dist, "dist")
+    T.require(dist.dim() == 3, "SelectionSort expects (b,m,n) dist shape")
+    b, m, n = dist.shape
+    outi = torch.empty((b, m, n), dtype=torch.int32, device=dist.device)
+    out = torch.empty((b, m, n), dtype=torch.float32, device=dist.device)
+    N.check(N.lib().sa_selection_sort(b, n, m, int(k), dist.data_ptr(), outi.data_ptr(), out.data_ptr(),
+                                      N.current_stream()), "select_top_k")
+    return outi, out
+
+
+def knn_point(k, xyz1, xyz2):
+    """k nearest dataset points xyz1 [b,n,c] of every query xyz2 [b,m,c] -> (val [b,m,k] squared distances ascending,
+    idx [b,m,k]).   tf_grouping.py:130-160 (distance matrix + select_top_k + slices)"""
+    xyz1, xyz2 = T.f32_cuda(xyz1, "xyz1"), T.f32_cuda(xyz2, "xyz2")
+    T.require(xyz1.dim() == 3 and xyz2.dim() == 3 and xyz1.shape[0] == xyz2.shape[0] and xyz1.shape[2] == xyz2.shape[2],
+              "knn_point expects (b,n,c) xyz1 and (b,m,c) xyz2")
+    b, n, c = xyz1.shape
+    m = xyz2.shape[1]
+    dist = torch.empty((b, m, n), dtype=torch.float32, device=xyz1.device)
+    N.check(N.lib().sa_pairwise_sqdist(b, n, m, c, xyz1.data_ptr(), xyz2.data_ptr(), dist.data_ptr(), N.current_stream()),
+            "knn_point")
+    outi, out = select_top_k(k, dist)
+    return out[:, :, :int(k)].contiguous(), outi[:, :, :int(k)].contiguous()

@@ -65,3 +65,26 @@ def k_interpolate(points, idx, weight):
                                   N.current_stream())
     N.check(st, "k_interpolate")
     return out
+
+
+def _interpolate_grad(op, points, idx, weight, grad_out, k):
+    points, idx = T.f32_cuda(points, "points"), T.i32_cuda(idx, "idx")
+    weight, grad_out = T.f32_cuda(weight, "weight"), T.f32_cuda(grad_out, "grad_out")
+    _check_interp(op, points, idx, weight, k)
+    b, m, c = points.shape
+    n = idx.shape[1]
+    T.require(tuple(grad_out.shape) == (b, n, c), "%s expects (b,n,c) grad_out shape" % op)
+    gp = torch.empty((b, m, c), dtype=torch.float32, device=points.device)
+    N.check(N.lib().sa_k_interpolate_grad(b, n, c, m, idx.shape[2], grad_out.data_ptr(), idx.data_ptr(),
+                                          weight.data_ptr(), gp.data_ptr(), N.current_stream()), op)
+    return gp
+
+
+def three_interpolate_grad(points, idx, weight, grad_out):
+    """Gradient of three_interpolate w.r.t. points: [b,m,c] (float atomics; tf_interpolate.py:32-36)."""
+    return _interpolate_grad("ThreeInterpolateGrad", points, idx, weight, grad_out, 3)
+
+
+def k_interpolate_grad(points, idx, weight, grad_out):
+    """Gradient of k_interpolate w.r.t. points: [b,m,c].   tf_interpolate.py:53-58"""
+    return _interpolate_grad("KInterpolateGrad", points, idx, weight, grad_out, None)

@@ -90,3 +90,20 @@ def gather_by_mask(proposal_num, inp, mask):
     N.check(N.lib().sa_gather_by_mask(b, n, c, int(proposal_num), inp.data_ptr(), mask.data_ptr(), out.data_ptr(),
                                       sel.data_ptr(), N.current_stream()), "gather_by_mask")
     return out
+
+
+def farthest_point_sample_with_preidx(npoint, inp, preidx):
+    """FPS continued from an already chosen set: the running minimum starts as the distance to the nearest of
+    preidx [b,m1]; the first output is the point farthest from that set (lowest index on ties), then npoint-1
+    ordinary iterations.  inp [b,n,c] -> int32 [b,npoint].   tf_sampling.py:65-74"""
+    T.require(int(npoint) > 0, "FarthestPointSampleWithPreidx expects positive npoint")
+    inp, preidx = T.f32_cuda(inp, "inp"), T.i32_cuda(preidx, "preidx")
+    T.require(inp.dim() == 3, "FarthestPointSampleWithPreidx expects (batch_size,num_points,c) inp shape")
+    b, n, c = inp.shape
+    T.require(preidx.dim() == 2 and preidx.shape[0] == b, "FarthestPointSampleWithPreidx expects (batch_size,m1) preidx shape")
+    out = torch.empty((b, int(npoint)), dtype=torch.int32, device=inp.device)
+    temp = torch.empty((b, n), dtype=torch.float32, device=inp.device)
+    N.check(N.lib().sa_farthest_point_sample_with_preidx(b, n, c, int(npoint), preidx.shape[1], inp.data_ptr(),
+                                                         preidx.data_ptr(), temp.data_ptr(), out.data_ptr(),
+                                                         N.current_stream()), "farthest_point_sample_with_preidx")
+    return out

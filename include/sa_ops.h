@@ -167,6 +167,26 @@ int sa_group_point_grad(int b, int n, int c, int m, int nsample, const float *gr
 int sa_gather_by_mask(int b, int n, int c, int proposal_num, const float *inp, const float *mask, float *out,
                       int *sel, sa_stream_t stream);
 
+/* queryBallPointWithidxLauncher(b,n,m,radius,nsample,xyz1,xyz2,sort_idx,idx,pts_cnt) -- tf_grouping.cpp:314.
+ * sort_idx [b,m,n]: the order in which the dataset points are visited for every query. */
+int sa_query_ball_point_withidx(int b, int n, int m, float radius, int nsample, const float *xyz1, const float *xyz2,
+                                const int *sort_idx, int *idx, int *pts_cnt, sa_stream_t stream);
+/* selectionSortLauncher(b,n,m,k,dist,outi,out) -- tf_grouping.cpp:411.  dist/outi/out [b,m,n]; n <= 16384. */
+int sa_selection_sort(int b, int n, int m, int k, const float *dist, int *outi, float *out, sa_stream_t stream);
+/* The distance matrix knn_point builds with TensorFlow ops (tf_grouping.py:146-150): xyz1 [b,n,c], xyz2 [b,m,c] ->
+ * dist [b,m,n] = sum_l (xyz1 - xyz2)^2.  No launcher in the reference (graph ops). */
+int sa_pairwise_sqdist(int b, int n, int m, int c, const float *xyz1, const float *xyz2, float *dist,
+                       sa_stream_t stream);
+/* farthestpointsamplingwithpreidxLauncher(b,n,c,m,m1,inp,preidx,temp,out) -- tf_sampling.cpp:195. */
+int sa_farthest_point_sample_with_preidx(int b, int n, int c, int m, int m1, const float *inp, const int *preidx,
+                                         float *temp, int *out, sa_stream_t stream);
+/* ThreeInterpolateGradLauncher(b,n,c,m,grad_out,idx,weight,grad_points) -- tf_interpolate.cpp:363 and
+ * KInterpolateGradLauncher(b,n,c,m,k,...) -- tf_interpolate.cpp:445; grad_points [b,m,c] is zeroed first. */
+int sa_three_interpolate_grad(int b, int n, int c, int m, const float *grad_out, const int *idx, const float *weight,
+                              float *grad_points, sa_stream_t stream);
+int sa_k_interpolate_grad(int b, int n, int c, int m, int k, const float *grad_out, const int *idx,
+                          const float *weight, float *grad_points, sa_stream_t stream);
+
 /* ---- host-side helper (no device work) --------------------------------------------------------------------- */
 /* CRC-32C of `len` bytes continuing from `crc` (0 to start): the checksum of TensorFlow tensor-bundle checkpoints
  * (tensorflow/core/lib/hash/crc32c.h), used by 3dssd_amd/utils/tf_checkpoint.py when importing the reference's

@@ -54,6 +54,19 @@ def ref_three_interpolate(points, idx, weight):
     return out
 
 
+def ref_three_interpolate_grad(points_shape, idx, weight, grad_out):
+    """threeinterpolate_grad_cpu (tf_interpolate.cpp:158-180); the op zeroes grad_points first (:356)."""
+    lib = ref_lib()
+    idx = np.ascontiguousarray(idx, np.int32); weight = np.ascontiguousarray(weight, f32)
+    grad_out = np.ascontiguousarray(grad_out, f32)
+    b, m, c = points_shape
+    n = idx.shape[1]
+    gp = np.zeros((b, m, c), f32)
+    lib.threeinterpolate_grad_cpu(b, n, c, m, grad_out.ctypes.data_as(_f32p), idx.ctypes.data_as(_i32p),
+                                  weight.ctypes.data_as(_f32p), gp.ctypes.data_as(_f32p))
+    return gp
+
+
 def three_nn(xyz1, xyz2):
     """tf_interpolate.py:8-18 -> tf_interpolate.cpp:86-132.  xyz1 [b,n,3] unknown, xyz2 [b,m,3] known ->
     (dist [b,n,3] squared distances ascending, idx [b,n,3]); equal distances keep index order (strict '<'

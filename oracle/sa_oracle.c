@@ -452,3 +452,134 @@ void orc_group_point_grad(int b, int n, int c, int m, int nsample, const float *
         for (int l = 0; l < c; ++l) d[l] += grad_out[(size_t)r * c + l];
     }
 }
+
+/* tf_grouping_g.cu:259-304: ball query visiting the points in the caller's order sort_idx[q, :] */
+void orc_query_ball_point_withidx(int b, int n, int m, float radius, int nsample, const float *xyz1, const float *xyz2,
+                                  const int *sort_idx, int *idx, int *pts_cnt) {
+#pragma omp parallel for schedule(static)
+    for (long q = 0; q < (long)b * m; ++q) {
+        const float *P = xyz1 + (size_t)(q / m) * n * 3, *c2 = xyz2 + (size_t)q * 3;
+        const int *order = sort_idx + (size_t)q * n;
+        int *ci = idx + (size_t)q * nsample;
+        int cnt = 0;
+        for (int l = 0; l < nsample; ++l) ci[l] = 0;
+        for (int i = 0; i < n; ++i) {
+            if (cnt == nsample) break;
+            int k = order[i];                                      /* :284 */
+            float d = fmaxf(sqrtf(ball_d2(P[k * 3], P[k * 3 + 1], P[k * 3 + 2], c2[0], c2[1], c2[2])), 1e-20f);
+            if (d < radius) {
+                if (cnt == 0)
+                    for (int l = 0; l < nsample; ++l) ci[l] = k;
+                ci[cnt] = k;
+                cnt += 1;
+            }
+        }
+        pts_cnt[q] = cnt;
+    }
+}
+
+/* tf_grouping_g.cu:404-443, one row at a time */
+void orc_selection_sort(int b, int n, int m, int k, const float *dist, int *outi, float *out) {
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < (long)b * m; ++r) {
+        float *p = out + (size_t)r * n;
+        int *pi = outi + (size_t)r * n;
+        for (int s = 0; s < n; ++s) { p[s] = dist[(size_t)r * n + s]; pi[s] = s; }
+        for (int s = 0; s < k && s < n; ++s) {
+            int mn = s;
+            for (int t = s + 1; t < n; ++t)
+                if (p[t] < p[mn]) mn = t;
+            if (mn != s) {
+                float tv = p[mn]; p[mn] = p[s]; p[s] = tv;
+                int ti = pi[mn]; pi[mn] = pi[s]; pi[s] = ti;
+            }
+        }
+    }
+}
+
+/* knn_point's distance matrix, tf_grouping.py:146-150: tf.reduce_sum((xyz1 - xyz2)**2, -1) -- squares rounded by the
+ * square op, then summed over the channels (taken ascending); dist [b,m,n] */
+void orc_pairwise_sqdist(int b, int n, int m, int c, const float *xyz1, const float *xyz2, float *dist) {
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < (long)b * m; ++r) {
+        const float *q = xyz2 + (size_t)r * c;
+        const float *A = xyz1 + (size_t)(r / m) * n * c;
+        for (int i = 0; i < n; ++i) {
+            float d = 0.0f;
+            for (int l = 0; l < c; ++l) {
+                float df = A[(size_t)i * c + l] - q[l];
+                float sq = df * df;
+                d = l == 0 ? sq : d + sq;
+            }
+            dist[(size_t)r * n + i] = d;
+        }
+    }
+}
+
+/* tf_sampling_g.cu:232-318 */
+void orc_farthest_point_sample_with_preidx(int b, int n, int c, int m, int m1, const float *inp, const int *preidx,
+                                           float *temp, int *out) {
+#pragma omp parallel for schedule(static)
+    for (int bi = 0; bi < b; ++bi) {
+        const float *p = inp + (size_t)bi * n * c;
+        float *td = temp + (size_t)bi * n;
+        int *o = out + (size_t)bi * m;
+        for (int j = 0; j < n; ++j) {
+            float best = 1e38f;                                    /* :247 */
+            for (int k = 0; k < m1; ++k) {
+                const float *pp = p + (size_t)preidx[(size_t)bi * m1 + k] * c;
+                float d = 0.0f;
+                for (int l = 0; l < c; ++l) {
+                    float diff = p[(size_t)j * c + l] - pp[l];
+                    d = fmaf(diff, diff, d);                       /* decision A */
+                }
+                best = fminf(best, d);
+            }
+            td[j] = best;
+        }
+        int old = 0;
+        float pre_best = -1.0f;
+        for (int j = 0; j < n; ++j)
+            if (pre_best < td[j]) { pre_best = td[j]; old = j; }   /* :262-269: serial scan, first maximum */
+        o[0] = old;
+        for (int it = 1; it < m; ++it) {
+            /* one ordinary FPS iteration with the (k mod 1024, k) tie order: per-thread first strict maximum, then
+             * the lowest thread among equal values (the tree of :295-306) */
+            float tbest[FPS_BLOCK];
+            int tidx[FPS_BLOCK];
+            for (int t = 0; t < FPS_BLOCK; ++t) { tbest[t] = -1.0f; tidx[t] = 0; }
+            const float *po = p + (size_t)old * c;
+            for (int k = 0; k < n; ++k) {
+                float d = 0.0f;
+                for (int l = 0; l < c; ++l) {
+                    float diff = p[(size_t)k * c + l] - po[l];
+                    d = fmaf(diff, diff, d);
+                }
+                float d2 = fminf(d, td[k]);
+                td[k] = d2;
+                int t = k % FPS_BLOCK;
+                if (d2 > tbest[t]) { tbest[t] = d2; tidx[t] = k; }
+            }
+            int bt = 0;
+            for (int t = 1; t < FPS_BLOCK; ++t)
+                if (tbest[t] > tbest[bt]) bt = t;
+            old = tidx[bt];
+            o[it] = old;
+        }
+    }
+}
+
+/* tf_interpolate_g.cu:115-140,167-189 / threeinterpolate_grad_cpu (tf_interpolate.cpp:158-180): contributions summed
+ * in (j, i) order, each product rounded before the add */
+void orc_k_interpolate_grad(int b, int n, int c, int m, int k, const float *grad_out, const int *idx, const float *weight,
+                            float *grad_points) {
+    memset(grad_points, 0, sizeof(float) * (size_t)b * m * c);
+    for (int bi = 0; bi < b; ++bi)
+        for (int j = 0; j < n; ++j)
+            for (int l = 0; l < c; ++l)
+                for (int i = 0; i < k; ++i) {
+                    size_t r = (size_t)bi * n + j;
+                    float pr = grad_out[r * c + l] * weight[r * k + i];
+                    grad_points[((size_t)bi * m + idx[r * k + i]) * c + l] += pr;
+                }
+}

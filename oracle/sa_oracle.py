@@ -209,6 +209,66 @@ def group_point_grad(points, idx, grad_out):
     return out
 
 
+def query_ball_point_withidx(radius, nsample, xyz1, xyz2, sort_idx):
+    """tf_grouping.py:85-100 -> tf_grouping_g.cu:259-304."""
+    xyz1, p1 = _f(xyz1)
+    xyz2, p2 = _f(xyz2)
+    sort_idx, ps = _i(sort_idx)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    idx = np.empty((b, m, nsample), np.int32)
+    cnt = np.empty((b, m), np.int32)
+    lib().orc_query_ball_point_withidx(b, n, m, ctypes.c_float(np.float32(radius)), int(nsample), p1, p2, ps,
+                                       idx.ctypes.data_as(_i32p), cnt.ctypes.data_as(_i32p))
+    return idx, cnt
+
+
+def select_top_k(k, dist):
+    """tf_grouping.py:103-113 -> tf_grouping_g.cu:404-443.  -> (idx [b,m,n], dist_out [b,m,n])."""
+    dist, pd = _f(dist)
+    b, m, n = dist.shape
+    outi = np.empty((b, m, n), np.int32)
+    out = np.empty((b, m, n), np.float32)
+    lib().orc_selection_sort(b, n, m, int(k), pd, outi.ctypes.data_as(_i32p), out.ctypes.data_as(_f32p))
+    return outi, out
+
+
+def knn_point(k, xyz1, xyz2):
+    """tf_grouping.py:130-160."""
+    xyz1, p1 = _f(xyz1)
+    xyz2, p2 = _f(xyz2)
+    b, n, c = xyz1.shape
+    m = xyz2.shape[1]
+    dist = np.empty((b, m, n), np.float32)
+    lib().orc_pairwise_sqdist(b, n, m, c, p1, p2, dist.ctypes.data_as(_f32p))
+    outi, out = select_top_k(k, dist)
+    return out[:, :, :k].copy(), outi[:, :, :k].copy()
+
+
+def farthest_point_sample_with_preidx(npoint, inp, preidx):
+    """tf_sampling.py:65-74 -> tf_sampling_g.cu:232-318."""
+    inp, pi = _f(inp)
+    preidx, pp = _i(preidx)
+    b, n, c = inp.shape
+    out = np.empty((b, npoint), np.int32)
+    temp = np.empty((b, n), np.float32)
+    lib().orc_farthest_point_sample_with_preidx(b, n, c, int(npoint), preidx.shape[1], pi, pp,
+                                                temp.ctypes.data_as(_f32p), out.ctypes.data_as(_i32p))
+    return out
+
+
+def k_interpolate_grad(points, idx, weight, grad_out):
+    """tf_interpolate.py:32-36,53-58 -> tf_interpolate_g.cu:115-140,167-189 (three = k == 3)."""
+    idx, px = _i(idx)
+    weight, pw = _f(weight)
+    grad_out, pg = _f(grad_out)
+    b, m, c = np.shape(points)
+    n, k = idx.shape[1], idx.shape[2]
+    out = np.empty((b, m, c), np.float32)
+    lib().orc_k_interpolate_grad(b, n, c, m, k, pg, px, pw, out.ctypes.data_as(_f32p))
+    return out
+
+
 # --------------------------------------------------------------------------- MLP pieces
 BN_EPS = 1e-3  # tf.contrib.layers.batch_norm default, tf_util.py:424-444
 

@@ -1,4 +1,4 @@
-"""Golden vectors of three_nn / three_interpolate generated FROM THE REFERENCE'S OWN CPU FUNCTIONS
+"""Golden vectors of three_nn / three_interpolate / three_interpolate_grad generated FROM THE REFERENCE'S OWN CPU FUNCTIONS
 (oracle/_ref/libtf_interpolate_ref.so, `make -C oracle ref`; needs /root/reference, so it runs in the build
 container only).  Writes tests/golden/interp_ref.npz."""
 import os
@@ -24,7 +24,9 @@ for name, (b, n, m) in cases.items():
     w = rng.uniform(0, 1, (b, n, 3)).astype(np.float32)
     w /= w.sum(-1, keepdims=True)
     interp = I.ref_three_interpolate(pts, idx, w)
-    for k, v in dict(xyz1=xyz1, xyz2=xyz2, dist=dist, idx=idx, pts=pts, w=w, interp=interp).items():
+    gout = rng.normal(0, 1, (b, n, 37)).astype(np.float32)
+    gpts = I.ref_three_interpolate_grad(pts.shape, idx, w, gout)
+    for k, v in dict(xyz1=xyz1, xyz2=xyz2, dist=dist, idx=idx, pts=pts, w=w, interp=interp, gout=gout, gpts=gpts).items():
         out["%s_%s" % (name, k)] = v
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "interp_ref.npz"), **out)
 print("wrote", len(out), "arrays")
