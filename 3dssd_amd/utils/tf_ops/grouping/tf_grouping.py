@@ -7,6 +7,9 @@ function `group_point_grad(points, idx, grad_out)` -- no autograd registration. 
 messages (lib/utils/tf_ops/grouping/tf_grouping.cpp:275-288,368-384,453-459).
 Rows of empty balls are zero-filled (the reference leaves them unwritten).
 """
+import ctypes
+import os
+
 import torch
 
 from .. import _tensor as T
@@ -19,6 +22,35 @@ def _check_xyz(op, xyz1, xyz2):
     T.require(xyz1.shape[0] == xyz2.shape[0], "%s expects xyz1 and xyz2 with the same batch_size" % op)
 
 
+# frames with at least this many points go through the grid ball query (csrc/ballquery_grid.hip), like the fused
+# per-layer call of layers_util.py; identical outputs, ~10x fewer distance evaluations on large frames
+GRID_BALL_QUERY_MIN_N = int(os.environ.get("SA_GRID_BALL_QUERY_MIN_N", "512"))
+
+
+def _ball_query_one_band(op, min_radius, max_radius, nsample, dilated, xyz1, xyz2):
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    idx = torch.empty((b, m, int(nsample)), dtype=torch.int32, device=xyz1.device)
+    cnt = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
+    lib = N.lib()
+    if n >= GRID_BALL_QUERY_MIN_N:
+        ws = torch.empty((lib.sa_query_ball_point_grid_ws_bytes(b, n, m) + 3) // 4, dtype=torch.int32, device=xyz1.device)
+        st = lib.sa_query_ball_point_grid(b, n, m, 1, (ctypes.c_float * 1)(float(min_radius)),
+                                          (ctypes.c_float * 1)(float(max_radius)), (ctypes.c_int * 1)(int(nsample)),
+                                          1 if dilated else 0, xyz1.data_ptr(), xyz2.data_ptr(),
+                                          (ctypes.c_void_p * 1)(idx.data_ptr()), (ctypes.c_void_p * 1)(cnt.data_ptr()),
+                                          ws.data_ptr(), N.current_stream())
+    elif dilated:
+        st = lib.sa_query_ball_point_dilated(b, n, m, float(min_radius), float(max_radius), int(nsample),
+                                             xyz1.data_ptr(), xyz2.data_ptr(), idx.data_ptr(), cnt.data_ptr(),
+                                             N.current_stream())
+    else:
+        st = lib.sa_query_ball_point(b, n, m, float(max_radius), int(nsample), xyz1.data_ptr(), xyz2.data_ptr(),
+                                     idx.data_ptr(), cnt.data_ptr(), N.current_stream())
+    N.check(st, op)
+    return idx, cnt
+
+
 def query_ball_point(radius, nsample, xyz1, xyz2):
     """xyz1: (batch, ndataset, 3), xyz2: (batch, npoint, 3) ->
     idx (batch, npoint, nsample) int32, pts_cnt (batch, npoint) int32.   tf_grouping.py:53-66"""
@@ -27,14 +59,7 @@ def query_ball_point(radius, nsample, xyz1, xyz2):
     xyz1 = T.f32_cuda(xyz1, "xyz1")
     xyz2 = T.f32_cuda(xyz2, "xyz2")
     _check_xyz("QueryBallPoint", xyz1, xyz2)
-    b, n, _ = xyz1.shape
-    m = xyz2.shape[1]
-    idx = torch.empty((b, m, int(nsample)), dtype=torch.int32, device=xyz1.device)
-    cnt = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
-    st = N.lib().sa_query_ball_point(b, n, m, float(radius), int(nsample), xyz1.data_ptr(),
-                                     xyz2.data_ptr(), idx.data_ptr(), cnt.data_ptr(), N.current_stream())
-    N.check(st, "query_ball_point")
-    return idx, cnt
+    return _ball_query_one_band("query_ball_point", 0.0, radius, nsample, False, xyz1, xyz2)
 
 
 def query_ball_point_dilated(min_radius, max_radius, nsample, xyz1, xyz2):
@@ -45,15 +70,7 @@ def query_ball_point_dilated(min_radius, max_radius, nsample, xyz1, xyz2):
     xyz1 = T.f32_cuda(xyz1, "xyz1")
     xyz2 = T.f32_cuda(xyz2, "xyz2")
     _check_xyz("QueryBallPointDilated", xyz1, xyz2)
-    b, n, _ = xyz1.shape
-    m = xyz2.shape[1]
-    idx = torch.empty((b, m, int(nsample)), dtype=torch.int32, device=xyz1.device)
-    cnt = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
-    st = N.lib().sa_query_ball_point_dilated(b, n, m, float(min_radius), float(max_radius), int(nsample),
-                                             xyz1.data_ptr(), xyz2.data_ptr(), idx.data_ptr(),
-                                             cnt.data_ptr(), N.current_stream())
-    N.check(st, "query_ball_point_dilated")
-    return idx, cnt
+    return _ball_query_one_band("query_ball_point_dilated", min_radius, max_radius, nsample, True, xyz1, xyz2)
 
 
 def group_point(points, idx):

@@ -97,6 +97,25 @@ def test_fps_cooperative_kernel_all_identical_and_two_values(gpu, oracle):
     assert np.array_equal(got, oracle.farthest_point_sample(12, q))
 
 
+def test_single_band_api_grid_and_scan_kernels_agree(gpu, oracle, monkeypatch):
+    """query_ball_point(_dilated) goes through the grid kernel from n = 512 up; the plain scan kernels (forced here
+    by raising the threshold) must give the same bits, and both equal the oracle"""
+    G, syn = pkg("utils.tf_ops.grouping.tf_grouping"), pkg("synthetic")
+    xyz = syn.kitti_like_batch(2, n=6000)[:, :, :3].copy()
+    ctr = xyz[:, ::11].copy()
+    a = G.query_ball_point_dilated(0.4, 0.8, 48, _t(xyz, gpu), _t(ctr, gpu))
+    c = G.query_ball_point(1.1, 300, _t(xyz, gpu), _t(ctr, gpu))          # nsample beyond the grid kernel's LDS rows
+    monkeypatch.setattr(G, "GRID_BALL_QUERY_MIN_N", 1 << 30)
+    a2 = G.query_ball_point_dilated(0.4, 0.8, 48, _t(xyz, gpu), _t(ctr, gpu))
+    c2 = G.query_ball_point(1.1, 300, _t(xyz, gpu), _t(ctr, gpu))
+    for x, y in zip(a + c, a2 + c2):
+        assert torch.equal(x, y)
+    ri, rc = oracle.query_ball_point_dilated(0.4, 0.8, 48, xyz, ctr)
+    assert np.array_equal(a[0].cpu().numpy(), ri) and np.array_equal(a[1].cpu().numpy(), rc)
+    ri, rc = oracle.query_ball_point(1.1, 300, xyz, ctr)
+    assert np.array_equal(c[0].cpu().numpy(), ri) and np.array_equal(c[1].cpu().numpy(), rc)
+
+
 def test_fps_forced_generic_kernel_equals_register_kernel(gpu, oracle):
     N = pkg("utils._native")
     rng = np.random.default_rng(5)
