@@ -11,6 +11,11 @@
 //     store and polled by the G-1 partners (agent-scope atomic loads) -- the cross-workgroup arg-max.
 // Co-residency of the partners is guaranteed by hipLaunchCooperativeKernel; the poll is bounded and traps, so a
 // bug cannot hang the device.
+// Tried and dropped (measured, MI355X): keeping the G partners of a frame on one XCD (ids of one residue class mod 8,
+// verified in-kernel through HW_REG_XCC_ID) and exchanging the slots through that XCD's L2 instead of the
+// device-coherent sc1 path.  A plain / sc0 store is not seen by an sc0 load outside threadgroup-split mode (poll
+// times out), a returning atomic-OR poll serialises the 16 x G pollers on one line (64 us per pick), and
+// buffer_inv sc1 + plain load costs 34 us per pick; the sc1 store / sc1 load pair below stays at 2.3 us.
 //
 // Semantics = tf_sampling_g.cu:123-178 exactly (same fmaf chain over the channels, same strict-maximum rule).
 // The reference's tie-break among equal maxima is "lowest k mod 1024, then lowest k" (thread t owns k = t,

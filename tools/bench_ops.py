@@ -84,5 +84,14 @@ ms = timeit(lambda: G.query_ball_point_dilated(0.4, 0.8, 64, p64, c64), iters=5)
 by = 16 * (65536 * 12 + 4096 * 12 + 4096 * 65 * 4)
 out.append(dict(op="query_ball_point_dilated (configs[4])", case="16 x 65536, m=4096, r 0.4-0.8, ns 64", ms=round(ms, 4),
                 mbytes=round(by / 1e6, 2), gbs=round(by / ms / 1e6, 1)))
+# BASELINE.json configs[4], whole backbone: 16 frames of 65536 points through the same ARCHITECTURE rows (SURVEY.md 8d
+# Config 5: only layer 1 sees the larger frame), eager launches on one stream (the cooperative FPS is not graph-captured)
+cfgs = importlib.import_module("3dssd_amd.configs")
+net = importlib.import_module("3dssd_amd.backbone").SABackbone(cfgs.KITTI_3DSSD_ARCH, syn.random_backbone_params(cfgs.KITTI_3DSSD_ARCH),
+                                                             dev, cfgs.KITTI_MAX_TRANSLATE_RANGE)
+f64 = torch.from_numpy(syn.kitti_like_batch(16, n=65536)).to(dev)
+ms = timeit(lambda: net(f64), iters=5, warm=2)
+out.append(dict(op="SA backbone (configs[4])", case="16 x 65536-pt frames, one stream, eager", ms=round(ms, 2),
+                frames_per_s=round(16 / ms * 1e3, 1)))
 for o in out:
     print(json.dumps(o))
