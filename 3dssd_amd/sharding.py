@@ -23,6 +23,8 @@ def init(backend=None):
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)        # RCCL binds its communicator to the current device
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
@@ -34,7 +36,10 @@ def frames_of_rank(first_frame, n_frames, rank, world):
 
 def barrier():
     if dist.is_initialized():
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def reduce_timing(elapsed_s, frames_done, device="cpu"):
