@@ -282,6 +282,10 @@ extern "C" size_t sa_query_ball_point_grid_ws_bytes(int b, int n, int m) {
     return ((size_t)b * ws_stride(n) + 4 + (size_t)b * m) * sizeof(int);
 }
 
+extern "C" int sa_query_ball_point_multi(int b, int n, int m, int nbands, const float *rmin, const float *rmax,
+                                         const int *ns, int dilated, const float *xyz1, const float *xyz2,
+                                         int *const *idx, int *const *cnt, hipStream_t stream);
+
 // Same contract as sa_query_ball_point_multi (all bands of one SA layer), through the grid.  `workspace` is
 // caller-owned device memory of sa_query_ball_point_grid_ws_bytes(b, n, m) bytes.  nbands <= 4.
 extern "C" int sa_query_ball_point_grid(int b, int n, int m, int nbands, const float *rmin, const float *rmax,
@@ -289,6 +293,10 @@ extern "C" int sa_query_ball_point_grid(int b, int n, int m, int nbands, const f
                                         int *const *idx, int *const *cnt, void *workspace, hipStream_t stream) {
     if (b <= 0 || n <= 0 || m <= 0 || nbands <= 0 || nbands > kMaxBands || !xyz1 || !xyz2 || !idx || !cnt || !workspace)
         return SA_ERR_INVALID;
+    // the per-query hit lists (LDS) and the ordered fallback scan hold kCap entries per band: larger nsample goes to
+    // the plain scan kernels (found by tools/fuzz_ops.py: nsample = 300 rows were cut at 256)
+    for (int i = 0; i < nbands; ++i)
+        if (ns[i] > kCap) return sa_query_ball_point_multi(b, n, m, nbands, rmin, rmax, ns, dilated, xyz1, xyz2, idx, cnt, stream);
     GBands B;
     B.nbands = nbands;
     B.dilated = dilated ? 1 : 0;

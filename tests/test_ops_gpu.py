@@ -104,16 +104,22 @@ def test_single_band_api_grid_and_scan_kernels_agree(gpu, oracle, monkeypatch):
     xyz = syn.kitti_like_batch(2, n=6000)[:, :, :3].copy()
     ctr = xyz[:, ::11].copy()
     a = G.query_ball_point_dilated(0.4, 0.8, 48, _t(xyz, gpu), _t(ctr, gpu))
-    c = G.query_ball_point(1.1, 300, _t(xyz, gpu), _t(ctr, gpu))          # nsample beyond the grid kernel's LDS rows
+    c = G.query_ball_point(6.0, 300, _t(xyz, gpu), _t(ctr, gpu))          # nsample beyond the grid kernel's LDS rows,
+                                                                           # and balls that really hold > 256 points
     monkeypatch.setattr(G, "GRID_BALL_QUERY_MIN_N", 1 << 30)
     a2 = G.query_ball_point_dilated(0.4, 0.8, 48, _t(xyz, gpu), _t(ctr, gpu))
-    c2 = G.query_ball_point(1.1, 300, _t(xyz, gpu), _t(ctr, gpu))
+    c2 = G.query_ball_point(6.0, 300, _t(xyz, gpu), _t(ctr, gpu))
     for x, y in zip(a + c, a2 + c2):
         assert torch.equal(x, y)
     ri, rc = oracle.query_ball_point_dilated(0.4, 0.8, 48, xyz, ctr)
     assert np.array_equal(a[0].cpu().numpy(), ri) and np.array_equal(a[1].cpu().numpy(), rc)
-    ri, rc = oracle.query_ball_point(1.1, 300, xyz, ctr)
+    ri, rc = oracle.query_ball_point(6.0, 300, xyz, ctr)
     assert np.array_equal(c[0].cpu().numpy(), ri) and np.array_equal(c[1].cpu().numpy(), rc)
+    assert rc.max() == 300
+    # nsample = 256 (the capacity of the grid kernel's lists) with fuller balls: the ordered fallback scan
+    d = G.query_ball_point(6.0, 256, _t(xyz, gpu), _t(ctr, gpu))
+    ri, rc = oracle.query_ball_point(6.0, 256, xyz, ctr)
+    assert np.array_equal(d[0].cpu().numpy(), ri) and np.array_equal(d[1].cpu().numpy(), rc)
 
 
 def test_fps_forced_generic_kernel_equals_register_kernel(gpu, oracle):

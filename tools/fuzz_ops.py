@@ -1,0 +1,247 @@
+"""Randomised parity sweep: every operator of the C ABI on random small/ragged shapes against the CPU oracle
+(bit-exact for index/byte results, 1e-3 relative for the MLP).  Test infrastructure (uses oracle/), meant for the GPU
+box:  python tools/fuzz_ops.py [seconds] [seed]   -> prints one line per failure and a summary; exit code 1 on failure.
+"""
+import ctypes
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import interp_oracle as IO  # noqa: E402
+from oracle import sa_oracle as O  # noqa: E402
+
+
+def pkg(name):
+    return importlib.import_module("3dssd_amd." + name)
+
+
+S, G = pkg("utils.tf_ops.sampling.tf_sampling"), pkg("utils.tf_ops.grouping.tf_grouping")
+I, M = pkg("utils.tf_ops.interpolation.tf_interpolate"), pkg("utils.model_util")
+N, Wt = pkg("utils._native"), pkg("utils.weights")
+dev = torch.device("cuda:0")
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def cloud(rng, b, n, c=3, dup=0.0, lattice=False):
+    p = rng.normal(0, 2, (b, n, c)).astype(np.float32)
+    if lattice:
+        p = np.round(p * 2) / 2
+    if dup > 0 and n > 2:
+        k = max(1, int(n * dup))
+        for i in range(b):
+            p[i, rng.integers(0, n, k)] = p[i, rng.integers(0, n, k)]
+    return p
+
+
+def eq(name, got, ref, info):
+    got = got.cpu().numpy() if isinstance(got, torch.Tensor) else got
+    if got.shape != ref.shape or not np.array_equal(got, ref):
+        bad = int((got != ref).sum()) if got.shape == ref.shape else -1
+        return "%s MISMATCH %s (%d elements)" % (name, info, bad)
+    return None
+
+
+def case_fps(rng):
+    b, c = int(rng.integers(1, 4)), int(rng.choice([3, 3, 3, 1, 2, 5, 16, 67]))
+    n = int(rng.choice([1, 2, 63, 64, 65, 500, 1023, 1024, 1025, 2047, 3000, 4097, 9000]))
+    if c == 67:
+        n = min(n, 3000)
+    m = int(rng.integers(1, min(n, 300) + 1))
+    p = cloud(rng, b, n, c, dup=float(rng.choice([0, 0.1, 0.5])), lattice=bool(rng.integers(0, 2)))
+    return eq("farthest_point_sample", S.farthest_point_sample(m, t(p)), O.farthest_point_sample(m, p), (b, n, c, m))
+
+
+def case_fps_dist(rng):
+    b, n = int(rng.integers(1, 3)), int(rng.choice([1, 5, 64, 100, 513, 1024, 1500]))
+    m = int(rng.integers(1, min(n, 200) + 1))
+    d = rng.uniform(-1, 5, (b, n, n)).astype(np.float32)
+    if rng.integers(0, 2):
+        d = np.round(d)
+    return eq("fps_with_distance", S.farthest_point_sample_with_distance(m, t(d)),
+              O.farthest_point_sample_with_distance(m, d), (b, n, m))
+
+
+def case_fps_preidx(rng):
+    b, c, n = int(rng.integers(1, 3)), int(rng.choice([3, 3, 7])), int(rng.choice([3, 70, 1024, 1100, 2500]))
+    m, m1 = int(rng.integers(1, min(n, 60) + 1)), int(rng.integers(0, 9))
+    p = cloud(rng, b, n, c, dup=float(rng.choice([0, 0.3])), lattice=bool(rng.integers(0, 2)))
+    pre = rng.integers(0, n, (b, m1)).astype(np.int32)
+    return eq("fps_with_preidx", S.farthest_point_sample_with_preidx(m, t(p), t(pre)),
+              O.farthest_point_sample_with_preidx(m, p, pre), (b, n, c, m, m1))
+
+
+def case_gather(rng):
+    b, n, c, m = int(rng.integers(1, 4)), int(rng.integers(1, 900)), int(rng.choice([1, 3, 4, 7, 64, 130])), int(rng.integers(1, 300))
+    p = rng.normal(0, 1, (b, n, c)).astype(np.float32)
+    idx = rng.integers(0, n, (b, m)).astype(np.int32)
+    e = eq("gather_point", S.gather_point(t(p), t(idx)), O.gather_point(p, idx), (b, n, c, m))
+    if e:
+        return e
+    ns = int(rng.integers(1, 40))
+    gi = rng.integers(-1, n, (b, m, ns)).astype(np.int32)
+    return eq("group_point", G.group_point(t(p), t(gi)), O.group_point(p, gi), (b, n, c, m, ns))
+
+
+def case_ball(rng):
+    b, n = int(rng.integers(1, 3)), int(rng.choice([1, 30, 64, 511, 512, 513, 2000, 5000]))
+    m, ns = int(rng.integers(1, 200)), int(rng.choice([1, 2, 16, 32, 33, 64, 65, 100, 300]))
+    xyz = cloud(rng, b, n, 3, dup=float(rng.choice([0, 0.2])), lattice=bool(rng.integers(0, 2)))
+    ctr = xyz[:, rng.integers(0, n, m)] + (rng.normal(0, 0.2, (b, m, 3)).astype(np.float32) if rng.integers(0, 2) else 0)
+    ctr = np.ascontiguousarray(ctr, np.float32)
+    r0, r1 = sorted(rng.choice([0.0, 0.25, 0.5, 1.0, 1.5, 3.0, 50.0], 2, replace=False).tolist())
+    i1, c1 = G.query_ball_point_dilated(r0, r1, ns, t(xyz), t(ctr))
+    ri, rc = O.query_ball_point_dilated(r0, r1, ns, xyz, ctr)
+    e = eq("query_ball_point_dilated idx", i1, ri, (b, n, m, ns, r0, r1)) or eq("query_ball_point_dilated cnt", c1, rc, (b, n, m, ns, r0, r1))
+    if e:
+        return e
+    i2, c2 = G.query_ball_point(r1, ns, t(xyz), t(ctr))
+    ri, rc = O.query_ball_point(r1, ns, xyz, ctr)
+    e = eq("query_ball_point idx", i2, ri, (b, n, m, ns, r1)) or eq("query_ball_point cnt", c2, rc, (b, n, m, ns, r1))
+    if e or n > 600:
+        return e
+    order = np.stack([np.stack([rng.permutation(n) for _ in range(m)]) for _ in range(b)]).astype(np.int32)
+    i3, c3 = G.query_ball_point_withidx(r1, ns, t(xyz), t(ctr), t(order))
+    ri, rc = O.query_ball_point_withidx(r1, ns, xyz, ctr, order)
+    return eq("withidx idx", i3, ri, (b, n, m, ns, r1)) or eq("withidx cnt", c3, rc, (b, n, m, ns, r1))
+
+
+def case_sqdist(rng):
+    b, n, m = int(rng.integers(1, 3)), int(rng.choice([1, 31, 128, 129, 300, 512])), int(rng.choice([1, 64, 127, 300, 512]))
+    c = int(rng.choice([1, 3, 4, 35, 67, 68, 131]))
+    a = rng.normal(0, 1, (b, n, c)).astype(np.float32)
+    bb = a if (n == m and rng.integers(0, 2)) else rng.normal(0, 1, (b, m, c)).astype(np.float32)
+    ta = t(a)
+    tb = ta if bb is a else t(bb)
+    return eq("calc_square_dist", M.calc_square_dist(ta, tb), O.calc_square_dist(a, bb), (b, n, m, c, bb is a))
+
+
+def case_mlp(rng):
+    b, n, m = int(rng.integers(1, 3)), int(rng.integers(4, 400)), int(rng.integers(1, 120))
+    c = int(rng.choice([0, 1, 1, 5, 8, 64, 64, 128, 256]))
+    ns = int(rng.choice([1, 3, 8, 16, 20, 32, 48, 64, 70]))
+    nl = int(rng.integers(1, 4))
+    wide = int(rng.choice([16, 32, 64, 128, 256])) if c < 128 else int(rng.choice([128, 256]))
+    dims = [int(rng.choice([wide, wide, wide // 2 + 4, wide + 8])) for _ in range(nl)]
+    if rng.integers(0, 3) == 0 and nl == 3:
+        dims = {1: [16, 16, 32], 64: [64, 64, 128], 128: [128, 192, 256], 256: [256, 256, 512]}.get(c, dims)
+    xyz = cloud(rng, b, n)
+    feat = rng.normal(0, 1, (b, n, c)).astype(np.float32) if c else None
+    new_xyz = np.ascontiguousarray(xyz[:, rng.integers(0, n, m)] + rng.normal(0, 0.1, (b, m, 3)), np.float32)
+    idx = rng.integers(0, n, (b, m, ns)).astype(np.int32)
+    cnt = rng.integers(0, ns + 1, (b, m)).astype(np.int32)
+    cin = [c + 3] + dims[:-1]
+    ws = [rng.normal(0, 1.0 / np.sqrt(k), (k, o)).astype(np.float32) for k, o in zip(cin, dims)]
+    bs = [rng.normal(0, 0.1, o).astype(np.float32) for o in dims]
+    layers = Wt.pack_scale(ws, bs, dev) if rng.integers(0, 2) else [Wt.PackedLayer(w, x, dev) for w, x in zip(ws, bs)]
+    out = torch.empty((b, m, dims[-1]), dtype=torch.float32, device=dev)
+    dm = (ctypes.c_int * (nl + 1))(*([c + 3] + dims))
+    tx, tn, ti, tc = t(xyz), t(new_xyz), t(idx), t(cnt)
+    tf = t(feat) if c else None
+    st = N.lib().sa_group_mlp_max(b, n, m, ns, c, tx.data_ptr(), tf.data_ptr() if c else None, tn.data_ptr(), ti.data_ptr(),
+                                  tc.data_ptr(), nl, dm, (ctypes.c_void_p * nl)(*[l.w.data_ptr() for l in layers]),
+                                  (ctypes.c_void_p * nl)(*[l.bias.data_ptr() for l in layers]), out.data_ptr(), dims[-1], 0,
+                                  N.current_stream())
+    if st != 0:
+        return "group_mlp_max status %d %s" % (st, (b, n, m, c, ns, dims))
+    torch.cuda.synchronize()
+    ref = O.group_mlp_max(xyz, feat, new_xyz, idx, cnt, ws, bs)
+    got = out.cpu().numpy()
+    err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)
+    if not np.isfinite(got).all() or err > 1e-3 or (got[cnt == 0] != 0).any():
+        return "group_mlp_max rel err %.3g %s" % (err, (b, n, m, c, ns, dims))
+    return None
+
+
+def case_interp(rng):
+    b, n, m, c = int(rng.integers(1, 3)), int(rng.integers(1, 700)), int(rng.choice([1, 2, 3, 50, 2047, 2049, 5000])), int(rng.choice([1, 7, 64]))
+    x1 = cloud(rng, b, n, lattice=bool(rng.integers(0, 2)))
+    x2 = cloud(rng, b, m, lattice=bool(rng.integers(0, 2)))
+    d, ix = I.three_nn(t(x1), t(x2))
+    rd, ri = IO.three_nn(x1, x2)
+    e = eq("three_nn dist", d, rd, (b, n, m)) or eq("three_nn idx", ix, ri, (b, n, m))
+    if e:
+        return e
+    pts = rng.normal(0, 1, (b, m, c)).astype(np.float32)
+    w = rng.uniform(0, 1, (b, n, 3)).astype(np.float32)
+    return eq("three_interpolate", I.three_interpolate(t(pts), t(ri), t(w)), IO.three_interpolate(pts, ri, w), (b, n, m, c))
+
+
+def case_boxes(rng):
+    b, n, m, ns = int(rng.integers(1, 3)), int(rng.choice([1, 63, 64, 65, 1000, 3000])), int(rng.integers(1, 40)), int(rng.choice([1, 5, 64, 200]))
+    xyz = cloud(rng, b, n, lattice=bool(rng.integers(0, 2)))
+    boxes = np.zeros((b, m, 7), np.float32)
+    ctr = xyz[:, rng.integers(0, n, m)]
+    boxes[..., :3] = ctr + rng.normal(0, 0.5, (b, m, 3))
+    boxes[..., 3:6] = rng.uniform(0, 5, (b, m, 3))
+    boxes[..., 6] = rng.choice([0, np.pi / 2, np.pi, -np.pi / 2, 0.3, 1.7, -2.9], (b, m))
+    if rng.integers(0, 2):
+        boxes = np.round(boxes * 2) / 2
+    boxes = boxes.astype(np.float32)
+    i1, c1 = G.query_boxes_3d_points(ns, t(xyz), t(boxes))
+    ri, rc = O.query_boxes_3d_points(ns, xyz, boxes)
+    e = eq("boxes_points idx", i1, ri, (b, n, m, ns)) or eq("boxes_points cnt", c1, rc, (b, n, m, ns))
+    e = e or eq("boxes_mask", G.query_boxes_3d_mask(t(xyz), t(boxes)), O.query_boxes_3d_mask(xyz, boxes), (b, n, m))
+    if e:
+        return e
+    g = int(rng.integers(1, min(m, 5) + 1))
+    gt = boxes[:, :g].copy()
+    iou = rng.uniform(0, 0.004, (b, m, g)).astype(np.float32)
+    return eq("points_iou", G.query_points_iou(t(xyz), t(boxes), t(gt), t(iou)), O.query_points_iou(xyz, boxes, gt, iou), (b, n, m, g))
+
+
+def case_misc(rng):
+    b, n, c, pn = int(rng.integers(1, 4)), int(rng.choice([1, 255, 256, 257, 1000])), int(rng.choice([1, 3, 64])), int(rng.choice([1, 7, 300]))
+    inp = rng.normal(0, 1, (b, n, c)).astype(np.float32)
+    mask = ((rng.uniform(0, 1, (b, n)) < rng.choice([0.0, 0.02, 0.5, 1.0])) * rng.choice([1.0, -3.0, 0.7, 1.2], (b, n))).astype(np.float32)
+    e = eq("gather_by_mask", S.gather_by_mask(pn, t(inp), t(mask)), O.gather_by_mask(pn, inp, mask), (b, n, c, pn))
+    if e:
+        return e
+    m, k = int(rng.integers(1, 20)), int(rng.choice([1, 3, 16, 400]))
+    d = (rng.integers(0, 30, (b, m, n)) * 0.5).astype(np.float32)
+    oi, o = G.select_top_k(k, t(d))
+    roi, ro = O.select_top_k(k, d)
+    e = eq("select_top_k val", o, ro, (b, m, n, k)) or eq("select_top_k idx", oi, roi, (b, m, n, k))
+    if e:
+        return e
+    gi = rng.integers(-1, n, (b, m, 6)).astype(np.int32)
+    gg = rng.integers(-4, 5, (b, m, 6, c)).astype(np.float32)
+    return eq("group_point_grad", G.group_point_grad(t(inp), t(gi), t(gg)), O.group_point_grad(inp, gi, gg), (b, n, c, m))
+
+
+CASES = [case_fps, case_fps, case_fps_dist, case_fps_preidx, case_gather, case_ball, case_ball, case_sqdist, case_mlp, case_mlp,
+         case_mlp, case_interp, case_boxes, case_misc]
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    t0, runs, fails = time.time(), {}, []
+    while time.time() - t0 < budget:
+        fn = CASES[int(rng.integers(0, len(CASES)))]
+        sub = np.random.default_rng(int(rng.integers(0, 2 ** 31)))
+        try:
+            e = fn(sub)
+        except Exception as ex:  # noqa: BLE001
+            e = "%s raised %r" % (fn.__name__, ex)
+        runs[fn.__name__] = runs.get(fn.__name__, 0) + 1
+        if e:
+            fails.append(e)
+            print("FAIL", e, flush=True)
+            if len(fails) > 20:
+                break
+    print("fuzz: %d cases in %.0f s, %d failures; per op: %s" % (sum(runs.values()), time.time() - t0, len(fails), runs))
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()
