@@ -1,6 +1,6 @@
 """Randomised parity sweep: every operator of the C ABI on random small/ragged shapes against the CPU oracle
 (bit-exact for index/byte results, 1e-3 relative for the MLP).  Test infrastructure (uses oracle/), meant for the GPU
-box:  python tools/fuzz_ops.py [seconds] [seed]   -> prints one line per failure and a summary; exit code 1 on failure.
+box:  python tools/fuzz_ops.py [seconds] [seed] [big]   (big: mid-size shapes of the hot-path kernels) -> prints one line per failure and a summary; exit code 1 on failure.
 """
 import ctypes
 import importlib
@@ -217,6 +217,106 @@ def case_misc(rng):
     return eq("group_point_grad", G.group_point_grad(t(inp), t(gi), t(gg)), O.group_point_grad(inp, gi, gg), (b, n, c, m))
 
 
+def case_fps_big(rng):
+    """layer-1 shapes: the wave-bucket kernel (8192 <= n <= 16384, m >= 64), ragged n, clustered / duplicated / flat data"""
+    b, n = int(rng.integers(1, 4)), int(rng.integers(8192, 16385))
+    m = int(rng.integers(64, 700))
+    kind = int(rng.integers(0, 4))
+    if kind == 0:
+        p = pkg("synthetic").kitti_like_batch(b, n=n)[:, :, :3].copy()
+    elif kind == 1:
+        p = cloud(rng, b, n, 3, dup=0.3, lattice=True)
+    elif kind == 2:                                       # a few tight clusters + a far outlier
+        p = (rng.normal(0, 0.01, (b, n, 3)) + rng.integers(0, 5, (b, n, 1)) * 3.0).astype(np.float32)
+        p[:, n // 2] = 1000.0
+    else:
+        p = cloud(rng, b, n, 3)
+        p[:, :, 1] = 0.0                                  # flat
+    return eq("farthest_point_sample(big)", S.farthest_point_sample(m, t(p)), O.farthest_point_sample(m, p), (b, n, m, kind))
+
+
+def case_ball_multi(rng):
+    """the fused per-layer call: 2-4 bands in one pass, grid and scan kernels"""
+    b, n, m = int(rng.integers(1, 3)), int(rng.choice([300, 512, 1024, 4096, 12000])), int(rng.integers(1, 600))
+    nb = int(rng.integers(2, 5))
+    xyz = pkg("synthetic").kitti_like_batch(b, n=n)[:, :, :3].copy() if rng.integers(0, 2) else cloud(rng, b, n, 3, dup=0.1)
+    ctr = np.ascontiguousarray(xyz[:, rng.integers(0, n, m)])
+    edges = np.sort(rng.choice([0.1, 0.2, 0.4, 0.8, 1.6, 3.2, 4.8, 6.4], nb, replace=False)).astype(np.float32)
+    dil = bool(rng.integers(0, 2))
+    rmin = [0.0] + [float(e) for e in edges[:-1]]
+    rmax = [float(e) for e in edges]
+    ns = [int(rng.choice([8, 16, 32, 64])) for _ in range(nb)]
+    idx = [torch.empty((b, m, k), dtype=torch.int32, device=dev) for k in ns]
+    cnt = [torch.empty((b, m), dtype=torch.int32, device=dev) for _ in ns]
+    lib = N.lib()
+    args = (b, n, m, nb, (ctypes.c_float * nb)(*rmin), (ctypes.c_float * nb)(*rmax), (ctypes.c_int * nb)(*ns), 1 if dil else 0)
+    tx, tc = t(xyz), t(ctr)
+    ptrs = ((ctypes.c_void_p * nb)(*[x.data_ptr() for x in idx]), (ctypes.c_void_p * nb)(*[x.data_ptr() for x in cnt]))
+    if rng.integers(0, 2):
+        ws = torch.empty((lib.sa_query_ball_point_grid_ws_bytes(b, n, m) + 3) // 4, dtype=torch.int32, device=dev)
+        st = lib.sa_query_ball_point_grid(*args, tx.data_ptr(), tc.data_ptr(), *ptrs, ws.data_ptr(), N.current_stream())
+        which = "grid"
+    else:
+        st = lib.sa_query_ball_point_multi(*args, tx.data_ptr(), tc.data_ptr(), *ptrs, N.current_stream())
+        which = "scan"
+    if st != 0:
+        return "ball multi status %d" % st
+    for i in range(nb):
+        ri, rc = (O.query_ball_point_dilated(rmin[i], rmax[i], ns[i], xyz, ctr) if dil else O.query_ball_point(rmax[i], ns[i], xyz, ctr))
+        e = eq("ball multi idx[%d] %s" % (i, which), idx[i], ri, (b, n, m, nb, dil)) or eq("ball multi cnt[%d] %s" % (i, which), cnt[i], rc, (b, n, m, nb, dil))
+        if e:
+            return e
+    return None
+
+
+def case_sqdist_big(rng):
+    b, n = int(rng.integers(1, 3)), int(rng.choice([512, 640, 1000, 1024, 2048]))
+    c = int(rng.choice([67, 131, 35, 7, 64]))
+    a = rng.normal(0, 1, (b, n, c)).astype(np.float32)
+    ta = t(a)
+    e = eq("calc_square_dist(sym big)", M.calc_square_dist(ta, ta), O.calc_square_dist(a, a), (b, n, c))
+    if e:
+        return e
+    m = int(rng.choice([300, 512, 1111]))
+    bb = rng.normal(0, 1, (b, m, c)).astype(np.float32)
+    return eq("calc_square_dist(big)", M.calc_square_dist(ta, t(bb)), O.calc_square_dist(a, bb), (b, n, m, c))
+
+
+def case_mlp_big(rng):
+    """the backbone's own scales with enough balls for several tiles per workgroup"""
+    c, ns, dims = [(1, 32, [16, 16, 32]), (1, 64, [32, 32, 64]), (64, 32, [64, 64, 128]), (64, 64, [64, 96, 128]),
+                   (128, 32, [128, 128, 256]), (128, 32, [128, 192, 256]), (128, 32, [128, 256, 256]),
+                   (256, 16, [256, 256, 512]), (256, 32, [256, 512, 1024])][int(rng.integers(0, 9))]
+    b, n, m = int(rng.integers(1, 3)), int(rng.integers(300, 1500)), int(rng.integers(200, 1500))
+    xyz = cloud(rng, b, n)
+    feat = rng.normal(0, 1, (b, n, c)).astype(np.float32)
+    new_xyz = np.ascontiguousarray(xyz[:, rng.integers(0, n, m)], np.float32)
+    idx = rng.integers(0, n, (b, m, ns)).astype(np.int32)
+    cnt = rng.integers(0, ns + 1, (b, m)).astype(np.int32)
+    cin = [c + 3] + dims[:-1]
+    ws = [rng.normal(0, 1.0 / np.sqrt(k), (k, o)).astype(np.float32) for k, o in zip(cin, dims)]
+    bs = [rng.normal(0, 0.1, o).astype(np.float32) for o in dims]
+    layers = Wt.pack_scale(ws, bs, dev)
+    nl = 3
+    out = torch.empty((b, m, dims[-1]), dtype=torch.float32, device=dev)
+    tx, tn, ti, tc, tf = t(xyz), t(new_xyz), t(idx), t(cnt), t(feat)
+    st = N.lib().sa_group_mlp_max(b, n, m, ns, c, tx.data_ptr(), tf.data_ptr(), tn.data_ptr(), ti.data_ptr(), tc.data_ptr(), nl,
+                                  (ctypes.c_int * 4)(*([c + 3] + dims)), (ctypes.c_void_p * nl)(*[l.w.data_ptr() for l in layers]),
+                                  (ctypes.c_void_p * nl)(*[l.bias.data_ptr() for l in layers]), out.data_ptr(), dims[-1], 0,
+                                  N.current_stream())
+    if st != 0:
+        return "group_mlp_max(big) status %d" % st
+    torch.cuda.synchronize()
+    ref = O.group_mlp_max(xyz, feat, new_xyz, idx, cnt, ws, bs)
+    got = out.cpu().numpy()
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    if not np.isfinite(got).all() or err > 1e-3 or (got[cnt == 0] != 0).any():
+        return "group_mlp_max(big) rel err %.3g %s" % (err, (b, n, m, c, ns, dims))
+    return None
+
+
+BIG = [case_fps_big, case_ball_multi, case_sqdist_big, case_mlp_big]
+
 CASES = [case_fps, case_fps, case_fps_dist, case_fps_preidx, case_gather, case_ball, case_ball, case_sqdist, case_mlp, case_mlp,
          case_mlp, case_interp, case_boxes, case_misc]
 
@@ -224,10 +324,11 @@ CASES = [case_fps, case_fps, case_fps_dist, case_fps_preidx, case_gather, case_b
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    cases = BIG if (len(sys.argv) > 3 and sys.argv[3] == "big") else CASES
     rng = np.random.default_rng(seed)
     t0, runs, fails = time.time(), {}, []
     while time.time() - t0 < budget:
-        fn = CASES[int(rng.integers(0, len(CASES)))]
+        fn = cases[int(rng.integers(0, len(cases)))]
         sub = np.random.default_rng(int(rng.integers(0, 2 ** 31)))
         try:
             e = fn(sub)
