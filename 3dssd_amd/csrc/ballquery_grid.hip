@@ -294,7 +294,7 @@ extern "C" int sa_query_ball_point_grid(int b, int n, int m, int nbands, const f
     if (b <= 0 || n <= 0 || m <= 0 || nbands <= 0 || nbands > kMaxBands || !xyz1 || !xyz2 || !idx || !cnt || !workspace)
         return SA_ERR_INVALID;
     // the per-query hit lists (LDS) and the ordered fallback scan hold kCap entries per band: larger nsample goes to
-    // the plain scan kernels (found by tools/fuzz_ops.py: nsample = 300 rows were cut at 256)
+    // the plain scan kernels (found by tests/fuzz_ops.py: nsample = 300 rows were cut at 256)
     for (int i = 0; i < nbands; ++i)
         if (ns[i] > kCap) return sa_query_ball_point_multi(b, n, m, nbands, rmin, rmax, ns, dilated, xyz1, xyz2, idx, cnt, stream);
     GBands B;

@@ -1,6 +1,6 @@
 """Randomised parity sweep: every operator of the C ABI on random small/ragged shapes against the CPU oracle
 (bit-exact for index/byte results, 1e-3 relative for the MLP).  Test infrastructure (uses oracle/), meant for the GPU
-box:  python tools/fuzz_ops.py [seconds] [seed] [big]   (big: mid-size shapes of the hot-path kernels) -> prints one line per failure and a summary; exit code 1 on failure.
+box:  python tests/fuzz_ops.py [seconds] [seed] [big]   (big: mid-size shapes of the hot-path kernels) -> prints one line per failure and a summary; exit code 1 on failure.
 """
 import ctypes
 import importlib
