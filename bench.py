@@ -232,8 +232,8 @@ def cpu_baseline(arch, params, batch, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step (BASELINE.json configs[1])")
     ap.add_argument("--points", type=int, default=16384)
     ap.add_argument("--streams", type=int, default=16, help="HIP streams the steps are issued on")
