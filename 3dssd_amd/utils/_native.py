@@ -49,6 +49,8 @@ SIGNATURES = {
     "sa_farthest_point_sample_with_preidx": [_c_int] * 5 + [_vp, _vp, _vp, _vp, _vp],
     "sa_three_interpolate_grad": [_c_int] * 4 + [_vp, _vp, _vp, _vp, _vp],
     "sa_k_interpolate_grad": [_c_int] * 5 + [_vp, _vp, _vp, _vp, _vp],
+    "sa_points_pooling": [_c_int] * 8 + [_vp] * 8,
+    "sa_points_pooling_grad": [_c_int] * 8 + [_vp] * 5,
 }
 
 _ERRORS = {-1: "invalid argument", -2: "kernel launch failed (hipGetLastError)", -3: "unsupported size"}

@@ -583,3 +583,58 @@ void orc_k_interpolate_grad(int b, int n, int c, int m, int k, const float *grad
                     grad_points[((size_t)bi * m + idx[r * k + i]) * c + l] += pr;
                 }
 }
+
+/* ==== points_pooling: lib/utils/tf_ops/points_pooling/tf_points_pooling_g.cu:36-118,131-153 ==================== */
+/* The four outputs start at zero (the op's cudaMemsets, tf_points_pooling.cpp:133-140).  `pillars` uses the
+ * intended [.., l,h,w,3] layout; the reference offsets it by l*h*w floats per proposal (:66), so its proposals
+ * overwrite each other's centres. */
+void orc_points_pooling(int bs, int proposal_num, int point_num, int c, int l, int h, int w, int sample_num,
+                        const float *pc, const float *box_3d, const float *pc_loc, float *out_features, int *out_idx,
+                        int *sampled_num, float *pillars) {
+    long nvox = (long)l * h * w;
+    memset(out_features, 0, sizeof(float) * (size_t)bs * proposal_num * nvox * sample_num * c);
+    memset(out_idx, 0, sizeof(int) * (size_t)bs * proposal_num * nvox * sample_num);
+    memset(sampled_num, 0, sizeof(int) * (size_t)bs * proposal_num * nvox);
+    for (long q = 0; q < (long)bs * proposal_num; ++q) {
+        const float *bx = box_3d + q * 6, *loc = pc_loc + (size_t)q * point_num * 3, *ft = pc + (size_t)q * point_num * c;
+        float il = bx[3] / (float)l, ih = bx[4] / (float)h, iw = bx[5] / (float)w;          /* :57-59 */
+        float xmin = (float)(bx[0] - bx[3] / 2.), ymin = bx[1] - bx[4], zmin = (float)(bx[2] - bx[5] / 2.);
+        float *pl = pillars + (size_t)q * nvox * 3;
+        float *of = out_features + (size_t)q * nvox * sample_num * c;
+        int *oi = out_idx + (size_t)q * nvox * sample_num, *sn = sampled_num + (size_t)q * nvox;
+        for (int i = 0; i < l; ++i)
+            for (int j = 0; j < h; ++j)
+                for (int k = 0; k < w; ++k) {
+                    long t = ((long)i * h * w + (long)j * w + k) * 3;
+                    pl[t] = (float)(xmin + (i + 0.5) * il);                                  /* :74-76 */
+                    pl[t + 1] = (float)(ymin + (j + 0.5) * ih);
+                    pl[t + 2] = (float)(zmin + (k + 0.5) * iw);
+                }
+        for (int p = 0; p < point_num; ++p) {
+            int xi = (int)floorf((loc[p * 3] - xmin) / il), yi = (int)floorf((loc[p * 3 + 1] - ymin) / ih),
+                zi = (int)floorf((loc[p * 3 + 2] - zmin) / iw);
+            xi = xi < 0 ? 0 : (xi > l - 1 ? l - 1 : xi);                                      /* :91-93 */
+            yi = yi < 0 ? 0 : (yi > h - 1 ? h - 1 : yi);
+            zi = zi < 0 ? 0 : (zi > w - 1 ? w - 1 : zi);
+            long v = (long)xi * h * w + (long)yi * w + zi;
+            if (sn[v] >= sample_num) continue;                                                /* :96-97 */
+            long g = v * sample_num + sn[v];
+            oi[g] = p;
+            memcpy(of + g * c, ft + (size_t)p * c, sizeof(float) * c);
+            sn[v] += 1;
+        }
+    }
+}
+
+void orc_points_pooling_grad(int bs, int proposal_num, int point_num, int c, int l, int h, int w, int sample_num,
+                             const int *out_idx, const int *sampled_num, const float *features_grad, float *pc_grad) {
+    long nvox = (long)l * h * w;
+    memset(pc_grad, 0, sizeof(float) * (size_t)bs * proposal_num * point_num * c);
+    for (long q = 0; q < (long)bs * proposal_num; ++q)
+        for (long v = 0; v < nvox; ++v)
+            for (int s = 0; s < sample_num && s < sampled_num[q * nvox + v]; ++s) {
+                long g = (q * nvox + v) * sample_num + s;
+                float *d = pc_grad + ((size_t)q * point_num + out_idx[g]) * c;
+                for (int ch = 0; ch < c; ++ch) d[ch] += features_grad[g * c + ch];
+            }
+}

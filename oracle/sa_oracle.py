@@ -269,6 +269,33 @@ def k_interpolate_grad(points, idx, weight, grad_out):
     return out
 
 
+def points_pooling(pc, box_3d, pc_loc, l=7, h=7, w=7, sample_num=35):
+    """points_pooling.py:10-21 -> tf_points_pooling_g.cu:36-118."""
+    pc, ppc = _f(pc)
+    box_3d, pb = _f(box_3d)
+    pc_loc, pl = _f(pc_loc)
+    bs, pn, pts, c = pc.shape
+    feats = np.empty((bs, pn, l, h, w, sample_num, c), np.float32)
+    idx = np.empty((bs, pn, l, h, w, sample_num), np.int32)
+    num = np.empty((bs, pn, l, h, w), np.int32)
+    pillars = np.empty((bs, pn, l, h, w, 3), np.float32)
+    lib().orc_points_pooling(bs, pn, pts, c, l, h, w, sample_num, ppc, pb, pl, feats.ctypes.data_as(_f32p),
+                             idx.ctypes.data_as(_i32p), num.ctypes.data_as(_i32p), pillars.ctypes.data_as(_f32p))
+    return feats, idx, num, pillars
+
+
+def points_pooling_grad(pc, out_idx, sampled_num_lists, features_grad):
+    """points_pooling.py:22-29 -> tf_points_pooling_g.cu:131-153."""
+    out_idx, pi = _i(out_idx)
+    sampled_num_lists, ps = _i(sampled_num_lists)
+    features_grad, pg = _f(features_grad)
+    bs, pn, pts, c = np.shape(pc)
+    _, _, l, h, w, sample_num = out_idx.shape
+    out = np.empty((bs, pn, pts, c), np.float32)
+    lib().orc_points_pooling_grad(bs, pn, pts, c, l, h, w, sample_num, pi, ps, pg, out.ctypes.data_as(_f32p))
+    return out
+
+
 # --------------------------------------------------------------------------- MLP pieces
 BN_EPS = 1e-3  # tf.contrib.layers.batch_norm default, tf_util.py:424-444
 
