@@ -772,6 +772,37 @@ struct DenseParams {
 constexpr int kDW = 4;               // waves per dense workgroup
 constexpr int kDThreads = kDW * 64;
 
+constexpr int kDStageIt = (kRows * 32 + kDThreads - 1) / kDThreads;   // KC <= 256 -> at most 32 eight-float groups per row
+
+// requests the fp32 values of chunk k0 (32 rows x KC channels, 8 per item) into registers; no wait here
+__device__ __forceinline__ void dense_stage_load(const DenseParams &P, float (&sv)[kDStageIt][8], long r0, int k0, int Kp,
+                                                 int tid) {
+    const LayerDesc &L = P.L;
+    const int kc = min(P.KC, Kp - k0);
+    const int G = kc / 8;
+#pragma unroll
+    for (int i = 0; i < kDStageIt; ++i) {
+        const int it = tid + i * kDThreads;
+        const int itc = it < kRows * G ? it : 0;
+        const int row = itc / G, g = itc - row * G;
+        long r = r0 + row;
+        if (r >= P.rows) r = P.rows - 1;
+        const int c0 = k0 + g * 8;
+        if ((L.K & 3) == 0 && c0 + 8 <= L.K) {
+            const float4 f0 = *(const float4 *)(P.x + r * L.K + c0);
+            const float4 f1 = *(const float4 *)(P.x + r * L.K + c0 + 4);
+            sv[i][0] = f0.x; sv[i][1] = f0.y; sv[i][2] = f0.z; sv[i][3] = f0.w;
+            sv[i][4] = f1.x; sv[i][5] = f1.y; sv[i][6] = f1.z; sv[i][7] = f1.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float x = P.x[r * L.K + (c0 + e < L.K ? c0 + e : L.K - 1)];
+                sv[i][e] = c0 + e < L.K ? x : 0.0f;
+            }
+        }
+    }
+}
+
 // One workgroup: 32 rows x (kDW*TG output tiles starting at tile blockIdx.y*kDW*TG).  Splitting the output
 // channels over blockIdx.y keeps >= 256 workgroups in flight for the short, wide aggregation layers
 // (2048 rows x 1536 -> 512 is only 64 row tiles).
@@ -794,34 +825,27 @@ __device__ __forceinline__ void dense_body(const DenseParams &P, unsigned char *
                 acc[tt][4 * q + 2] = bv.z; acc[tt][4 * q + 3] = bv.w;
             }
         }
+        // The fp32 rows of chunk k0 + KC are requested (into registers) before the matrix work of chunk k0 starts, so
+        // their HBM/L2 latency overlaps it; one LDS buffer is enough (it is rewritten after the closing barrier).
+        float sv[kDStageIt][8];
+        dense_stage_load(P, sv, r0, 0, Kp, tid);
         for (int k0 = 0; k0 < Kp; k0 += P.KC) {
             const int kc = min(P.KC, Kp - k0);
             const int G = kc / 8;
-            for (int it = tid; it < kRows * G; it += kDThreads) {
-                const int row = it / G, g = it - row * G;
-                long r = r0 + row;
-                if (r >= P.rows) r = P.rows - 1;
-                const int c0 = k0 + g * 8;
-                float v[8];
-                if ((L.K & 3) == 0 && c0 + 8 <= L.K) {
-                    const float4 f0 = *(const float4 *)(P.x + r * L.K + c0);
-                    const float4 f1 = *(const float4 *)(P.x + r * L.K + c0 + 4);
-                    v[0] = f0.x; v[1] = f0.y; v[2] = f0.z; v[3] = f0.w;
-                    v[4] = f1.x; v[5] = f1.y; v[6] = f1.z; v[7] = f1.w;
-                } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float x = P.x[r * L.K + (c0 + e < L.K ? c0 + e : L.K - 1)];
-                        v[e] = c0 + e < L.K ? x : 0.0f;
-                    }
+            for (int i = 0; i < kDStageIt; ++i) {
+                const int it = tid + i * kDThreads;
+                if (it < kRows * G) {
+                    const int row = it / G, g = it - row * G;
+                    uint4 hi, lo;
+                    split8(sv[i], hi, lo);
+                    unsigned char *dst = buf + row * P.stride + g * 32;
+                    *(uint4 *)dst = hi;
+                    *(uint4 *)(dst + 16) = lo;
                 }
-                uint4 hi, lo;
-                split8(v, hi, lo);
-                unsigned char *dst = buf + row * P.stride + g * 32;
-                *(uint4 *)dst = hi;
-                *(uint4 *)(dst + 16) = lo;
             }
             __syncthreads();
+            if (k0 + P.KC < Kp) dense_stage_load(P, sv, r0, k0 + P.KC, Kp, tid);
             if (gb < L.NT) {
                 // k-steps batched behind a scheduling barrier like mma_k_loop: one L2 round trip per KB k-steps
                 const unsigned char *arow = buf + col * P.stride + half * 32;
@@ -889,13 +913,12 @@ __device__ __forceinline__ void dense_body(const DenseParams &P, unsigned char *
     }
 }
 
-// TG (tiles per wave) is chosen on the host and passed in P.tg
+// TG (tiles per wave) is chosen on the host; one kernel per TG so that each gets its own register allocation
+template <int TG>
 __global__ __launch_bounds__(kDThreads) void dense_kernel(DenseParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (P.tg == 1) dense_body<1>(P, smem, lane, w, tid);
-    else if (P.tg == 2) dense_body<2>(P, smem, lane, w, tid);
-    else dense_body<4>(P, smem, lane, w, tid);
+    dense_body<TG>(P, smem, lane, w, tid);
 }
 
 // vote_layer tail (layers_util.py:21-23): out = xyz + clip(off, lo, -lo), lo = MAX_TRANSLATE_RANGE (< 0)
@@ -1044,9 +1067,12 @@ extern "C" int sa_dense(long rows, int K, int N, const float *x, const void *wpa
     // tiles per wave: as few as keeps >= ~512 workgroups in flight, at most 4
     P.tg = 4;
     while (P.tg > 1 && tiles * ((P.L.NT + kDW * P.tg - 1) / (kDW * P.tg)) < 512) P.tg >>= 1;
+    while (P.tg > 1 && kDW * P.tg / 2 >= P.L.NT) P.tg >>= 1;     // no more tile slots per workgroup than the layer has tiles
     const int ysplit = (P.L.NT + kDW * P.tg - 1) / (kDW * P.tg);
     const int gx = (int)(tiles < 8192 ? tiles : 8192);
-    hipLaunchKernelGGL(dense_kernel, dim3(gx, ysplit), dim3(kDThreads), lds, stream, P);
+    if (P.tg == 1) hipLaunchKernelGGL(dense_kernel<1>, dim3(gx, ysplit), dim3(kDThreads), lds, stream, P);
+    else if (P.tg == 2) hipLaunchKernelGGL(dense_kernel<2>, dim3(gx, ysplit), dim3(kDThreads), lds, stream, P);
+    else hipLaunchKernelGGL(dense_kernel<4>, dim3(gx, ysplit), dim3(kDThreads), lds, stream, P);
     SA_CHECK_LAUNCH();
     return SA_OK;
 }
