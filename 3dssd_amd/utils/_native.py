@@ -50,6 +50,7 @@ SIGNATURES = {
     "sa_three_interpolate_grad": [_c_int] * 4 + [_vp, _vp, _vp, _vp, _vp],
     "sa_k_interpolate_grad": [_c_int] * 5 + [_vp, _vp, _vp, _vp, _vp],
     "sa_points_pooling": [_c_int] * 8 + [_vp] * 8,
+    "sa_prob_sample": [_c_int] * 3 + [_vp] * 5,
     "sa_points_pooling_grad": [_c_int] * 8 + [_vp] * 5,
 }
 

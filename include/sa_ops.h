@@ -200,6 +200,11 @@ int sa_points_pooling_grad(int bs, int proposal_num, int point_num, int channel_
                            int sample_num, const int *out_idx, const int *sampled_num_lists, const float *features_grad,
                            float *pc_grad, sa_stream_t stream);
 
+/* probsampleLauncher(b,n,m,inp_p,inp_r,temp,out) -- tf_sampling.cpp:102: cumulative sum of inp_p [b,n] into temp [b,n]
+ * (the reference's summation order), then out [b,m] = first position with temp >= inp_r * temp[n-1]. */
+int sa_prob_sample(int b, int n, int m, const float *inp_p, const float *inp_r, float *temp, int *out,
+                   sa_stream_t stream);
+
 /* ---- host-side helper (no device work) --------------------------------------------------------------------- */
 /* CRC-32C of `len` bytes continuing from `crc` (0 to start): the checksum of TensorFlow tensor-bundle checkpoints
  * (tensorflow/core/lib/hash/crc32c.h), used by 3dssd_amd/utils/tf_checkpoint.py when importing the reference's

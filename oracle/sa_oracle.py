@@ -296,6 +296,18 @@ def points_pooling_grad(pc, out_idx, sampled_num_lists, features_grad):
     return out
 
 
+def prob_sample(inp, inpr, return_cumsum=False):
+    """tf_sampling.py:8-17 -> tf_sampling_g.cu:24-121."""
+    inp, pi = _f(inp)
+    inpr, pr = _f(inpr)
+    b, n = inp.shape
+    m = inpr.shape[1]
+    temp = np.empty((b, n), np.float32)
+    out = np.empty((b, m), np.int32)
+    lib().orc_prob_sample(b, n, m, pi, pr, temp.ctypes.data_as(_f32p), out.ctypes.data_as(_i32p))
+    return (out, temp) if return_cumsum else out
+
+
 # --------------------------------------------------------------------------- MLP pieces
 BN_EPS = 1e-3  # tf.contrib.layers.batch_norm default, tf_util.py:424-444
 
