@@ -51,6 +51,8 @@ SIGNATURES = {
     "sa_k_interpolate_grad": [_c_int] * 5 + [_vp, _vp, _vp, _vp, _vp],
     "sa_points_pooling": [_c_int] * 8 + [_vp] * 8,
     "sa_prob_sample": [_c_int] * 3 + [_vp] * 5,
+    "sa_calc_iou": [_c_int] * 3 + [_vp] * 5,
+    "sa_calc_iou_match": [_c_int] + [_vp] * 5,
     "sa_points_pooling_grad": [_c_int] * 8 + [_vp] * 5,
 }
 

@@ -205,6 +205,14 @@ int sa_points_pooling_grad(int bs, int proposal_num, int point_num, int channel_
 int sa_prob_sample(int b, int n, int m, const float *inp_p, const float *inp_r, float *temp, int *out,
                    sa_stream_t stream);
 
+/* ---- lib/utils/tf_ops/evaluation: rotated-box IoU (a CPU op on boost::geometry in the reference) -------------------- */
+/* calc_intersections_cpu(dets,gts,det_num,gt_num,num_images,IoU3D,IoUBeV) -- tf_evaluate.cpp:142.  dets [bs,det_num,7],
+ * gts [bs,gt_num,7] = (x, bottom y, z, l, h, w, ry) -> iou_bev, iou_3d [bs,det_num,gt_num] (agreement to rounding). */
+int sa_calc_iou(int bs, int det_num, int gt_num, const float *dets, const float *gts, float *iou_bev, float *iou_3d,
+                sa_stream_t stream);
+/* calc_intersections_matching_cpu(dets,gts,bs,IoU3D,IoUBeV) -- tf_evaluate.cpp:182: row i against row i, [n] outputs. */
+int sa_calc_iou_match(int n, const float *dets, const float *gts, float *iou_bev, float *iou_3d, sa_stream_t stream);
+
 /* ---- host-side helper (no device work) --------------------------------------------------------------------- */
 /* CRC-32C of `len` bytes continuing from `crc` (0 to start): the checksum of TensorFlow tensor-bundle checkpoints
  * (tensorflow/core/lib/hash/crc32c.h), used by 3dssd_amd/utils/tf_checkpoint.py when importing the reference's

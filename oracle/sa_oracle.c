@@ -701,3 +701,89 @@ void orc_prob_sample(int b, int n, int m, const float *inp_p, const float *inp_r
         }
     }
 }
+
+/* ==== calc_iou / calc_iou_match: lib/utils/tf_ops/evaluation/evaluate.cpp:461-537,1161-1227 ====================== */
+/* The reference intersects boost::geometry polygons (not available here).  This restatement builds the
+ * intersection polygon a different way than the HIP kernel (which clips edge by edge): the vertices of each rectangle
+ * that lie inside the other plus all edge-edge crossing points, ordered by angle around their centroid, shoelace. */
+typedef struct { double x, y; } orc_p2;
+
+static void iou_corners(const float *q, orc_p2 *c) {                  /* toPolygon, :461-485 */
+    double t1 = q[0], t3 = q[2], l = q[3], w = q[5], ry = q[6];
+    double cs = cos(ry), sn = sin(ry);
+    double dx[4] = {l / 2, l / 2, -l / 2, -l / 2}, dy[4] = {w / 2, -w / 2, -w / 2, w / 2};
+    for (int i = 0; i < 4; ++i) { c[i].x = cs * dx[i] + sn * dy[i] + t1; c[i].y = -sn * dx[i] + cs * dy[i] + t3; }
+}
+
+static double iou_shoelace(const orc_p2 *p, int n) {
+    double a = 0.0;
+    for (int i = 0; i < n; ++i) { int j = (i + 1) % n; a += p[i].x * p[j].y - p[j].x * p[i].y; }
+    return fabs(a) * 0.5;
+}
+
+static int iou_inside(const orc_p2 *r, orc_p2 q) {                    /* q inside (or on) the convex quad r */
+    int pos = 0, neg = 0;
+    for (int i = 0; i < 4; ++i) {
+        orc_p2 a = r[i], b = r[(i + 1) % 4];
+        double cr = (b.x - a.x) * (q.y - a.y) - (b.y - a.y) * (q.x - a.x);
+        if (cr > 1e-12) pos = 1;
+        if (cr < -1e-12) neg = 1;
+    }
+    if (!pos && !neg) return 0;                                        /* a quad without area contains nothing */
+    return !(pos && neg);
+}
+
+static double iou_inter_area(const orc_p2 *A, const orc_p2 *B) {
+    orc_p2 pts[24];
+    int n = 0;
+    for (int i = 0; i < 4; ++i) if (iou_inside(B, A[i])) pts[n++] = A[i];
+    for (int i = 0; i < 4; ++i) if (iou_inside(A, B[i])) pts[n++] = B[i];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            orc_p2 p = A[i], r = {A[(i + 1) % 4].x - A[i].x, A[(i + 1) % 4].y - A[i].y};
+            orc_p2 q = B[j], s = {B[(j + 1) % 4].x - B[j].x, B[(j + 1) % 4].y - B[j].y};
+            double den = r.x * s.y - r.y * s.x;
+            if (fabs(den) < 1e-14) continue;                           /* parallel */
+            double t = ((q.x - p.x) * s.y - (q.y - p.y) * s.x) / den;
+            double u = ((q.x - p.x) * r.y - (q.y - p.y) * r.x) / den;
+            if (t >= 0.0 && t <= 1.0 && u >= 0.0 && u <= 1.0) { pts[n].x = p.x + t * r.x; pts[n].y = p.y + t * r.y; ++n; }
+        }
+    if (n < 3) return 0.0;
+    double cx = 0, cy = 0;
+    for (int i = 0; i < n; ++i) { cx += pts[i].x; cy += pts[i].y; }
+    cx /= n; cy /= n;
+    for (int i = 1; i < n; ++i) {                                      /* insertion sort by angle */
+        orc_p2 v = pts[i];
+        double av = atan2(v.y - cy, v.x - cx);
+        int j = i - 1;
+        while (j >= 0 && atan2(pts[j].y - cy, pts[j].x - cx) > av) { pts[j + 1] = pts[j]; --j; }
+        pts[j + 1] = v;
+    }
+    return iou_shoelace(pts, n);
+}
+
+static void iou_pair(const float *d, const float *g, float *bev, float *i3d) {
+    orc_p2 dc[4], gc[4];
+    iou_corners(d, dc);
+    iou_corners(g, gc);
+    double inter = iou_inter_area(gc, dc), ad = iou_shoelace(dc, 4), ag = iou_shoelace(gc, 4);
+    double uni = ad + ag - inter;                                       /* :497-501 */
+    *bev = uni > 0.0 ? (float)(inter / uni) : 0.0f;
+    double ymax = fmin((double)d[1], (double)g[1]);                     /* :518-519 */
+    double ymin = fmax((double)d[1] - (double)d[4], (double)g[1] - (double)g[4]);
+    double ivol = inter * fmax(0.0, ymax - ymin);
+    double dvol = (double)d[4] * d[3] * d[5], gvol = (double)g[4] * g[3] * g[5];
+    double uvol = dvol + gvol - ivol;
+    *i3d = uvol > 0.0 ? (float)(ivol / uvol) : 0.0f;                    /* :527-528 */
+}
+
+void orc_calc_iou(int bs, int det_num, int gt_num, const float *dets, const float *gts, float *iou_bev, float *iou_3d) {
+    for (long e = 0; e < (long)bs * det_num * gt_num; ++e) {
+        long img = e / ((long)det_num * gt_num), r = e % ((long)det_num * gt_num);
+        iou_pair(dets + (img * det_num + r / gt_num) * 7, gts + (img * gt_num + r % gt_num) * 7, iou_bev + e, iou_3d + e);
+    }
+}
+
+void orc_calc_iou_match(int n, const float *dets, const float *gts, float *iou_bev, float *iou_3d) {
+    for (long e = 0; e < n; ++e) iou_pair(dets + e * 7, gts + e * 7, iou_bev + e, iou_3d + e);
+}

@@ -308,6 +308,29 @@ def prob_sample(inp, inpr, return_cumsum=False):
     return (out, temp) if return_cumsum else out
 
 
+def calc_iou(detections, groundtruths):
+    """tf_evaluate.py:26-33 -> evaluate.cpp:1161-1194.  -> (iou_bev, iou_3d) [bs, det_num, gt_num]."""
+    detections, pd = _f(detections)
+    groundtruths, pg = _f(groundtruths)
+    bs, dn, _ = detections.shape
+    gn = groundtruths.shape[1]
+    bev = np.empty((bs, dn, gn), np.float32)
+    i3d = np.empty((bs, dn, gn), np.float32)
+    lib().orc_calc_iou(bs, dn, gn, pd, pg, bev.ctypes.data_as(_f32p), i3d.ctypes.data_as(_f32p))
+    return bev, i3d
+
+
+def calc_iou_match(detections, groundtruths):
+    """tf_evaluate.py:35-42 -> evaluate.cpp:1196-1227."""
+    detections, pd = _f(detections)
+    groundtruths, pg = _f(groundtruths)
+    n = detections.shape[0]
+    bev = np.empty((n,), np.float32)
+    i3d = np.empty((n,), np.float32)
+    lib().orc_calc_iou_match(n, pd, pg, bev.ctypes.data_as(_f32p), i3d.ctypes.data_as(_f32p))
+    return bev, i3d
+
+
 # --------------------------------------------------------------------------- MLP pieces
 BN_EPS = 1e-3  # tf.contrib.layers.batch_norm default, tf_util.py:424-444
 
