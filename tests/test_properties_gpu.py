@@ -12,7 +12,8 @@ implementation of the reference operators and that a wrong kernel would almost s
   * distance matrix: bitwise symmetric;
   * fused grouped MLP: invariant (bit for bit) under any permutation of the samples inside a ball;
   * backbone: batched == frame by frame, bit for bit (no cross-frame coupling, SURVEY.md 8e);
-  * determinism: two runs of the backbone give identical bits.
+  * determinism: two runs of the backbone give identical bits;
+  * execution mode of bench.py: hipGraph replays on four concurrent streams reproduce the eager result bit for bit.
 """
 import numpy as np
 import pytest
@@ -197,3 +198,33 @@ def test_backbone_batched_equals_per_frame_and_is_deterministic(gpu, frames):
             assert torch.equal(f1[li][0], fl[li][f]), "features of list index %d differ for frame %d" % (li, f)
             if il[li] is not None:
                 assert torch.equal(i1[li][0], il[li][f])
+
+
+def test_graph_replay_on_concurrent_streams_equals_eager(gpu, frames):
+    """bench.py's execution mode: one captured hipGraph per stream, replays of several streams in flight at once.  Every
+    replay must reproduce the eager single-stream result bit for bit (no shared scratch between streams, workspace
+    counters reset inside the graph)."""
+    cfgs, syn = pkg("configs"), pkg("synthetic")
+    arch = cfgs.KITTI_3DSSD_ARCH
+    net = pkg("backbone").SABackbone(arch, syn.random_backbone_params(arch), gpu, cfgs.KITTI_MAX_TRANSLATE_RANGE)
+    xl, fl, _ = net(frames)
+    torch.cuda.synchronize()
+    ref_xyz, ref_feat = xl[-1].clone(), fl[-1].clone()
+    streams = [torch.cuda.Stream(device=gpu) for _ in range(4)]
+    graphs = []
+    for st in streams:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            gx, gf, _ = net(frames)
+        graphs.append((g, gx[-1], gf[-1]))
+    torch.cuda.synchronize()
+    for rnd in range(3):
+        for (g, ox, of), st in zip(graphs, streams):
+            of.fill_(-1.0)                                   # on the default stream, before the replays of this round
+        torch.cuda.synchronize()
+        for (g, _, _), st in zip(graphs, streams):
+            with torch.cuda.stream(st):
+                g.replay()
+        torch.cuda.synchronize()
+        for g, ox, of in graphs:
+            assert torch.equal(ox, ref_xyz) and torch.equal(of, ref_feat), "round %d" % rnd
