@@ -93,5 +93,17 @@ f64 = torch.from_numpy(syn.kitti_like_batch(16, n=65536)).to(dev)
 ms = timeit(lambda: net(f64), iters=5, warm=2)
 out.append(dict(op="SA backbone (configs[4])", case="16 x 65536-pt frames, one stream, eager", ms=round(ms, 2),
                 frames_per_s=round(16 / ms * 1e3, 1)))
+# points -> boxes: backbone + Det head + decode + per-class BEV NMS, batch 8, one stream, eager;
+# the reference's README quotes "more than 25 FPS" for the whole detector (one frame at a time, other hardware)
+M_ = importlib.import_module("3dssd_amd.modeling.single_stage_detector")
+params = syn.random_backbone_params(cfgs.KITTI_3DSSD_ARCH)
+syn.random_head_params(512, 1, cfgs.KITTI_ANGLE_CLS_NUM, params=params)
+det = M_.SingleStageDetector(cfgs.KITTI_3DSSD_ARCH, cfgs.KITTI_3DSSD_HEAD, params, dev, cls_num=1, angle_cls_num=cfgs.KITTI_ANGLE_CLS_NUM,
+                             max_output_size=cfgs.KITTI_MAX_OUTPUT_NUM, nms_threshold=cfgs.KITTI_NMS_THRESH)
+for nb in (8, 1):
+    fr = torch.from_numpy(syn.kitti_like_batch(nb)).to(dev)
+    ms = timeit(lambda: det(fr), iters=10, warm=3)
+    out.append(dict(op="detector points -> boxes", case="%d x 16384-pt frames, one stream, eager" % nb, ms=round(ms, 3),
+                    frames_per_s=round(nb / ms * 1e3, 1)))
 for o in out:
     print(json.dumps(o))
