@@ -317,8 +317,52 @@ def case_mlp_big(rng):
 
 BIG = [case_fps_big, case_ball_multi, case_sqdist_big, case_mlp_big]
 
+def case_pooling(rng):
+    P = pkg("utils.tf_ops.points_pooling.points_pooling")
+    bs, pn, pts, c = int(rng.integers(1, 3)), int(rng.integers(1, 20)), int(rng.choice([1, 63, 64, 65, 300])), int(rng.choice([1, 3, 16]))
+    l, h, w, sn = int(rng.integers(1, 9)), int(rng.integers(1, 9)), int(rng.integers(1, 9)), int(rng.choice([1, 2, 8, 35]))
+    box = np.concatenate([rng.normal(0, 3, (bs, pn, 3)), rng.uniform(0.5, 5, (bs, pn, 3))], -1).astype(np.float32)
+    if rng.integers(0, 2):
+        box = np.round(box * 2) / 2 + np.float32(0.5) * (box[..., :1] * 0 + np.array([0, 0, 0, 1, 1, 1], np.float32))
+        box = box.astype(np.float32)
+    ctr = box[..., :3].copy()
+    ctr[..., 1] -= box[..., 4] / 2
+    loc = (ctr[:, :, None, :] + rng.uniform(-0.7, 0.7, (bs, pn, pts, 3)) * box[:, :, None, 3:6]).astype(np.float32)
+    if rng.integers(0, 2):
+        loc = (np.round(loc * 4) / 4).astype(np.float32)
+    pc = rng.normal(0, 1, (bs, pn, pts, c)).astype(np.float32)
+    got = P.points_pooling(t(pc), t(box), t(loc), l=l, h=h, w=w, sample_num=sn)
+    ref = O.points_pooling(pc, box, loc, l=l, h=h, w=w, sample_num=sn)
+    for nm, a, b in zip(("features", "idx", "num", "pillars"), got, ref):
+        e = eq("points_pooling " + nm, a, b, (bs, pn, pts, c, l, h, w, sn))
+        if e:
+            return e
+    return None
+
+
+def case_prob_iou(rng):
+    E = pkg("utils.tf_ops.evaluation.tf_evaluate")
+    b, n, m = int(rng.integers(1, 3)), int(rng.choice([1, 4, 5, 1000, 8191, 8192, 8193, 20000])), int(rng.integers(1, 400))
+    w = rng.uniform(0, 1, (b, n)).astype(np.float32) * (rng.uniform(0, 1, (b, n)) < 0.8)
+    w = w.astype(np.float32)
+    w[:, -1] += np.float32(0.1)                               # a positive total
+    r = rng.uniform(0, 1, (b, m)).astype(np.float32)
+    e = eq("prob_sample", S.prob_sample(t(w), t(r)), O.prob_sample(w, r), (b, n, m))
+    if e:
+        return e
+    k = int(rng.integers(1, 200))
+    gt = np.concatenate([rng.normal(0, 4, (k, 3)), rng.uniform(0.3, 5, (k, 3)), rng.uniform(-4, 4, (k, 1))], -1).astype(np.float32)
+    det = (gt + rng.normal(0, 0.4, (k, 7)) * (rng.uniform(0, 1, (k, 1)) < 0.8)).astype(np.float32)
+    det[:, 3:6] = np.abs(det[:, 3:6])
+    b1, t1 = E.calc_iou_match(t(det), t(gt))
+    rb, rt = O.calc_iou_match(det, gt)
+    if np.abs(b1.cpu().numpy() - rb).max() > 5e-6 or np.abs(t1.cpu().numpy() - rt).max() > 5e-6:
+        return "calc_iou_match differs by %.3g / %.3g (k = %d)" % (np.abs(b1.cpu().numpy() - rb).max(), np.abs(t1.cpu().numpy() - rt).max(), k)
+    return None
+
+
 CASES = [case_fps, case_fps, case_fps_dist, case_fps_preidx, case_gather, case_ball, case_ball, case_sqdist, case_mlp, case_mlp,
-         case_mlp, case_interp, case_boxes, case_misc]
+         case_mlp, case_interp, case_boxes, case_misc, case_pooling, case_prob_iou]
 
 
 def main():
