@@ -234,6 +234,97 @@ __device__ unsigned long long g_sq_prof[8];
 constexpr int kKS2 = 36;            // channels per stage (two stages for the 67-channel layer-2 call; LDS 41 KB -> 3 workgroups per CU)
 constexpr int kPL = 20;             // floats per row in a parity plane (18 pairs + 2 padding; 80 B rows)
 
+// Epilogue shared by the two second-form kernels: out = (|a|^2 + |b|^2) - 2 a.b for the wave's 64 x 64 part of the
+// tile, the direct tile and (off the diagonal of a symmetric call) its mirror image.
+template <bool SYM, bool NT>
+__device__ __forceinline__ void sq_store_tile(float *lds, const float *sA, const float *sB, f32x16 (&acc)[2][2], int b, int n,
+                                              int m, int i0, int j0, bool mirror, int w, int lane, float *__restrict__ out) {
+    const int wr = w >> 1, wc = w & 1;
+    const int half = lane >> 5, col = lane & 31;
+    // Stores go through a per-wave LDS patch so that every lane writes 16 bytes: a (ti) strip of the wave's tile is
+    // 32 rows x 64 columns; row-major in the patch it leaves as 4 rows x 256 B per store instruction, transposed
+    // (64 patch rows x 32 columns) as 8 rows x 128 B for the mirrored tile.  (Straight from the accumulator layout
+    // the stores are dword stores of 2 rows x 128 B.)  Edge tiles (n not a multiple of 128) take the scalar path.
+    float *patch = lds + w * (32 * 68);                            // 32 x 68 floats, also viewed 64 x 34
+    const bool full = i0 + kMT <= n && j0 + kMT <= m && (m & 3) == 0 && (!SYM || (n & 3) == 0);
+    float *tile = out + ((size_t)b * n + i0) * m + j0;                           // (i0, j0) of this frame
+    float *tileT = SYM ? out + ((size_t)b * n + j0) * n + i0 : nullptr;          // (j0, i0): the mirrored tile
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        float sa[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *(const float4 *)(sA + wr * 64 + ti * 32 + 8 * q + 4 * half);
+            sa[4 * q + 0] = v.x; sa[4 * q + 1] = v.y; sa[4 * q + 2] = v.z; sa[4 * q + 3] = v.w;
+        }
+        float vv[2][16];
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            const float sb = sB[wc * 64 + tj * 32 + col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) vv[tj][r] = (sa[r] + sb) - 2.0f * acc[ti][tj][r];
+        }
+        if (full) {
+            // ---- direct tile: patch[ir][tj*32 + col], read back as float4 rows
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * half) * 68 + tj * 32 + col] = vv[tj][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int pr = it * 4 + (lane >> 4), pc = (lane & 15) * 4;       // 4 rows x 16 lanes x 16 B
+                const float4 q4 = *(const float4 *)(patch + pr * 68 + pc);
+                f32x4v *dst = (f32x4v *)(tile + (unsigned)((wr * 64 + ti * 32 + pr) * m + wc * 64 + pc));
+                const f32x4v qv = {q4.x, q4.y, q4.z, q4.w};
+                if (NT) __builtin_nontemporal_store(qv, dst); else *dst = qv;
+            }
+            if (mirror) {
+                // ---- mirrored tile: patch viewed as [64 columns j][34]: patchT[tj*32 + col][ir]
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) patch[(tj * 32 + col) * 34 + (r & 3) + 8 * (r >> 2) + 4 * half] = vv[tj][r];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int pj = it * 8 + (lane >> 3), pi = (lane & 7) * 4;    // 8 rows x 8 lanes x 16 B
+                    const float *src = patch + pj * 34 + pi;                     // 8-byte aligned rows: two float2 reads
+                    const float2 lo2 = *(const float2 *)src, hi2 = *(const float2 *)(src + 2);
+                    const float4 q4 = make_float4(lo2.x, lo2.y, hi2.x, hi2.y);
+                    f32x4v *dst = (f32x4v *)(tileT + (unsigned)((wc * 64 + pj) * n + wr * 64 + ti * 32 + pi));
+                    const f32x4v qv = {q4.x, q4.y, q4.z, q4.w};
+                    if (NT) __builtin_nontemporal_store(qv, dst); else *dst = qv;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        } else {
+            float (*sT)[34] = (float (*)[34])patch;
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) {
+                const int jl = wc * 64 + tj * 32 + col;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ir = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int il = wr * 64 + ti * 32 + ir;
+                    if (i0 + il < n && j0 + jl < m) tile[(unsigned)(il * m + jl)] = vv[tj][r];
+                    if (SYM) sT[tj * 32 + col][ir] = vv[tj][r];
+                }
+            }
+            if (mirror) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int r2 = 0; r2 < 32; ++r2) {
+                    const int r = r2 * 2 + half;
+                    const int jl = wc * 64 + r, il = wr * 64 + ti * 32 + col;
+                    if (j0 + jl < n && i0 + il < n) tileT[(unsigned)(jl * n + il)] = sT[r][col];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        }
+    }
+}
+
 // NT: non-temporal stores -- a matrix far larger than L2 + Infinity Cache (537 MB at the layer-2 shape, of which
 // F-FPS later reads one row in eight) should not displace everything else (-5 %); the 8 MB layer-3 matrix is
 // written normally so that the FPS kernel finds its rows on chip (non-temporal there: F-FPS +30 %).
@@ -371,91 +462,163 @@ __global__ __launch_bounds__(256, 4) void sqdist_mfma2_kernel(int n, int m, RowS
     if (tid < kMT) sA[tid] = nrm; else sB[tid - kMT] = nrm;
     __syncthreads();
 
-    // Stores go through a per-wave LDS patch so that every lane writes 16 bytes: a (ti) strip of the wave's tile is
-    // 32 rows x 64 columns; row-major in the patch it leaves as 4 rows x 256 B per store instruction, transposed
-    // (64 patch rows x 32 columns) as 8 rows x 128 B for the mirrored tile.  (Straight from the accumulator layout
-    // the stores are dword stores of 2 rows x 128 B.)  Edge tiles (n not a multiple of 128) take the scalar path.
-    float *patch = &s_pl[0][0][0][0] + w * (32 * 68);                            // 32 x 68 floats, also viewed 64 x 34
-    const bool mirror = SYM && bi != bj;
-    const bool full = i0 + kMT <= n && j0 + kMT <= m && (m & 3) == 0 && (!SYM || (n & 3) == 0);
-    float *tile = out + ((size_t)b * n + i0) * m + j0;                           // (i0, j0) of this frame
-    float *tileT = SYM ? out + ((size_t)b * n + j0) * n + i0 : nullptr;          // (j0, i0): the mirrored tile
+    sq_store_tile<SYM, NT>(&s_pl[0][0][0][0], sA, sB, acc, b, n, m, i0, j0, SYM && bi != bj, w, lane, out);
+    SQ_TICK(4)
+    SQ_FLUSH()
+}
+
+// ---- third form: operands packed once per call, tiles staged by plain 16-byte copies -------------------------
+// The second form spends ~1 000 of its ~2 000 non-MFMA instructions per wave and tile on staging: every tile turns the
+// same rows of [xyz | features] into parity planes again (index arithmetic, a parity select and a range check per
+// element), 32 times per row band.  Here a pre-pass writes the operand ONCE in exactly the LDS image the k loop reads
+//     pack[frame][stage][row tile][parity][128][kPL]            (20 KiB per (stage, row tile); zeros for padding)
+// together with the row norms (same ascending fmaf chain), and the matrix kernel stages a tile with five float4 loads
+// and five ds_write_b128 per thread and operand, the loads of stage s+1 in flight during the matrix work of stage s.
+// Same MFMA instruction, k order, norm chains and final expression as the other forms: bit-identical output.
+constexpr int kPackTile = 2 * kMT * kPL;       // floats per (stage, row tile)
+
+// One 256-thread workgroup per row tile.  The tile's rows are first copied into LDS with lanes running over the
+// channels of one row (coalesced; a thread-per-row read touches 64 cache lines per instruction and re-fetches each
+// line ~70 times: 15 us measured), then every thread owns one row: per stage its 36 channels go through the norm chain
+// in channel order and out as the two 80-byte plane rows.
+__global__ __launch_bounds__(2 * kMT) void sqdist_pack_kernel(int n, int np, int S, int ldc, RowSrc A,
+                                                             float *__restrict__ pack, float *__restrict__ norms) {
+    extern __shared__ float s_rows[];             // [kMT][ldc], ldc odd: a thread's row reads are conflict-free
+    const int b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
+    const int T = np / kMT, c = A.c0 + A.c1;
+    const int lo = tid & (kMT - 1), hi = tid >> 7;        // hi: which half of the rows (copy) / which stages (pack)
+    for (int ch = lo; ch < c; ch += kMT) {
+        // both pieces are read unconditionally (clamped addresses) and selected: no branch between the loads; 32 rows
+        // are requested before the first LDS store (a rolled load -> store loop pays one round trip per row: 61 us)
+        const int k0 = ch < A.c0 ? ch : A.c0 - 1;
+        const int k1 = A.c1 > 0 ? min(max(ch - A.c0, 0), A.c1 - 1) : 0;
+        const bool first = ch < A.c0;
+        for (int r0 = hi * (kMT / 2); r0 < (hi + 1) * (kMT / 2); r0 += 32) {
+            float x[32];
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti) {
-        float sa[16];
+            for (int u = 0; u < 32; ++u) {
+                const int row = t * kMT + r0 + u;
+                const long grow = (long)b * n + (row < n ? row : n - 1);
+                const float x0 = A.p0[grow * A.c0 + k0];
+                const float x1 = A.c1 > 0 ? A.p1[grow * A.c1 + k1] : 0.0f;
+                x[u] = row < n ? (first ? x0 : x1) : 0.0f;
+            }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 v = *(const float4 *)(sA + wr * 64 + ti * 32 + 8 * q + 4 * half);
-            sa[4 * q + 0] = v.x; sa[4 * q + 1] = v.y; sa[4 * q + 2] = v.z; sa[4 * q + 3] = v.w;
+            for (int u = 0; u < 32; ++u) s_rows[(r0 + u) * ldc + ch] = x[u];
         }
-        float vv[2][16];
+    }
+    __syncthreads();
+    const float *mine = s_rows + lo * ldc;
+    if (hi == 0) {                                        // the row's norm: one ascending fmaf chain over all channels
+        float nrm = 0.0f;
+        for (int k = 0; k < c; ++k) nrm = __builtin_fmaf(mine[k], mine[k], nrm);
+        norms[(size_t)b * np + t * kMT + lo] = nrm;
+    }
+    for (int st = hi; st < S; st += 2) {
+        float v[kKS2];
 #pragma unroll
-        for (int tj = 0; tj < 2; ++tj) {
-            const float sb = sB[wc * 64 + tj * 32 + col];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) vv[tj][r] = (sa[r] + sb) - 2.0f * acc[ti][tj][r];
+        for (int i = 0; i < kKS2; ++i) {
+            const int k = st * kKS2 + i;
+            const float x = mine[k < c ? k : 0];
+            v[i] = k < c ? x : 0.0f;
         }
-        if (full) {
-            // ---- direct tile: patch[ir][tj*32 + col], read back as float4 rows
+        float *dst = pack + ((((size_t)b * S + st) * T + t) * 2) * (kMT * kPL) + (size_t)lo * kPL;
 #pragma unroll
-            for (int tj = 0; tj < 2; ++tj)
+        for (int par = 0; par < 2; ++par) {
+            f32x4v *d4 = (f32x4v *)(dst + (size_t)par * kMT * kPL);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * half) * 68 + tj * 32 + col] = vv[tj][r];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (int q = 0; q < kPL / 4; ++q) {
+                f32x4v o;
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int pr = it * 4 + (lane >> 4), pc = (lane & 15) * 4;       // 4 rows x 16 lanes x 16 B
-                const float4 q4 = *(const float4 *)(patch + pr * 68 + pc);
-                f32x4v *dst = (f32x4v *)(tile + (unsigned)((wr * 64 + ti * 32 + pr) * m + wc * 64 + pc));
-                const f32x4v qv = {q4.x, q4.y, q4.z, q4.w};
-                if (NT) __builtin_nontemporal_store(qv, dst); else *dst = qv;
-            }
-            if (mirror) {
-                // ---- mirrored tile: patch viewed as [64 columns j][34]: patchT[tj*32 + col][ir]
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) patch[(tj * 32 + col) * 34 + (r & 3) + 8 * (r >> 2) + 4 * half] = vv[tj][r];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const int pj = it * 8 + (lane >> 3), pi = (lane & 7) * 4;    // 8 rows x 8 lanes x 16 B
-                    const float *src = patch + pj * 34 + pi;                     // 8-byte aligned rows: two float2 reads
-                    const float2 lo2 = *(const float2 *)src, hi2 = *(const float2 *)(src + 2);
-                    const float4 q4 = make_float4(lo2.x, lo2.y, hi2.x, hi2.y);
-                    f32x4v *dst = (f32x4v *)(tileT + (unsigned)((wc * 64 + pj) * n + wr * 64 + ti * 32 + pi));
-                    const f32x4v qv = {q4.x, q4.y, q4.z, q4.w};
-                    if (NT) __builtin_nontemporal_store(qv, dst); else *dst = qv;
+                for (int e = 0; e < 4; ++e) {
+                    const int j = 4 * q + e;
+                    o[e] = j < kKS2 / 2 ? v[2 * j + par] : 0.0f;
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-        } else {
-            float (*sT)[34] = (float (*)[34])patch;
-#pragma unroll
-            for (int tj = 0; tj < 2; ++tj) {
-                const int jl = wc * 64 + tj * 32 + col;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ir = (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const int il = wr * 64 + ti * 32 + ir;
-                    if (i0 + il < n && j0 + jl < m) tile[(unsigned)(il * m + jl)] = vv[tj][r];
-                    if (SYM) sT[tj * 32 + col][ir] = vv[tj][r];
-                }
-            }
-            if (mirror) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                for (int r2 = 0; r2 < 32; ++r2) {
-                    const int r = r2 * 2 + half;
-                    const int jl = wc * 64 + r, il = wr * 64 + ti * 32 + col;
-                    if (j0 + jl < n && i0 + il < n) tileT[(unsigned)(jl * n + il)] = sT[r][col];
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                d4[q] = o;
             }
         }
     }
-    SQ_TICK(4)
-    SQ_FLUSH()
+}
+
+template <bool SYM, bool NT>
+__global__ __launch_bounds__(256, 4) void sqdist_mfma3_kernel(int n, int m, int c, int npa, int npb,
+                                                             const float *__restrict__ packA,
+                                                             const float *__restrict__ packB,
+                                                             const float *__restrict__ normA,
+                                                             const float *__restrict__ normB, float *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float s_pl[2][2][kMT][kPL];
+    static_assert(4 * 32 * 68 + 2 * kMT <= 2 * 2 * kMT * kPL, "patches + norms must fit the operand planes");
+    float *sA = &s_pl[0][0][0][0] + 4 * 32 * 68, *sB = sA + kMT;
+    const int b = blockIdx.z;
+    int bi = blockIdx.y, bj = blockIdx.x;
+    if (SYM) {                                    // linear id over the upper triangle (row-major)
+        const int T = (n + kMT - 1) / kMT;
+        int rem = blockIdx.x;
+        bi = 0;
+        while (rem >= T - bi) { rem -= T - bi; ++bi; }
+        bj = bi + rem;
+    }
+    const int i0 = bi * kMT, j0 = bj * kMT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 1, wc = w & 1;
+    const int half = lane >> 5, col = lane & 31;
+    const int S = (c + kKS2 - 1) / kKS2, Ta = npa / kMT, Tb = npb / kMT;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.0f;
+    const float nrm = tid < kMT ? normA[(size_t)b * npa + i0 + tid] : normB[(size_t)b * npb + j0 + tid - kMT];
+
+    // (stage, tile) images of the two operands: kPackTile floats = 1280 float4 each, 5 per thread
+    constexpr int kCp = kPackTile / 4 / 256;
+    static_assert(kCp * 4 * 256 == kPackTile, "tile image must split evenly over the workgroup");
+    const f32x4v *srcA = (const f32x4v *)(packA + (((size_t)b * S) * Ta + bi) * kPackTile) + tid;
+    const f32x4v *srcB = (const f32x4v *)(packB + (((size_t)b * S) * Tb + bj) * kPackTile) + tid;
+    f32x4v ra[kCp], rb[kCp];
+#pragma unroll
+    for (int i = 0; i < kCp; ++i) { ra[i] = srcA[i * 256]; rb[i] = srcB[i * 256]; }
+    f32x4v *dA = (f32x4v *)&s_pl[0][0][0][0] + tid, *dB = (f32x4v *)&s_pl[1][0][0][0] + tid;
+
+    for (int st = 0; st < S; ++st) {
+        const int cnt = min(kKS2, c - st * kKS2);
+        const int npairs = (cnt + 1) >> 1;
+        if (st > 0) __syncthreads();                       // the previous stage is fully consumed
+#pragma unroll
+        for (int i = 0; i < kCp; ++i) { dA[i * 256] = ra[i]; dB[i * 256] = rb[i]; }
+        __syncthreads();
+        if (st + 1 < S) {                                  // next stage's images: in flight during the matrix work
+            const f32x4v *nA = srcA + (size_t)(st + 1) * Ta * (kPackTile / 4), *nB = srcB + (size_t)(st + 1) * Tb * (kPackTile / 4);
+#pragma unroll
+            for (int i = 0; i < kCp; ++i) { ra[i] = nA[i * 256]; rb[i] = nB[i * 256]; }
+        }
+        const float *pa0 = s_pl[0][half][wr * 64 + col], *pa1 = s_pl[0][half][wr * 64 + 32 + col];
+        const float *pb0 = s_pl[1][half][wc * 64 + col], *pb1 = s_pl[1][half][wc * 64 + 32 + col];
+        for (int p4 = 0; p4 < npairs; p4 += 4) {
+            const float4 a0 = *(const float4 *)(pa0 + p4), a1 = *(const float4 *)(pa1 + p4);
+            const float4 b0 = *(const float4 *)(pb0 + p4), b1 = *(const float4 *)(pb1 + p4);
+            const float av[2][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}};
+            const float bv[2][4] = {{b0.x, b0.y, b0.z, b0.w}, {b1.x, b1.y, b1.z, b1.w}};
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                if (p4 + x < npairs) {
+#pragma unroll
+                    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                        for (int tj = 0; tj < 2; ++tj)
+                            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ti][x], bv[tj][x], acc[ti][tj], 0, 0, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();                               // operand planes dead -> norms and transpose patches
+    if (tid < kMT) sA[tid] = nrm; else sB[tid - kMT] = nrm;
+    __syncthreads();
+    sq_store_tile<SYM, NT>(&s_pl[0][0][0][0], sA, sB, acc, b, n, m, i0, j0, SYM && bi != bj, w, lane, out);
 }
 
 #ifdef SA_SQ_TIMING
@@ -503,6 +666,63 @@ extern "C" int sa_calc_square_dist_split(int b, int n, int m, int c0, int c1, co
             else if (v2) hipLaunchKernelGGL((sqdist_mfma2_kernel<false, false>), grid, dim3(256), 0, stream, n, m, A, Bm, out);
             else hipLaunchKernelGGL(sqdist_mfma_kernel<false>, grid, dim3(256), 0, stream, n, m, A, Bm, out);
         }
+    }
+    SA_CHECK_LAUNCH();
+    return SA_OK;
+}
+
+// Workspace of the packed form: operand images (+ norms) of a, and of bb unless it is the same operand.
+extern "C" size_t sa_calc_square_dist_ws_bytes(int b, int n, int m, int c, int symmetric) {
+    if (b <= 0 || n <= 0 || m <= 0 || c <= 0) return 0;
+    const size_t S = (size_t)(c + kKS2 - 1) / kKS2;
+    const size_t npa = (size_t)(n + kMT - 1) / kMT * kMT, npb = (size_t)(m + kMT - 1) / kMT * kMT;
+    size_t fl = (size_t)b * (S * (npa / kMT) * kPackTile + npa);
+    if (!symmetric) fl += (size_t)b * (S * (npb / kMT) * kPackTile + npb);
+    return fl * sizeof(float);
+}
+
+// sa_calc_square_dist_split with caller-owned scratch of sa_calc_square_dist_ws_bytes(b, n, m, c0 + c1, a == bb)
+// bytes: the packed form (one pre-pass per operand, then plain-copy staging).  Same result, bit for bit.
+extern "C" int sa_calc_square_dist_split_ws(int b, int n, int m, int c0, int c1, const float *a0, const float *a1,
+                                            const float *b0, const float *b1, float *out, void *workspace,
+                                            hipStream_t stream) {
+    if (b <= 0 || n <= 0 || m <= 0 || c0 <= 0 || c1 < 0 || !a0 || !b0 || !out) return SA_ERR_INVALID;
+    if (c1 > 0 && (!a1 || !b1)) return SA_ERR_INVALID;
+    static const bool packed_on = !(getenv("SA_SQDIST_PACKED") && atoi(getenv("SA_SQDIST_PACKED")) == 0);
+    const long big = (long)kMT * (m > n ? m : n) + kMT;
+    if (!workspace || !packed_on || big >= (1l << 31) || ((uintptr_t)workspace % 16) != 0 || b > 65535)
+        return sa_calc_square_dist_split(b, n, m, c0, c1, a0, a1, b0, b1, out, stream);
+    const bool sym = n == m && a0 == b0 && a1 == b1;
+    const int c = c0 + c1, S = (c + kKS2 - 1) / kKS2;
+    const int npa = (n + kMT - 1) / kMT * kMT, npb = (m + kMT - 1) / kMT * kMT;
+    float *packA = (float *)workspace, *normA = packA + (size_t)b * S * (npa / kMT) * kPackTile;
+    float *packB = packA, *normB = normA;
+    RowSrc A{a0, c0, a1, c1}, Bm{b0, c0, b1, c1};
+    const int ldc = c | 1;
+    const size_t pack_lds = (size_t)kMT * ldc * sizeof(float);
+    if (pack_lds > 150 * 1024) return sa_calc_square_dist_split(b, n, m, c0, c1, a0, a1, b0, b1, out, stream);
+    if (pack_lds > 48 * 1024) {
+        (void)hipFuncSetAttribute((const void *)sqdist_pack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pack_lds);
+        (void)hipGetLastError();
+    }
+    hipLaunchKernelGGL(sqdist_pack_kernel, dim3(npa / kMT, b), dim3(2 * kMT), pack_lds, stream, n, npa, S, ldc, A, packA, normA);
+    SA_CHECK_LAUNCH();
+    if (!sym) {
+        packB = normA + (size_t)b * npa;
+        normB = packB + (size_t)b * S * (npb / kMT) * kPackTile;
+        hipLaunchKernelGGL(sqdist_pack_kernel, dim3(npb / kMT, b), dim3(2 * kMT), pack_lds, stream, m, npb, S, ldc, Bm, packB, normB);
+        SA_CHECK_LAUNCH();
+    }
+    const bool nt = (size_t)b * n * m * sizeof(float) > ((size_t)192 << 20);
+    if (sym) {
+        const int T = npa / kMT;
+        dim3 grid(T * (T + 1) / 2, 1, b);
+        if (nt) hipLaunchKernelGGL((sqdist_mfma3_kernel<true, true>), grid, dim3(256), 0, stream, n, m, c, npa, npb, packA, packB, normA, normB, out);
+        else hipLaunchKernelGGL((sqdist_mfma3_kernel<true, false>), grid, dim3(256), 0, stream, n, m, c, npa, npb, packA, packB, normA, normB, out);
+    } else {
+        dim3 grid(npb / kMT, npa / kMT, b);
+        if (nt) hipLaunchKernelGGL((sqdist_mfma3_kernel<false, true>), grid, dim3(256), 0, stream, n, m, c, npa, npb, packA, packB, normA, normB, out);
+        else hipLaunchKernelGGL((sqdist_mfma3_kernel<false, false>), grid, dim3(256), 0, stream, n, m, c, npa, npb, packA, packB, normA, normB, out);
     }
     SA_CHECK_LAUNCH();
     return SA_OK;

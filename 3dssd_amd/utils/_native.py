@@ -26,6 +26,7 @@ SIGNATURES = {
     "sa_fps_bucket_ex": [_c_int] * 3 + [_vp, _vp, _c_int, _c_int, _vp],
     "sa_fps_generic": [_c_int] * 4 + [_vp, _vp, _vp, _c_int, _vp],
     "sa_calc_square_dist_split": [_c_int] * 5 + [_vp, _vp, _vp, _vp, _vp, _vp],
+    "sa_calc_square_dist_split_ws": [_c_int] * 5 + [_vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sa_query_ball_point_multi": [_c_int] * 4 + [_vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _vp],
     "sa_query_ball_point_grid": [_c_int] * 4 + [_vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _vp, _vp],
     "sa_group_mlp_max": [_c_int] * 5 + [_vp] * 5 + [_c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp],
@@ -79,6 +80,8 @@ def lib():
             fn.restype = _c_int
         h.sa_query_ball_point_grid_ws_bytes.argtypes = [_c_int, _c_int, _c_int]     # the one non-status function
         h.sa_query_ball_point_grid_ws_bytes.restype = ctypes.c_size_t
+        h.sa_calc_square_dist_ws_bytes.argtypes = [_c_int] * 5
+        h.sa_calc_square_dist_ws_bytes.restype = ctypes.c_size_t
         h.sa_host_crc32c.argtypes = [_vp, ctypes.c_size_t, ctypes.c_uint32]          # host helper: returns the CRC
         h.sa_host_crc32c.restype = ctypes.c_uint32
         _LIB = h

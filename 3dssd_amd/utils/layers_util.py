@@ -63,9 +63,12 @@ def _ffps_into(npoint, tmp_xyz, tmp_points, out, col, idx_off):
     c1 = tmp_points.shape[2]
     dist = torch.empty((b, n, n), dtype=torch.float32, device=tmp_xyz.device)
     lib = N.lib()
-    st = lib.sa_calc_square_dist_split(b, n, n, 3, c1, tmp_xyz.data_ptr(), tmp_points.data_ptr(),
-                                       tmp_xyz.data_ptr(), tmp_points.data_ptr(), dist.data_ptr(),
-                                       N.current_stream())
+    # packed form: the operand is laid out once in the matrix kernel's LDS image, tiles are staged by plain copies
+    ws = torch.empty((lib.sa_calc_square_dist_ws_bytes(b, n, n, 3 + c1, 1) + 3) // 4, dtype=torch.float32,
+                     device=tmp_xyz.device)
+    st = lib.sa_calc_square_dist_split_ws(b, n, n, 3, c1, tmp_xyz.data_ptr(), tmp_points.data_ptr(),
+                                          tmp_xyz.data_ptr(), tmp_points.data_ptr(), dist.data_ptr(), ws.data_ptr(),
+                                          N.current_stream())
     N.check(st, "calc_square_dist")
     temp = torch.empty((b, n), dtype=torch.float32, device=dist.device) if n > 16384 else None
     st = lib.sa_fps_with_distance_ex(b, n, npoint, dist.data_ptr(),

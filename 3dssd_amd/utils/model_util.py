@@ -19,7 +19,10 @@ def calc_square_dist(a, b, norm=False):
     bs, n, c = a.shape
     m = b.shape[1]
     out = torch.empty((bs, n, m), dtype=torch.float32, device=a.device)
-    st = N.lib().sa_calc_square_dist(bs, n, m, c, a.data_ptr(), b.data_ptr(), out.data_ptr(),
-                                     N.current_stream())
+    lib = N.lib()
+    sym = a.data_ptr() == b.data_ptr() and n == m
+    ws = torch.empty((lib.sa_calc_square_dist_ws_bytes(bs, n, m, c, 1 if sym else 0) + 3) // 4, dtype=torch.float32, device=a.device)
+    st = lib.sa_calc_square_dist_split_ws(bs, n, m, c, 0, a.data_ptr(), None, b.data_ptr(), None, out.data_ptr(),
+                                          ws.data_ptr(), N.current_stream())
     N.check(st, "calc_square_dist")
     return out

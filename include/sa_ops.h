@@ -84,6 +84,13 @@ int sa_fps_generic(int b, int n, int c, int m, const float *inp, float *temp, in
  * layers_util.py:94,102). */
 int sa_calc_square_dist_split(int b, int n, int m, int c0, int c1, const float *a0, const float *a1,
                               const float *b0, const float *b1, float *out, sa_stream_t stream);
+/* The same with caller-owned scratch (device memory of sa_calc_square_dist_ws_bytes(b, n, m, c0 + c1, symmetric)
+ * bytes, 16-byte aligned; symmetric = a and bb are the same operand): each operand is first packed once into the
+ * matrix kernel's LDS image (3dssd_amd/csrc/sqdist.hip, third form).  Bit-identical output; workspace == NULL falls
+ * back to the scratch-free form. */
+unsigned long sa_calc_square_dist_ws_bytes(int b, int n, int m, int c, int symmetric);
+int sa_calc_square_dist_split_ws(int b, int n, int m, int c0, int c1, const float *a0, const float *a1,
+                                 const float *b0, const float *b1, float *out, void *workspace, sa_stream_t stream);
 
 /* All radius bands of one SA layer in one pass (layers_util.py:134-147).  rmin/rmax/ns: host arrays of
  * nbands entries; idx/cnt: host arrays of nbands device pointers.  dilated=0 ignores rmin. */

@@ -122,6 +122,37 @@ def test_single_band_api_grid_and_scan_kernels_agree(gpu, oracle, monkeypatch):
     assert np.array_equal(d[0].cpu().numpy(), ri) and np.array_equal(d[1].cpu().numpy(), rc)
 
 
+@pytest.mark.parametrize("b,n,m,c0,c1,sym", [(2, 512, 512, 3, 64, True), (1, 300, 300, 3, 128, True), (2, 1000, 1000, 3, 32, True),
+                                             (2, 384, 640, 3, 64, False), (1, 129, 77, 3, 4, False), (1, 128, 128, 5, 0, True),
+                                             (1, 700, 700, 3, 64, True)])
+def test_calc_square_dist_packed_form(gpu, oracle, b, n, m, c0, c1, sym):
+    """sa_calc_square_dist_split_ws (operands packed once into the LDS image, plain-copy staging) against the oracle,
+    bit for bit, incl. ragged sizes, several K stages, one-piece rows and distinct operands"""
+    N = pkg("utils._native")
+    rng = np.random.default_rng(n + m + c1)
+    a0 = rng.normal(0, 1, (b, n, c0)).astype(np.float32)
+    a1 = rng.normal(0, 1, (b, n, c1)).astype(np.float32)
+    if sym:
+        b0, b1 = a0, a1
+    else:
+        b0 = rng.normal(0, 1, (b, m, c0)).astype(np.float32)
+        b1 = rng.normal(0, 1, (b, m, c1)).astype(np.float32)
+    ta0, ta1 = _t(a0, gpu), (_t(a1, gpu) if c1 else None)
+    tb0, tb1 = (ta0, ta1) if sym else (_t(b0, gpu), (_t(b1, gpu) if c1 else None))
+    lib = N.lib()
+    ws = torch.empty((lib.sa_calc_square_dist_ws_bytes(b, n, m, c0 + c1, 1 if sym else 0) + 3) // 4, dtype=torch.float32, device=gpu)
+    out = torch.full((b, n, m), -7.0, dtype=torch.float32, device=gpu)
+    st = lib.sa_calc_square_dist_split_ws(b, n, m, c0, c1, ta0.data_ptr(), ta1.data_ptr() if c1 else None, tb0.data_ptr(),
+                                          tb1.data_ptr() if c1 else None, out.data_ptr(), ws.data_ptr(), N.current_stream())
+    assert st == 0
+    torch.cuda.synchronize()
+    ref = oracle.calc_square_dist(np.concatenate([a0, a1], -1), np.concatenate([b0, b1], -1))
+    got = out.cpu().numpy()
+    assert np.array_equal(got, ref)
+    if sym:
+        assert np.array_equal(got, got.transpose(0, 2, 1))
+
+
 def test_fps_forced_generic_kernel_equals_register_kernel(gpu, oracle):
     N = pkg("utils._native")
     rng = np.random.default_rng(5)
