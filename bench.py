@@ -71,7 +71,7 @@ def _algorithmic(name, a):
     if name == "sa_fps_with_distance_ex":
         b, n, m = a[0:3]
         return 2 * b * (m - 1) * n, b * ((m - 1) * n * 4 + m * 4), "fps_with_distance n=%d->%d" % (n, m)
-    if name == "sa_calc_square_dist_split":
+    if name in ("sa_calc_square_dist_split", "sa_calc_square_dist_split_ws"):
         b, n, m, c0, c1 = a[0:5]
         return 2 * b * n * m * (c0 + c1), b * (n * m * 4 + (n + m) * (c0 + c1) * 4), "calc_square_dist n=%d c=%d" % (n, c0 + c1)
     if name in ("sa_query_ball_point_multi", "sa_query_ball_point_grid"):
@@ -187,8 +187,8 @@ def _pmc_mlp_util():
 
 def roofline_of(stage):
     k = stage["kernel"]
-    if k in ("sa_group_mlp_max", "sa_dense", "sa_calc_square_dist_split"):
-        peak = MFMA_BF16_PEAK_TF if k != "sa_calc_square_dist_split" else VALU_F32_PEAK_TF
+    if k in ("sa_group_mlp_max", "sa_dense", "sa_calc_square_dist_split", "sa_calc_square_dist_split_ws"):
+        peak = MFMA_BF16_PEAK_TF if not k.startswith("sa_calc_square_dist") else VALU_F32_PEAK_TF
         a = stage.get("tflops", 0.0)
         return dict(kernel=stage["label"], bound="mfma", achieved=a, peak=peak, unit="TFLOP/s",
                     frac=round(a / peak, 5), traffic=None)
