@@ -65,7 +65,7 @@ def test_config0_single_sa_layer(gpu, oracle):
     assert _rel(fl[1].cpu().numpy(), rf) < TOL
 
 
-@pytest.mark.parametrize("batch,n,dup", [(2, 16384, 0.0), (1, 16384, 0.1)])
+@pytest.mark.parametrize("batch,n,dup", [(2, 16384, 0.0), (1, 16384, 0.1), (3, 6000, 0.05)])   # last: ragged frame size, the other FPS / ball-query kernel variants
 def test_kitti_backbone_teacher_forced(gpu, oracle, batch, n, dup):
     cfgs, syn = pkg("configs"), pkg("synthetic")
     arch = cfgs.KITTI_3DSSD_ARCH
