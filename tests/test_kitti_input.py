@@ -93,3 +93,34 @@ def test_cropped_scan_through_the_backbone(gpu, calib):
     torch.cuda.synchronize()
     assert xl[-1].shape == (1, 256, 3) and fl[-1].shape == (1, 256, 512) and torch.isfinite(fl[-1]).all()
     assert torch.unique(il[1][0]).numel() == 4096
+
+
+@pytest.mark.gpu
+def test_velodyne_files_to_kitti_result_files(gpu, tmp_path):
+    """tools/infer_kitti.py end to end on three synthetic sweeps: .bin + calib in, NNNNNN.txt out (random weights: only
+    the plumbing and the file format are checked)"""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("infer_kitti", os.path.join(ROOT, "tools", "infer_kitti.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    vel, cal, out = tmp_path / "velodyne", tmp_path / "calib", tmp_path / "results"
+    vel.mkdir(); cal.mkdir()
+    rng = np.random.default_rng(1)
+    for i in (3, 7, 12):
+        n = 50000
+        scan = np.stack([rng.uniform(0, 75, n), rng.uniform(-35, 35, n), rng.uniform(-2.0, 0.5, n), rng.uniform(0, 1, n)], -1).astype(np.float32)
+        scan.tofile(str(vel / ("%06d.bin" % i)))
+        (cal / ("%06d.txt" % i)).write_text(CALIB_TXT)
+    written = mod.main(["--velodyne", str(vel), "--calib", str(cal), "--out", str(out), "--batch", "2", "--cls-thresh", "0.0",
+                        "--image-shape", "370", "1224"])
+    assert [os.path.basename(w) for w in written] == ["000003.txt", "000007.txt", "000012.txt"]
+    lines = open(written[0]).read().splitlines()
+    assert 1 <= len(lines) <= 100
+    for ln in lines:
+        f = ln.split()
+        assert len(f) == 16 and f[0] == "Car" and f[1:4] == ["0.00", "0", "-10"]
+        x1, y1, x2, y2 = map(float, f[4:8])
+        assert 0 <= x1 <= x2 <= 1224 and 0 <= y1 <= y2 <= 370
+        assert 0.0 <= float(f[15]) <= 1.0
