@@ -5,11 +5,21 @@
  * link or execute this file.  Only tests/, __graft_entry__.smoke() and the
  * cpu_baseline leg of bench.py use it, as the checker / the timed CPU baseline.
  *
- * PARITY UNPINNED: the reference ships no CPU implementation of these ops, no
- * golden vectors and no known-answer tests for them, and it
- * cannot be built here (TensorFlow 1.4 headers + nvcc absent).  This file restates
- * the semantics of the reference CUDA kernels; the hand-derived known-answer tests in
- * tests/test_oracle_kat.py are what pins it.
+ * PARITY PINNED (round 2) to the reference's own device code.  The reference ships no CPU
+ * implementation of these ops, no golden vectors and no known-answer tests for them
+ * (SURVEY.md section 8c), and its OpKernels (tf_*.cpp) need the TensorFlow headers.  But the
+ * kernels + launchers themselves (tf_sampling_g.cu, tf_grouping_g.cu) include no TensorFlow
+ * header: `make -C oracle ref_gpu` compiles them UNMODIFIED, from where they lie under
+ * /root/reference, with hipcc for gfx950 into oracle/_ref/libtf_ops_ref_fma.so (scalar FMA
+ * contraction = the model of nvcc's default -fmad=true).  tests/test_ref_pin_gpu.py compares
+ * that library, this file and the HIP kernels three-way, bit for bit, on an MI355X;
+ * tests/golden/ref_gpu_pin.npz holds that library's outputs (generator committed) and
+ * tests/test_ref_golden_cpu.py checks this file against them in the CPU suite.  The
+ * hand-derived known-answer tests in tests/test_oracle_kat.py remain as a second pin.
+ * What stays unpinned: the nvcc/PTX binary itself (no nvcc here) -- decisions A and B below are
+ * the scalar LLVM contraction of the reference's expressions, which the `fma` build reproduces
+ * and the -ffp-contract=off build and the gfx950 packed-math default build measurably do not
+ * (test_fma_policy_is_discriminated) -- and TensorFlow/cuBLAS/cuDNN arithmetic (decisions E, F).
  *
  * Arithmetic decisions (recorded once, used by oracle and HIP kernels alike):
  *  A. FPS distance (lib/utils/tf_ops/sampling/tf_sampling_g.cu:144-150) is the loop
@@ -20,8 +30,10 @@
  *     single expression dx*dx + dy*dy + dz*dz.  Under -fmad=true the LLVM/NVVM
  *     contraction of ((dx*dx + dy*dy) + dz*dz) is fma(dz,dz, fma(dx,dx, dy*dy))
  *     (the left product of each add is the fused one, the remaining product is a
- *     plain multiply).  nvcc is not available to confirm the PTX; this is the pinned
- *     definition.  The comparison is on the correctly rounded sqrtf of that value.
+ *     plain multiply).  nvcc is not available to confirm the PTX; hipcc with scalar
+ *     contraction emits exactly this for the unmodified source (v_mul dy,dy; v_fmac dx,dx;
+ *     v_fmac dz,dz), and the three-way GPU test holds on points a few ulps either side of
+ *     the radius.  The comparison is on the correctly rounded sqrtf of that value.
  *  C. FPS tie-break is the reference's (k mod 1024, k) order: thread t of the
  *     1024-thread block keeps its first strict maximum over k = t, t+1024, ... and the
  *     shared-memory tree keeps the left entry on ties (tf_sampling_g.cu:154-171).

@@ -3,8 +3,11 @@
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the cpu_baseline leg
 of bench.py.  The product package (3dssd_amd/) never imports it.
 
-PARITY UNPINNED: the reference has no CPU path, no golden vectors and cannot be built here
-(SURVEY.md 8c); see the header of sa_oracle.c for the arithmetic decisions this oracle pins.
+PARITY PINNED to the reference's own device code (tf_sampling_g.cu / tf_grouping_g.cu compiled unmodified for
+gfx950 into oracle/_ref, `make -C oracle ref_gpu`): tests/test_ref_pin_gpu.py (live, three-way with the HIP kernels)
+and tests/golden/ref_gpu_pin.npz + tests/test_ref_golden_cpu.py (CPU suite).  See the header of sa_oracle.c for what
+that covers and for the arithmetic decisions; the MLP / distance-matrix arithmetic (TensorFlow, cuBLAS) stays a
+stated definition.
 
 Function names, positional argument order and return arity follow the reference's Python
 operator API (scalars first, tensors last):
