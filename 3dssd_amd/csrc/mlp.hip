@@ -29,6 +29,7 @@
 #include <stdlib.h>
 
 #include "sa_common.h"
+#include "mlp_plan.h"
 
 namespace {
 
@@ -39,7 +40,6 @@ constexpr int kNW = 8;             // waves per workgroup
 constexpr int kThreads = kNW * 64;
 constexpr int kRows = 32;          // rows (= MFMA N) per pass
 constexpr int kMaxLayers = 3;
-constexpr int kMaxBallsPerItem = 4;
 
 struct LayerDesc {
     const uint4 *w;     // fragment-packed hi/lo weights
@@ -55,10 +55,11 @@ struct MlpParams {
     int n, m, ns, C;
     long nballs;
     int out_stride, out_off;
-    int rp;             // rows per ball after padding: 8, 16, 32 or a multiple of 32
+    const int *gran;    // row plan (mlp_plan.h): granule entries, 4 per 32-row tile
+    const int *hdr;     // hdr[0] = number of granules
     int nl;
     LayerDesc L[kMaxLayers];
-    int strideA, strideB, pool_off;   // bytes
+    int strideA, strideB, lds_bytes;  // bytes
 };
 
 #ifdef SA_MLP_TIMING
@@ -208,19 +209,18 @@ __device__ __forceinline__ void gather8(const MlpParams &P, long pt, long ball, 
 //    are separated from the short tail (left-over feature channels + relative xyz + zero padding), which
 //    only 32..128 slots execute.
 template <int ROWS, int NTHR>
-__device__ __forceinline__ void gather_tile(const MlpParams &P, unsigned char *buf, int stride, long ball0,
-                                            int pass, int G0, int tid) {
+__device__ __forceinline__ void gather_tile(const MlpParams &P, unsigned char *buf, int stride, int item,
+                                            int ngran, int G0, int tid) {
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
     // rows lane and lane+64 (ROWS == 64) / lane&31 (ROWS == 32) resolved by this lane
     int r_pt[ROWS / 32 > 1 ? 1 : 1], r_ball[1];
     {
         const int row = ROWS == 64 ? lane : (lane & 31);
-        int bl, s;
-        if (P.rp <= ROWS) { bl = row / P.rp; s = row - bl * P.rp; } else { bl = 0; s = pass * ROWS + row; }
-        long ball = ball0 + bl;
-        if (ball >= P.nballs) ball = P.nballs - 1;
-        if (s >= P.ns) s = 0;                               // padded rows repeat sample 0
+        // granule row>>3 of the item -> plan entry -> (ball, sample); entries past the end read ball 0
+        const int ent = sa::plan_entry(P.gran, ngran, item * (ROWS / 8) + (row >> 3));
+        const long ball = ent >= 0 ? sa::plan_ball(ent) : 0;
+        const int s = sa::plan_sample(ent, row & 7, P.ns);
         const int a_raw = P.idx[ball * P.ns + s];           // both loads issue together
         const int a = P.cnt[ball] > 0 ? a_raw : 0;          // layers_util.py:157-159
         r_ball[0] = (int)ball;
@@ -329,7 +329,7 @@ __device__ __forceinline__ void layer_hidden(const unsigned char *in, int stride
 // ---- last layer, D form + max over the rows of each ball; bias/ReLU/mask are applied at write-out ---
 template <int TG, int NW>
 __device__ __forceinline__ void layer_last(const unsigned char *in, int strideIn, const LayerDesc &L,
-                                           float *pooled, int pooled_ld, bool first, int rp, int lane,
+                                           const MlpParams &P, const int (&ent)[4], const int (&cn)[4], int lane,
                                            int w) {
     const int half = lane >> 5, col = lane & 31;
     const unsigned char *arow = in + col * strideIn + half * 32;
@@ -343,32 +343,11 @@ __device__ __forceinline__ void layer_last(const unsigned char *in, int strideIn
 #pragma unroll
         for (int tt = 0; tt < TG; ++tt) {
             if (gb + tt < L.NT) {
-                // rows of reg r: (r&3) + 8*(r>>2) + 4*half  ->  quarter q = r>>2 covers rows 8q..8q+7
+                // granule maxima (rows 8q..8q+7), combined per ball run, relu(max + bias) written (mlp_plan.h)
                 float qm[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float a0 = sa::fmax_nn(acc[tt][4 * q], acc[tt][4 * q + 1]);
-                    float a1 = sa::fmax_nn(acc[tt][4 * q + 2], acc[tt][4 * q + 3]);
-                    float a = sa::fmax_nn(a0, a1);
-                    auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(a), false, false);
-                    qm[q] = sa::fmax_nn(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-                }
-                float bm[4];
-                int nb;
-                if (rp == 8) { nb = 4; bm[0] = qm[0]; bm[1] = qm[1]; bm[2] = qm[2]; bm[3] = qm[3]; }
-                else if (rp == 16) { nb = 2; bm[0] = sa::fmax_nn(qm[0], qm[1]); bm[1] = sa::fmax_nn(qm[2], qm[3]); bm[2] = bm[3] = 0.f; }
-                else { nb = 1; bm[0] = sa::fmax_nn(sa::fmax_nn(qm[0], qm[1]), sa::fmax_nn(qm[2], qm[3])); bm[1] = bm[2] = bm[3] = 0.f; }
-                if (lane < 32) {
-                    float *pp = pooled + (gb + tt) * 32 + col;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        if (g < nb) {
-                            float v = bm[g];
-                            if (!first) v = sa::fmax_nn(v, pp[g * pooled_ld]);
-                            pp[g * pooled_ld] = v;
-                        }
-                    }
-                }
+                sa::granule_max(acc[tt], qm);
+                const int c = (gb + tt) * 32 + col;
+                sa::pool_write_tile(qm, ent, cn, L.bias[c], c, L.N, P.out, P.out_stride, P.out_off, lane);
             }
         }
     }
@@ -397,70 +376,59 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? SA_MLP_WPE8 : 4) void group_mlp_
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *bufA = smem;
     unsigned char *bufB = smem + kRows * P.strideA;
-    float *pooled = (float *)(smem + P.pool_off);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int bpi = P.rp <= 32 ? 32 / P.rp : 1;       // balls per item
-    const int chunks = P.rp <= 32 ? 1 : P.rp / 32;    // 32-row passes per item
-    const long nitems = (P.nballs + bpi - 1) / bpi;
+    const int ngran = __builtin_amdgcn_readfirstlane(P.hdr[0]);
+    const int nitems = (ngran + 3) >> 2;               // 32-row tiles of the plan
     const LayerDesc &LL = P.L[P.nl - 1];
-    const int N3p = LL.NT * 32;
     const int G0 = P.L[0].KS * 2;                     // 8-channel groups of the input tile
     SA_T0();
 
-    for (long item = blockIdx.x; item < nitems; item += gridDim.x) {
-        const long ball0 = item * bpi;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         SA_COUNT(0);
-        for (int ch = 0; ch < chunks; ++ch) {
-            SA_COUNT(1);
-            // ---- gather the [32 rows x cin] input tile (features first, then relative xyz:
-            //      layers_util.py:160-165) into bufA as hi/lo bf16
-            gather_tile<kRows, kThr>(P, bufA, P.strideA, ball0, ch, G0, tid);
-            __syncthreads();
-            SA_TICK(0)
-            // ---- hidden layers (ping-pong A -> B -> A)
-            for (int l = 0; l + 1 < P.nl; ++l) {
-                const unsigned char *in = (l & 1) ? bufB : bufA;
-                unsigned char *ob = (l & 1) ? bufA : bufB;
-                const int si = (l & 1) ? P.strideB : P.strideA, so = (l & 1) ? P.strideA : P.strideB;
-                switch (pick_tg<NW>(P.L[l].NT)) {
-#if SA_MLP_MAXTG >= 4
-                    case 4: layer_hidden<4, NW>(in, si, ob, so, P.L[l], lane, w); break;
-#endif
-                    case 2: layer_hidden<2, NW>(in, si, ob, so, P.L[l], lane, w); break;
-                    default: layer_hidden<1, NW>(in, si, ob, so, P.L[l], lane, w); break;
-                }
-                __syncthreads();
-            }
-            SA_TICK(1)
-            // ---- last layer + pooling
-            {
-                const int l = P.nl - 1;
-                const unsigned char *in = (l & 1) ? bufB : bufA;
-                const int si = (l & 1) ? P.strideB : P.strideA;
-                switch (pick_tg<NW>(LL.NT)) {
-#if SA_MLP_MAXTG >= 4
-                    case 4: layer_last<4, NW>(in, si, LL, pooled, N3p, ch == 0, P.rp, lane, w); break;
-#endif
-                    case 2: layer_last<2, NW>(in, si, LL, pooled, N3p, ch == 0, P.rp, lane, w); break;
-                    default: layer_last<1, NW>(in, si, LL, pooled, N3p, ch == 0, P.rp, lane, w); break;
-                }
-            }
-            __syncthreads();
-            SA_TICK(2)
+        SA_COUNT(1);
+        // ---- gather the [32 rows x cin] input tile (features first, then relative xyz:
+        //      layers_util.py:160-165) into bufA as hi/lo bf16
+        gather_tile<kRows, kThr>(P, bufA, P.strideA, item, ngran, G0, tid);
+        // the tile's plan entries and ball counts, wave-uniform
+        int ent[4], cn[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int e = sa::plan_entry(P.gran, ngran, item * 4 + g);
+            ent[g] = __builtin_amdgcn_readfirstlane(e);
+            cn[g] = __builtin_amdgcn_readfirstlane(e >= 0 ? P.cnt[sa::plan_ball(e)] : 0);
         }
-        // ---- write out: relu(max + bias), zero for empty balls (layers_util.py:178-181)
-        for (int e = tid; e < bpi * LL.N; e += kThr) {
-            const int g = e / LL.N, c = e - g * LL.N;
-            const long ball = ball0 + g;
-            if (ball < P.nballs) {
-                float v = pooled[g * N3p + c] + LL.bias[c];
-                v = v > 0.0f ? v : 0.0f;
-                if (P.cnt[ball] <= 0) v = 0.0f;
-                P.out[ball * P.out_stride + P.out_off + c] = v;
+        __syncthreads();
+        SA_TICK(0)
+        // ---- hidden layers (ping-pong A -> B -> A)
+        for (int l = 0; l + 1 < P.nl; ++l) {
+            const unsigned char *in = (l & 1) ? bufB : bufA;
+            unsigned char *ob = (l & 1) ? bufA : bufB;
+            const int si = (l & 1) ? P.strideB : P.strideA, so = (l & 1) ? P.strideA : P.strideB;
+            switch (pick_tg<NW>(P.L[l].NT)) {
+#if SA_MLP_MAXTG >= 4
+                case 4: layer_hidden<4, NW>(in, si, ob, so, P.L[l], lane, w); break;
+#endif
+                case 2: layer_hidden<2, NW>(in, si, ob, so, P.L[l], lane, w); break;
+                default: layer_hidden<1, NW>(in, si, ob, so, P.L[l], lane, w); break;
+            }
+            __syncthreads();
+        }
+        SA_TICK(1)
+        // ---- last layer + pooling + write-out: relu(max + bias), zero for empty balls (layers_util.py:178-181)
+        {
+            const int l = P.nl - 1;
+            const unsigned char *in = (l & 1) ? bufB : bufA;
+            const int si = (l & 1) ? P.strideB : P.strideA;
+            switch (pick_tg<NW>(LL.NT)) {
+#if SA_MLP_MAXTG >= 4
+                case 4: layer_last<4, NW>(in, si, LL, P, ent, cn, lane, w); break;
+#endif
+                case 2: layer_last<2, NW>(in, si, LL, P, ent, cn, lane, w); break;
+                default: layer_last<1, NW>(in, si, LL, P, ent, cn, lane, w); break;
             }
         }
         __syncthreads();
-        SA_TICK(3)
+        SA_TICK(2)
     }
     SA_TFLUSH(tid == 0)
 }
@@ -477,7 +445,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? SA_MLP_WPE8 : 4) void group_mlp_
 constexpr int kWRows = 64;
 
 struct WideParams {
-    MlpParams M;          // strideA/strideB/pool_off are for 64-row buffers here
+    MlpParams M;          // strideA/strideB/lds_bytes are for 64-row buffers here
     int tiles_per_chunk;  // output tiles of the last hidden layer per chunk (all of them when nl == 1)
     int nchunks;
 };
@@ -625,30 +593,9 @@ __device__ __forceinline__ void wide_last_partial(f32x16 (&acc)[TGL][2], const u
     }
 }
 
-// max over the rows of each ball for one 32-row tile: bm[g], g < nb = 32/min(rp,32)
-__device__ __forceinline__ int tile_ball_max(const f32x16 &a, int rp, float (&bm)[4]) {
-    float qm[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        float a0 = sa::fmax_nn(a[4 * q], a[4 * q + 1]);
-        float a1 = sa::fmax_nn(a[4 * q + 2], a[4 * q + 3]);
-        float x = sa::fmax_nn(a0, a1);
-        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-        qm[q] = sa::fmax_nn(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-    }
-    // selects, not branches: branches turn bm[] into a private-memory object
-    const float m01 = sa::fmax_nn(qm[0], qm[1]), m23 = sa::fmax_nn(qm[2], qm[3]);
-    const float mall = sa::fmax_nn(m01, m23);
-    bm[0] = rp == 8 ? qm[0] : (rp == 16 ? m01 : mall);
-    bm[1] = rp == 8 ? qm[1] : (rp == 16 ? m23 : 0.0f);
-    bm[2] = rp == 8 ? qm[2] : 0.0f;
-    bm[3] = rp == 8 ? qm[3] : 0.0f;
-    return rp == 8 ? 4 : (rp == 16 ? 2 : 1);
-}
-
 template <int TGL>
 __device__ __forceinline__ void wide_item_layers(const WideParams &WP, unsigned char *bufA, unsigned char *bufB,
-                                                 float *pooled, int N3p, bool first_pass, int lane, int w) {
+                                                 const int (&ent)[2][4], const int (&cn)[2][4], int lane, int w) {
     const MlpParams &P = WP.M;
     const int nl = P.nl;
     const LayerDesc &LL = P.L[nl - 1];
@@ -687,31 +634,20 @@ __device__ __forceinline__ void wide_item_layers(const WideParams &WP, unsigned 
             if (ks_lo < ks_hi) wide_last_partial<TGL>(acc, ob, so, LL, ks_lo, ks_hi, lane, w);
         }
     }
-    // pooling: row tile j covers rows 32j..32j+31 of the item
+    // pooling + write-out: row tile j covers rows 32j..32j+31 of the item = plan tile 2*item + j
     asm volatile("" : "+v"(lane));
     const int col = lane & 31;
 #pragma unroll
     for (int tt = 0; tt < TGL; ++tt) {
         const int ct = w + kNW * tt;
         if (ct < LL.NT) {
+            const int c = ct * 32 + col;
+            const float bc = LL.bias[c];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                float bm[4];
-                const int nb = tile_ball_max(acc[tt][j], P.rp, bm);
-                if (lane < 32) {
-                    // ball slot inside the item: rp <= 32 -> j*nb + g ; rp >= 64 -> 0 for both tiles
-                    const int base = P.rp <= 32 ? j * nb : 0;
-                    const bool fresh = first_pass && (P.rp <= 32 || j == 0);
-                    float *pp = pooled + ct * 32 + col;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        if (g < nb) {
-                            float v = bm[g];
-                            if (!fresh) v = sa::fmax_nn(v, pp[(base + g) * N3p]);
-                            pp[(base + g) * N3p] = v;
-                        }
-                    }
-                }
+                float qm[4];
+                sa::granule_max(acc[tt][j], qm);
+                sa::pool_write_tile(qm, ent[j], cn[j], bc, c, LL.N, P.out, P.out_stride, P.out_off, lane);
             }
         }
     }
@@ -722,36 +658,26 @@ __global__ __launch_bounds__(kThreads, 2) void group_mlp_wide_kernel(WideParams 
     const MlpParams &P = WP.M;
     unsigned char *bufA = smem;
     unsigned char *bufB = smem + kWRows * P.strideA;
-    float *pooled = (float *)(smem + P.pool_off);
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bpi = P.rp <= 64 ? 64 / P.rp : 1;        // balls per item
-    const int passes = P.rp <= 64 ? 1 : P.rp / 64;     // 64-row passes per item
-    const long nitems = (P.nballs + bpi - 1) / bpi;
+    const int ngran = __builtin_amdgcn_readfirstlane(P.hdr[0]);
+    const int nitems = (ngran + 7) >> 3;               // 64-row items = 8 granules of the plan
     const LayerDesc &LL = P.L[P.nl - 1];
-    const int N3p = LL.NT * 32;
     const int G0 = P.L[0].KS * 2;
     const int tgl = (LL.NT + kNW - 1) / kNW;
 
-    for (long item = blockIdx.x; item < nitems; item += gridDim.x) {
-        const long ball0 = item * bpi;
-        for (int ps = 0; ps < passes; ++ps) {
-            gather_tile<kWRows, kThreads>(P, bufA, P.strideA, ball0, ps, G0, tid);
-            __syncthreads();
-            if (tgl <= 1) wide_item_layers<1>(WP, bufA, bufB, pooled, N3p, ps == 0, lane, w);
-            else if (tgl <= 2) wide_item_layers<2>(WP, bufA, bufB, pooled, N3p, ps == 0, lane, w);
-            else wide_item_layers<4>(WP, bufA, bufB, pooled, N3p, ps == 0, lane, w);
-            __syncthreads();
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        gather_tile<kWRows, kThreads>(P, bufA, P.strideA, item, ngran, G0, tid);
+        int ent[2][4], cn[2][4];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int e = sa::plan_entry(P.gran, ngran, item * 8 + g);
+            ent[g >> 2][g & 3] = __builtin_amdgcn_readfirstlane(e);
+            cn[g >> 2][g & 3] = __builtin_amdgcn_readfirstlane(e >= 0 ? P.cnt[sa::plan_ball(e)] : 0);
         }
-        for (int e = tid; e < bpi * LL.N; e += kThreads) {
-            const int g = e / LL.N, c = e - g * LL.N;
-            const long ball = ball0 + g;
-            if (ball < P.nballs) {
-                float v = pooled[g * N3p + c] + LL.bias[c];
-                v = v > 0.0f ? v : 0.0f;
-                if (P.cnt[ball] <= 0) v = 0.0f;
-                P.out[ball * P.out_stride + P.out_off + c] = v;
-            }
-        }
+        __syncthreads();
+        if (tgl <= 1) wide_item_layers<1>(WP, bufA, bufB, ent, cn, lane, w);
+        else if (tgl <= 2) wide_item_layers<2>(WP, bufA, bufB, ent, cn, lane, w);
+        else wide_item_layers<4>(WP, bufA, bufB, ent, cn, lane, w);
         __syncthreads();
     }
 }
@@ -935,6 +861,133 @@ __global__ void vote_translate_kernel(long total, const float *__restrict__ xyz,
     }
 }
 
+// ---- row plan (mlp_plan.h): ball -> ceil(clamp(cnt, 1, ns) / 8) granules of 8 rows -------------------------------
+// Packing is "next fit" into 32-row tiles (4 granules): a ball of <= 4 granules never straddles a tile boundary (the
+// rest of the tile is padded with invalid entries), so its maximum is complete inside one wave and is written with a
+// plain store; only balls of more than 32 distinct rows are split (atomic max on a row zeroed here).  Next fit is a
+// sequential rule; it is evaluated in parallel as a scan over FUNCTIONS phase -> (phase, advance) (phase = fill of
+// the current tile, 0..3): a thread folds its 8 balls for each of the 4 start phases, waves scan by composition.
+constexpr int kPlanThreads = 256, kPlanBallsPerThread = 8;
+
+struct PlanFn { int t[4]; };     // t[p] = advance << 2 | end phase, for start phase p
+__device__ __forceinline__ int plan_fn_at(const PlanFn &f, int p) {
+    return p == 0 ? f.t[0] : (p == 1 ? f.t[1] : (p == 2 ? f.t[2] : f.t[3]));
+}
+// first a, then b
+__device__ __forceinline__ PlanFn plan_fn_compose(const PlanFn &a, const PlanFn &b) {
+    PlanFn c;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int x = a.t[p], y = plan_fn_at(b, x & 3);
+        c.t[p] = (((x >> 2) + (y >> 2)) << 2) | (y & 3);
+    }
+    return c;
+}
+// one ball of g granules placed from phase ph: returns the padding in front of it; updates ph
+__device__ __forceinline__ int plan_place(int g, int &ph) {
+    int pad = 0;
+    if (g <= 4 && ph + g > 4) { pad = 4 - ph; ph = 0; }
+    ph = (ph + g) & 3;
+    return pad;
+}
+
+__global__ void mlp_plan_reset_kernel(int *hdr) {
+    if (threadIdx.x < sa::kPlanHeaderInts) hdr[threadIdx.x] = 0;
+}
+
+__global__ __launch_bounds__(kPlanThreads) void mlp_plan_kernel(const int *__restrict__ cnt, int nballs, int ns, int dense,
+                                                                int *__restrict__ hdr, int *__restrict__ gran,
+                                                                float *__restrict__ out, int out_stride, int out_off, int N) {
+    __shared__ int wfn[kPlanThreads / 64][4];
+    __shared__ int base_s, nsplit_s;
+    __shared__ int split_ball[kPlanThreads * kPlanBallsPerThread];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) nsplit_s = 0;
+    const int ball0 = (blockIdx.x * kPlanThreads + tid) * kPlanBallsPerThread;
+    int g[kPlanBallsPerThread], rows = 0;
+#pragma unroll
+    for (int k = 0; k < kPlanBallsPerThread; ++k) {
+        const int ball = ball0 + k;
+        int c = 0;
+        if (ball < nballs) { c = cnt[ball]; c = c < 1 ? 1 : (c > ns ? ns : c); if (dense) c = ns; }
+        g[k] = (c + 7) >> 3;
+        rows += c;
+    }
+    PlanFn f;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        int ph = p, adv = 0;
+#pragma unroll
+        for (int k = 0; k < kPlanBallsPerThread; ++k)
+            if (g[k] > 0) { adv += plan_place(g[k], ph); adv += g[k]; }
+        f.t[p] = (adv << 2) | ph;
+    }
+    PlanFn incl = f;                                    // inclusive scan by composition over the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        PlanFn o;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) o.t[p] = __shfl_up(incl.t[p], d);
+        if (lane >= d) incl = plan_fn_compose(o, incl);
+    }
+    int rsum = rows;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) rsum += __shfl_xor(rsum, d);
+    if (lane == 63) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) wfn[w][p] = incl.t[p];
+    }
+    __syncthreads();
+    // the workgroup starts tile-aligned (phase 0): state in front of this wave, then in front of this thread
+    int st = 0;                                         // advance << 2 | phase
+    int btot = 0;
+#pragma unroll
+    for (int i = 0; i < kPlanThreads / 64; ++i) {
+        const int y = wfn[i][btot & 3];
+        const int nx = (((btot >> 2) + (y >> 2)) << 2) | (y & 3);
+        if (i < w) st = nx;
+        btot = nx;
+    }
+    const int total = ((btot >> 2) + 3) & ~3;           // whole tiles per workgroup
+    if (tid == 0) base_s = atomicAdd(&hdr[0], total);   // order of the workgroups' ranges is irrelevant to the results
+    if (lane == 0 && rsum) atomicAdd(&hdr[2], rsum);
+    {
+        PlanFn excl;                                    // exclusive prefix of this thread inside its wave
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { const int v = __shfl_up(incl.t[p], 1); excl.t[p] = lane == 0 ? p : v; }
+        const int y = plan_fn_at(excl, st & 3);
+        st = (((st >> 2) + (y >> 2)) << 2) | (y & 3);
+    }
+    __syncthreads();
+    int pos = base_s + (st >> 2), ph = st & 3;
+#pragma unroll
+    for (int k = 0; k < kPlanBallsPerThread; ++k) {
+        if (g[k] > 0) {
+            const int ball = ball0 + k;
+            const int pad = plan_place(g[k], ph);
+            for (int j = 0; j < pad; ++j) gran[pos + j] = -1;
+            pos += pad;
+            const int split = g[k] > 4 ? 1 : 0;
+            for (int j = 0; j < g[k]; ++j) gran[pos + j] = (ball << 7) | (j << 1) | split;
+            pos += g[k];
+            if (split) split_ball[atomicAdd(&nsplit_s, 1)] = ball;
+        }
+    }
+    // the last thread that placed something pads the workgroup's range to whole tiles
+    if (tid == kPlanThreads - 1) {
+        const int end = base_s + total;
+        for (int q = base_s + (btot >> 2); q < end; ++q) gran[q] = -1;
+    }
+    __syncthreads();
+    // rows of split balls are zeroed (their partial maxima meet through an atomic max): all threads, coalesced
+    const int nsp = nsplit_s;
+    for (int i = 0; i < nsp; ++i) {
+        float *o = out + (size_t)split_ball[i] * out_stride + out_off;
+        for (int c = tid; c < N; c += kPlanThreads) o[c] = 0.0f;
+    }
+    if (tid == 0 && nsp) atomicAdd(&hdr[1], nsp);
+}
+
 int roundup(int x, int q) { return (x + q - 1) / q * q; }
 
 }  // namespace
@@ -942,37 +995,69 @@ int roundup(int x, int q) { return (x + q - 1) / q * q; }
 // mlp_rowwave.hip: LDS-resident-weight / register-resident-activation kernel for the narrow and mid scales
 int sa_rowwave_try(int b, int n, int m, int ns, int c, const float *xyz, const float *feat, const float *new_xyz,
                    const int *idx, const int *cnt, int nl, const int *dims, const void *const *wpack,
-                   const float *const *bias, float *out, int out_stride, int out_off, hipStream_t stream,
-                   int *st);
+                   const float *const *bias, float *out, int out_stride, int out_off, const int *plan_hdr,
+                   const int *plan_gran, long max_tiles, hipStream_t stream, int *st);
+
+// Upper bound of the plan length: next fit never leaves two consecutive tiles with a combined fill <= 4 granules, so
+// the list is shorter than twice the granules + one tile per 2048-ball workgroup of the plan kernel (its alignment).
+static long sa_plan_max_granules(long nballs, int ns) {
+    const long g = nballs * ((ns + 7) / 8);
+    const long wgs = (nballs + kPlanThreads * kPlanBallsPerThread - 1) / (kPlanThreads * kPlanBallsPerThread);
+    return (ns <= 8 ? g : 2 * g) + 4 * wgs + 8;
+}
+
+// Bytes of caller-owned scratch sa_group_mlp_max needs for the row plan of one scale (header + one int per granule
+// of the densest plan).
+extern "C" size_t sa_group_mlp_max_ws_bytes(int b, int m, int ns) {
+    if (b <= 0 || m <= 0 || ns <= 0) return 0;
+    return (size_t)sa::kPlanHeaderInts * sizeof(int) + ((size_t)sa_plan_max_granules((long)b * m, ns) + 8) * sizeof(int);
+}
 
 // One scale of an SA layer.  Layer l: wpack[l] (device, fragment-packed hi/lo bf16, see header),
 // bias[l] (device, fp32, zero-padded to a multiple of 32), dims[0] = C+3, dims[l+1] = output channels.
 // out[(b*m + j)*out_stride + out_off + c] receives the pooled channel c.  Additional to the reference
-// API (the reference has no fused op).
+// API (the reference has no fused op).  ws: sa_group_mlp_max_ws_bytes(b, m, ns) bytes of device scratch (the row
+// plan; contents are private to the call).  flags bit 0: dense plan -- every ball is evaluated on all nsample rows
+// like the reference does (A/B measurements); default: only the distinct rows of a ball (mlp_plan.h), same results.
 extern "C" int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float *xyz, const float *feat,
                                 const float *new_xyz, const int *idx, const int *cnt, int nl,
                                 const int *dims, const void *const *wpack, const float *const *bias,
-                                float *out, int out_stride, int out_off, hipStream_t stream) {
+                                float *out, int out_stride, int out_off, void *ws, size_t ws_bytes, int flags,
+                                hipStream_t stream) {
     if (b <= 0 || n <= 0 || m <= 0 || ns <= 0 || c < 0 || nl < 1 || nl > kMaxLayers) return SA_ERR_INVALID;
     if (!xyz || !new_xyz || !idx || !cnt || !out || !dims || !wpack || !bias) return SA_ERR_INVALID;
     if (c > 0 && !feat) return SA_ERR_INVALID;
     if (dims[0] != c + 3) return SA_ERR_INVALID;
     for (int l = 0; l < nl; ++l)
         if (dims[l + 1] <= 0 || !wpack[l] || !bias[l]) return SA_ERR_INVALID;
+    if (!ws || ws_bytes < sa_group_mlp_max_ws_bytes(b, m, ns)) return SA_ERR_INVALID;
+    const long nballs = (long)b * m;
+    if (nballs >= (1l << 24) || ns > 8 * sa::kPlanMaxOrd) return SA_ERR_UNSUPPORTED;   // plan entry fields
+    const long gmax = sa_plan_max_granules(nballs, ns);
+    const long max_tiles = (gmax + 3) / 4;
+    if (max_tiles > 0x0FFFFFFFl) return SA_ERR_UNSUPPORTED;
+    int *hdr = (int *)ws, *gran = hdr + sa::kPlanHeaderInts;
+    // ---- the row plan of this call
+    {
+        hipLaunchKernelGGL(mlp_plan_reset_kernel, dim3(1), dim3(64), 0, stream, hdr);
+        const int per = kPlanThreads * kPlanBallsPerThread;
+        hipLaunchKernelGGL(mlp_plan_kernel, dim3((unsigned)((nballs + per - 1) / per)), dim3(kPlanThreads), 0, stream,
+                           cnt, (int)nballs, ns, flags & 1, hdr, gran, out, out_stride, out_off, dims[nl]);
+        SA_CHECK_LAUNCH();
+    }
     {
         int st = SA_OK;
         if (sa_rowwave_try(b, n, m, ns, c, xyz, feat, new_xyz, idx, cnt, nl, dims, wpack, bias, out, out_stride,
-                           out_off, stream, &st))
+                           out_off, hdr, gran, max_tiles, stream, &st))
             return st;
     }
     MlpParams P{};
     P.xyz = xyz; P.feat = feat; P.new_xyz = new_xyz; P.idx = idx; P.cnt = cnt; P.out = out;
-    P.n = n; P.m = m; P.ns = ns; P.C = c; P.nballs = (long)b * m;
+    P.n = n; P.m = m; P.ns = ns; P.C = c; P.nballs = nballs;
     P.out_stride = out_stride; P.out_off = out_off; P.nl = nl;
-    P.rp = ns <= 8 ? 8 : (ns <= 16 ? 16 : roundup(ns, 32));
+    P.hdr = hdr; P.gran = gran;
     int wA = roundup(dims[0], 16), wB = 0;
     for (int l = 0; l < nl; ++l) {
-        if (dims[l + 1] <= 0 || !wpack[l] || !bias[l]) return SA_ERR_INVALID;
         P.L[l].w = (const uint4 *)wpack[l];
         P.L[l].bias = bias[l];
         P.L[l].K = dims[l];
@@ -986,16 +1071,15 @@ extern "C" int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float 
     }
     P.strideA = wA * 4 + 16;
     P.strideB = wB * 4 + 16;
-    P.pool_off = kRows * (P.strideA + P.strideB);
-    const int bpi = P.rp <= 32 ? 32 / P.rp : 1;
-    const size_t lds = (size_t)P.pool_off + (size_t)bpi * P.L[nl - 1].NT * 32 * sizeof(float);
+    P.lds_bytes = kRows * (P.strideA + P.strideB);
+    const size_t lds = (size_t)P.lds_bytes;
     if (lds > 160 * 1024) return SA_ERR_UNSUPPORTED;
     if (lds > 48 * 1024) {   // opt in to large dynamic LDS; a refusal surfaces at the launch check below
         (void)hipFuncSetAttribute((const void *)group_mlp_max_kernel<kNW>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipGetLastError();
     }
-    const long nitems = (P.nballs + bpi - 1) / bpi;
+    const long nitems = max_tiles;             // the densest plan; workgroups past the planned tiles leave at once
     int max_nt = 0;
     for (int l = 0; l < nl; ++l) if (P.L[l].NT > max_nt) max_nt = P.L[l].NT;
     static const int narrow_nt = getenv("SA_MLP_NARROW_NT") ? atoi(getenv("SA_MLP_NARROW_NT")) : 4;  // tuning knob
@@ -1014,8 +1098,6 @@ extern "C" int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float 
     if (use_wide && P.L[nl - 1].NT <= 4 * kNW) {
         WideParams WP{};
         WP.M = P;
-        WP.M.rp = ns <= 8 ? 8 : (ns <= 16 ? 16 : (ns <= 32 ? 32 : roundup(ns, 64)));
-        const int wbpi = WP.M.rp <= 64 ? 64 / WP.M.rp : 1;
         const int nt_h = nl >= 2 ? P.L[nl - 2].NT : 0;            // tiles of the last hidden layer
         for (int nch = 1; nch <= (nt_h > 0 ? nt_h : 1); nch *= 2) {
             const int tpc = nt_h > 0 ? (nt_h + nch - 1) / nch : 0;
@@ -1026,15 +1108,15 @@ extern "C" int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float 
             }
             WP.M.strideA = wwA * 4 + 16;
             WP.M.strideB = wwB * 4 + 16;
-            WP.M.pool_off = kWRows * (WP.M.strideA + WP.M.strideB);
-            const size_t wlds = (size_t)WP.M.pool_off + (size_t)wbpi * P.L[nl - 1].NT * 32 * sizeof(float);
+            WP.M.lds_bytes = kWRows * (WP.M.strideA + WP.M.strideB);
+            const size_t wlds = (size_t)WP.M.lds_bytes;
             if (wlds <= 156 * 1024) {
                 WP.tiles_per_chunk = tpc;
                 WP.nchunks = nt_h > 0 ? (nt_h + tpc - 1) / tpc : 1;
                 (void)hipFuncSetAttribute((const void *)group_mlp_wide_kernel,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);
                 (void)hipGetLastError();
-                const long witems = (WP.M.nballs + wbpi - 1) / wbpi;
+                const long witems = (max_tiles + 1) / 2;
                 const int grid = (int)(witems < 16384 ? witems : 16384);
                 hipLaunchKernelGGL(group_mlp_wide_kernel, dim3(grid), dim3(kThreads), wlds, stream, WP);
                 SA_CHECK_LAUNCH();

@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "sa_common.h"
+#include "mlp_plan.h"
 
 namespace {
 
@@ -33,13 +34,11 @@ struct RwParams {
     int n, m, ns, C;
     long nballs;
     int out_stride, out_off;
-    int rp;        // rows per ball after padding: 8, 16, 32 or a multiple of 32
-    int rp_shift;  // log2(rp) when rp <= 32
     int m_shift;   // log2(m) when m is a power of two, else -1
     float inv_m;
     int N3;        // true output channels of the last layer
-    int ntiles;    // 32-row tiles
-    int tpu;       // tiles per pooling unit (rp / 32 when rp > 32, else 1)
+    const int *gran;   // row plan (mlp_plan.h): granule entries, 4 per 32-row tile
+    const int *hdr;    // hdr[0] = number of granules (written by mlp_plan_kernel earlier on the stream)
 };
 
 __device__ __forceinline__ f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) {
@@ -80,18 +79,16 @@ __device__ unsigned long long g_rw_prof[65536 * 8];
 #define RW_FLUSH(wave)
 #endif
 
-struct RowRef { int pt, ball, cnt; };   // source point (flat index), ball and its count for this lane's row
+struct RowRef { int pt, ball, cnt, ent; };   // source point (flat index), ball, its count and the plan entry of this lane's row
 
 // All element offsets on this path fit 32 bits (checked on the host), so every access is base pointer (SGPR
 // pair) + 32-bit lane offset: no 64-bit address arithmetic on the VALU.
-// unit u (a ball when rp > 32, else the tile itself), tile tp of the unit, row of the tile -> source point;
-// the index and count loads issue together
-__device__ __forceinline__ RowRef load_row_ref(const RwParams &P, int u, int tp, int row) {
-    int ball, s;
-    if (P.rp <= 32) { const int bl = row >> P.rp_shift; ball = (u << (5 - P.rp_shift)) + bl; s = row - (bl << P.rp_shift); }
-    else { ball = u; s = tp * 32 + row; }
-    if (ball >= (int)P.nballs) ball = (int)P.nballs - 1;
-    if (s >= P.ns) s = 0;                                   // padded rows repeat sample 0
+// tile, row of the tile -> plan entry (granule row>>3 of the tile) -> ball, sample -> source point; the index and
+// count loads issue together.  Granules past the end of the plan (ent < 0) read ball 0 and are never written.
+__device__ __forceinline__ RowRef load_row_ref(const RwParams &P, int ngran, int tile, int row) {
+    const int ent = sa::plan_entry(P.gran, ngran, tile * 4 + (row >> 3));
+    const int ball = ent >= 0 ? sa::plan_ball(ent) : 0;
+    const int s = sa::plan_sample(ent, row & 7, P.ns);
     const int a_raw = P.idx[(unsigned)(ball * P.ns + s)];
     const int c = P.cnt[(unsigned)ball];
     int frame;
@@ -103,6 +100,7 @@ __device__ __forceinline__ RowRef load_row_ref(const RwParams &P, int u, int tp,
     }
     RowRef r;
     r.cnt = c;
+    r.ent = ent;
     r.ball = ball;
     r.pt = frame * P.n + (c > 0 ? a_raw : 0);               // layers_util.py:157-159
     return r;
@@ -165,26 +163,6 @@ __device__ __forceinline__ void acc_to_frags(const f32x16 &acc, int ct, uint4 (&
     }
 }
 
-// max over the rows of each ball for one 32-row tile (D form: reg r of lane (col, h) = row (r&3)+8*(r>>2)+4h)
-__device__ __forceinline__ void tile_ball_max(const f32x16 &a, int rp, float (&bm)[4]) {
-    float qm[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float a0 = sa::fmax_nn(a[4 * q], a[4 * q + 1]);
-        const float a1 = sa::fmax_nn(a[4 * q + 2], a[4 * q + 3]);
-        const float x = sa::fmax_nn(a0, a1);
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-        qm[q] = sa::fmax_nn(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-    }
-    // selects, not branches: branches turn bm[] into a private-memory object
-    const float m01 = sa::fmax_nn(qm[0], qm[1]), m23 = sa::fmax_nn(qm[2], qm[3]);
-    const float m = sa::fmax_nn(m01, m23);
-    bm[0] = rp == 8 ? qm[0] : (rp == 16 ? m01 : m);
-    bm[1] = rp == 8 ? qm[1] : (rp == 16 ? m23 : 0.0f);
-    bm[2] = rp == 8 ? qm[2] : 0.0f;
-    bm[3] = rp == 8 ? qm[3] : 0.0f;
-}
-
 // hidden layer: KS k-steps of input fragments (ih, il) -> NT output tiles -> next layer's fragments (oh, ol)
 template <int KS, int NT, int KSN>
 __device__ __forceinline__ void hidden_layer(const uint4 *W, const float *bias, const uint4 (&ih)[KS],
@@ -233,6 +211,9 @@ __global__ __launch_bounds__(NW * 64, WPE) void mlp_rw_kernel(RwParams P) {
     float *b0 = (float *)(W2 + nW2), *b1 = b0 + NT1 * 32, *b2 = b1 + NT2 * 32;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ngran = __builtin_amdgcn_readfirstlane(P.hdr[0]);
+    const int ntiles = (ngran + 3) >> 2;
+    if ((int)blockIdx.x * NW >= ntiles) return;          // persistent grid sized for the densest plan: no work, no copy
     RW_T0();
     // one-time copy of the packed weights and biases: all loads of a layer are issued before its stores
     {
@@ -263,37 +244,37 @@ __global__ __launch_bounds__(NW * 64, WPE) void mlp_rw_kernel(RwParams P) {
     //  changed the measured time of these kernels: it tracks MFMA-busy + VALU-issue cycles.)
     const int row = lane & 31, half = lane >> 5;
     const int gw = blockIdx.x * NW + w, nwaves = gridDim.x * NW;
-    const int nunits = P.ntiles / P.tpu;
-    if (gw >= nunits) return;
-    // this wave's tiles: units gw, gw + nwaves, ... ; tiles 0 .. tpu-1 of each.  (u, tp) cursors for the three
-    // pipeline stages: compute (uc, tc), feature loads (one tile ahead), index loads (two ahead).
-    auto advance = [&](int &u, int &tp) {
-        if (tp + 1 < P.tpu) ++tp;
-        else if (u + nwaves < nunits) { u += nwaves; tp = 0; }      // past the end: stay on the last tile
-    };
-    int uc = gw, tc = 0, uf = gw, tf = 0;
-    advance(uf, tf);
-    int ui = uf, ti = tf;
-    advance(ui, ti);
+    if (gw >= ntiles) return;
+    // this wave's tiles: gw, gw + nwaves, ...  Cursors of the three pipeline stages: compute (tc), feature loads (one
+    // tile ahead), index loads (two ahead); past the end they stay on the last tile.
+    auto advance = [&](int &t) { if (t + nwaves < ntiles) t += nwaves; };
+    int tc = gw, tf = gw;
+    advance(tf);
+    int ti = tf;
+    advance(ti);
 
     float raw[KS0][8];
-    RowRef cur = load_row_ref(P, uc, tc, row);
+    RowRef cur = load_row_ref(P, ngran, tc, row);
     {
         const RowTail tl = load_row_tail<TAILF>(P, cur);
 #pragma unroll
         for (int ks = 0; ks < KS0; ++ks) load_group(P, cur, tl, 2 * ks + half, raw[ks]);
     }
-    RowRef nxt = load_row_ref(P, uf, tf, row);
-    float pooled[NT3][4];
+    RowRef nxt = load_row_ref(P, ngran, tf, row);
 
     for (bool more = true; more;) {
-        const int T_u = uc, tp = tc;
-        more = tc + 1 < P.tpu || uc + nwaves < nunits;
+        more = tc + nwaves < ntiles;
         // ---- this tile's input as B-operand fragments
         uint4 h0[KS0], l0[KS0];
 #pragma unroll
         for (int ks = 0; ks < KS0; ++ks) split8(raw[ks], h0[ks], l0[ks]);
-        const int cnt_row = cur.cnt;
+        // the tile's four plan entries and ball counts, wave-uniform (rows 0, 8, 16, 24)
+        int ent[4], cn[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            ent[g] = __builtin_amdgcn_readlane(cur.ent, 8 * g);
+            cn[g] = __builtin_amdgcn_readlane(cur.cnt, 8 * g);
+        }
         RW_COUNT();
         RW_TICK(1)
         // ---- loads of the next tile (features) and of the one after (indices), then pin them above the math
@@ -303,10 +284,10 @@ __global__ __launch_bounds__(NW * 64, WPE) void mlp_rw_kernel(RwParams P) {
 #pragma unroll
             for (int ks = 0; ks < KS0; ++ks) load_group(P, cur, tl, 2 * ks + half, raw[ks]);
         }
-        nxt = load_row_ref(P, ui, ti, row);
-        advance(uc, tc);
-        advance(uf, tf);
-        advance(ui, ti);
+        nxt = load_row_ref(P, ngran, ti, row);
+        advance(tc);
+        advance(tf);
+        advance(ti);
         __builtin_amdgcn_sched_barrier(0);
         RW_TICK(2)
 
@@ -316,7 +297,8 @@ __global__ __launch_bounds__(NW * 64, WPE) void mlp_rw_kernel(RwParams P) {
         uint4 h2[KS2], l2[KS2];
         hidden_layer<KS1, NT2, KS2>(W1, b1, h1, l1, h2, l2, lane);
         RW_TICK(4)
-        // ---- last layer (D form) + max over the rows of each ball
+        // ---- last layer (D form), max over the rows of each granule, relu(max + bias) written per ball run
+        //      (layers_util.py:178-181)
         constexpr int TG = NT3 >= 2 ? 2 : 1;
 #pragma unroll
         for (int ct0 = 0; ct0 < NT3; ct0 += TG) {
@@ -341,41 +323,14 @@ __global__ __launch_bounds__(NW * 64, WPE) void mlp_rw_kernel(RwParams P) {
 #pragma unroll
             for (int tt = 0; tt < TG; ++tt) {
                 if (ct0 + tt < NT3) {
-                    float bm[4];
-                    tile_ball_max(acc[tt], P.rp, bm);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        pooled[ct0 + tt][g] = tp == 0 ? bm[g] : sa::fmax_nn(pooled[ct0 + tt][g], bm[g]);
+                    float qm[4];
+                    sa::granule_max(acc[tt], qm);
+                    const int c = (ct0 + tt) * 32 + (lane & 31);
+                    sa::pool_write_tile(qm, ent, cn, b2[c], c, P.N3, P.out, P.out_stride, P.out_off, lane);
                 }
             }
         }
         RW_TICK(5)
-        // ---- write out after the last tile of the unit: relu(max + bias), zero for empty balls
-        //      (layers_util.py:178-181)
-        if (tp == P.tpu - 1) {
-            const int nb = P.rp <= 32 ? 32 >> P.rp_shift : 1;
-            const int ball0 = P.rp <= 32 ? T_u * nb : T_u;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (g < nb) {
-                    const int ball = ball0 + g;
-                    const int cg = __builtin_amdgcn_readlane(cnt_row, P.rp <= 32 ? g * P.rp : 0);
-                    if (ball < (int)P.nballs && lane < 32) {
-#pragma unroll
-                        for (int ct = 0; ct < NT3; ++ct) {
-                            const int c = ct * 32 + lane;
-                            if (c < P.N3) {
-                                float v = pooled[ct][g] + b2[c];
-                                v = v > 0.0f ? v : 0.0f;
-                                if (cg <= 0) v = 0.0f;
-                                P.out[(unsigned)(ball * P.out_stride + P.out_off + c)] = v;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        RW_TICK(6)
     }
     RW_FLUSH(gw)
 }
@@ -483,7 +438,7 @@ __device__ __forceinline__ void load_bias_tile(const float *bias, int ct, int ha
     }
 }
 
-template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF, int DEPTH, int NBALL>
+template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF, int DEPTH>
 __global__ __launch_bounds__(NW * 64, WPE) void mlp_rs_kernel(RwParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KT0 = NT1 * KS0, KT1 = NT2 * KS1, KT2 = NT3 * KS2, TOT = KT0 + KT1 + KT2;
@@ -500,21 +455,24 @@ __global__ __launch_bounds__(NW * 64, WPE) void mlp_rs_kernel(RwParams P) {
     const int row = lane & 31, half = lane >> 5;
     X.w = w; X.lane = lane; X.abase = 0;
 
+    const int ngran = __builtin_amdgcn_readfirstlane(P.hdr[0]);
+    const int ntiles = (ngran + 3) >> 2;
+    if ((int)blockIdx.x * NW >= ntiles) return;          // persistent grid sized for the densest plan
+
     for (int i = tid; i < NT1 * 32; i += NW * 64) b0[i] = P.bias[0][i];
     for (int i = tid; i < NT2 * 32; i += NW * 64) b1[i] = P.bias[1][i];
     for (int i = tid; i < NT3 * 32; i += NW * 64) b2[i] = P.bias[2][i];
     RW_T0();
 
-    // every wave of the grid runs the same number of tiles (barriers inside): clamped repeats at the end
-    const int nunits = P.ntiles / P.tpu;
+    // every wave of a workgroup runs the same number of tiles (barriers inside); tiles past the end resolve to
+    // invalid plan entries (ball 0 is read, nothing is written)
     const int nwaves = gridDim.x * NW, gw = blockIdx.x * NW + w;
-    const int npass = ((nunits + nwaves - 1) / nwaves) * P.tpu;
-    int uc = gw, tc = 0, uf = gw, tf = 0;
-    if (tf + 1 < P.tpu) ++tf; else { uf += nwaves; tf = 0; }
+    const int npass = (ntiles - (int)blockIdx.x * NW + nwaves - 1) / nwaves;
+    int tc = gw, tf = gw + nwaves;
 
     // ---- prologue: chunk 0 into slot 0, chunks 1 .. DEPTH staged; first tile's rows and features
     rs_issue_chunk<G, NW, PPW>(P, X, stage[0], 0);
-    RowRef cur = load_row_ref(P, uc < nunits ? uc : nunits - 1, tc, row);
+    RowRef cur = load_row_ref(P, ngran, tc, row);
     rs_store_stage<G, NW, PPW>(X, stage[0], 0);
 #pragma unroll
     for (int k = 1; k <= DEPTH; ++k) rs_issue_chunk<G, NW, PPW>(P, X, stage[k % DEPTH], k % kRsCPP);
@@ -524,17 +482,20 @@ __global__ __launch_bounds__(NW * 64, WPE) void mlp_rs_kernel(RwParams P) {
 #pragma unroll
         for (int ks = 0; ks < KS0; ++ks) load_group(P, cur, tl, 2 * ks + half, raw[ks]);
     }
-    RowRef nxt = load_row_ref(P, uf < nunits ? uf : nunits - 1, tf, row);
-    float pooled[NT3][NBALL];
+    RowRef nxt = load_row_ref(P, ngran, tf, row);
 
     RW_TICK(0)
     for (int q = 0; q < npass; ++q) {
-        const int T_u = uc, tp = tc;
         RW_COUNT();
         uint4 h0[KS0], l0[KS0];
 #pragma unroll
         for (int ks = 0; ks < KS0; ++ks) split8(raw[ks], h0[ks], l0[ks]);
-        const int cnt_row = cur.cnt;
+        int ent[4], cn[4];                       // the tile's plan entries / ball counts, wave-uniform
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            ent[g] = __builtin_amdgcn_readlane(cur.ent, 8 * g);
+            cn[g] = __builtin_amdgcn_readlane(cur.cnt, 8 * g);
+        }
         RW_TICK(1)
 
         // ---- hidden layer 0
@@ -557,51 +518,30 @@ __global__ __launch_bounds__(NW * 64, WPE) void mlp_rs_kernel(RwParams P) {
             acc_to_frags<KS2>(ae, ct, h2, l2);
         }
         RW_TICK(3)
-        // ---- last layer (D form) + max over the rows of each ball
+        // ---- last layer (D form), granule maxima, relu(max + bias) written per ball run (layers_util.py:178-181)
 #pragma unroll
         for (int ct = 0; ct < NT3; ++ct) {
             f32x16 ae;
 #pragma unroll
             for (int r = 0; r < 16; ++r) ae[r] = 0.0f;
             rs_tile_mma<KS2, G, NW, PPW, DEPTH, false>(P, X, stage, h2, l2, KT0 + KT1 + ct * KS2, ae);
-            float bm[4];
-            tile_ball_max(ae, P.rp, bm);
-#pragma unroll
-            for (int g = 0; g < NBALL; ++g) pooled[ct][g] = tp == 0 ? bm[g] : sa::fmax_nn(pooled[ct][g], bm[g]);
+            float qm[4];
+            sa::granule_max(ae, qm);
+            const int c = ct * 32 + (lane & 31);
+            sa::pool_write_tile(qm, ent, cn, b2[c], c, P.N3, P.out, P.out_stride, P.out_off, lane);
         }
         RW_TICK(4)
-        // ---- write out after the last tile of the unit
-        if (tp == P.tpu - 1 && T_u < nunits) {
-            const int ball0 = P.rp <= 32 ? T_u * NBALL : T_u;
-#pragma unroll
-            for (int g = 0; g < NBALL; ++g) {
-                const int ball = ball0 + g;
-                const int cg = __builtin_amdgcn_readlane(cnt_row, P.rp <= 32 ? g * P.rp : 0);
-                if (ball < (int)P.nballs && lane < 32) {
-#pragma unroll
-                    for (int ct = 0; ct < NT3; ++ct) {
-                        const int c = ct * 32 + lane;
-                        if (c < P.N3) {
-                            float v = pooled[ct][g] + b2[c];
-                            v = v > 0.0f ? v : 0.0f;
-                            if (cg <= 0) v = 0.0f;
-                            P.out[(unsigned)(ball * P.out_stride + P.out_off + c)] = v;
-                        }
-                    }
-                }
-            }
-        }
         // ---- the next tile's rows: issued here, converted at the top of the next iteration (the other wave of
         //      the SIMD works under their latency; during the last layer the register budget has no room for them)
-        if (tc + 1 < P.tpu) ++tc; else { uc += nwaves; tc = 0; }
-        if (tf + 1 < P.tpu) ++tf; else { uf += nwaves; tf = 0; }
+        tc += nwaves;
+        tf += nwaves;
         cur = nxt;
         {
             const RowTail tl = load_row_tail<TAILF>(P, cur);
 #pragma unroll
             for (int ks = 0; ks < KS0; ++ks) load_group(P, cur, tl, 2 * ks + half, raw[ks]);
         }
-        nxt = load_row_ref(P, uf < nunits ? uf : nunits - 1, tf, row);
+        nxt = load_row_ref(P, ngran, tf, row);
         RW_TICK(5)
     }
     RW_FLUSH(gw)
@@ -622,15 +562,14 @@ int num_cus() {
 }
 
 template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF>
-int launch_rw(const RwParams &P, int wgs_per_cu, hipStream_t stream) {
+int launch_rw(const RwParams &P, long max_tiles, int wgs_per_cu, hipStream_t stream) {
     constexpr size_t lds = (size_t)(NT1 * KS0 + NT2 * KS1 + NT3 * KS2) * 2048 + (size_t)(NT1 + NT2 + NT3) * 128;
     auto kern = mlp_rw_kernel<KS0, NT1, KS1, NT2, KS2, NT3, NW, WPE, TAILF>;
     if (lds > 48 * 1024) {
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipGetLastError();
     }
-    const long nunits = P.ntiles / P.tpu;
-    long grid = (nunits + NW - 1) / NW;
+    long grid = (max_tiles + NW - 1) / NW;      // the densest plan; workgroups without a tile leave at once
     const long cap = (long)num_cus() * wgs_per_cu;
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, stream, P);
@@ -638,17 +577,16 @@ int launch_rw(const RwParams &P, int wgs_per_cu, hipStream_t stream) {
     return SA_OK;
 }
 
-template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF, int DEPTH, int NBALL>
-int launch_rs(const RwParams &P, int wgs_per_cu, hipStream_t stream) {
+template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF, int DEPTH>
+int launch_rs(const RwParams &P, long max_tiles, int wgs_per_cu, hipStream_t stream) {
     constexpr int G = (NT1 * KS0 + NT2 * KS1 + NT3 * KS2) / kRsCPP;
     constexpr size_t lds = (size_t)2 * 2 * G * 1024 + (size_t)(NT1 + NT2 + NT3) * 128;
-    auto kern = mlp_rs_kernel<KS0, NT1, KS1, NT2, KS2, NT3, NW, WPE, TAILF, DEPTH, NBALL>;
+    auto kern = mlp_rs_kernel<KS0, NT1, KS1, NT2, KS2, NT3, NW, WPE, TAILF, DEPTH>;
     if (lds > 48 * 1024) {
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipGetLastError();
     }
-    const long nunits = P.ntiles / P.tpu;
-    long grid = (nunits + NW - 1) / NW;
+    long grid = (max_tiles + NW - 1) / NW;      // the densest plan; workgroups without a tile leave at once
     const long cap = (long)num_cus() * wgs_per_cu;
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, stream, P);
@@ -662,8 +600,8 @@ int launch_rs(const RwParams &P, int wgs_per_cu, hipStream_t stream) {
 // caller should take the generic kernel.
 int sa_rowwave_try(int b, int n, int m, int ns, int c, const float *xyz, const float *feat, const float *new_xyz,
                    const int *idx, const int *cnt, int nl, const int *dims, const void *const *wpack,
-                   const float *const *bias, float *out, int out_stride, int out_off, hipStream_t stream,
-                   int *st) {
+                   const float *const *bias, float *out, int out_stride, int out_off, const int *plan_hdr,
+                   const int *plan_gran, long max_tiles, hipStream_t stream, int *st) {
     static const bool enabled = !(getenv("SA_MLP_ROWWAVE") && atoi(getenv("SA_MLP_ROWWAVE")) == 0);
     if (!enabled || nl != 3) return 0;
     if (!(c == 1 || (c > 0 && (c & 7) == 0))) return 0;      // input layouts the in-register gather handles
@@ -681,21 +619,16 @@ int sa_rowwave_try(int b, int n, int m, int ns, int c, const float *xyz, const f
     for (int l = 0; l < 3; ++l) { P.w[l] = (const uint4 *)wpack[l]; P.bias[l] = bias[l]; }
     P.n = n; P.m = m; P.ns = ns; P.C = c; P.nballs = (long)b * m;
     P.out_stride = out_stride; P.out_off = out_off;
-    P.rp = ns <= 8 ? 8 : (ns <= 16 ? 16 : roundup(ns, 32));
     P.N3 = dims[3];
-    P.rp_shift = P.rp == 8 ? 3 : (P.rp == 16 ? 4 : 5);
+    P.hdr = plan_hdr; P.gran = plan_gran;
     P.m_shift = -1;
     for (int sft = 0; sft < 31; ++sft) if (m == (1 << sft)) P.m_shift = sft;
     P.inv_m = 1.0f / (float)m;
-    P.tpu = P.rp <= 32 ? 1 : P.rp / 32;
-    const int bpt = P.rp <= 32 ? 32 / P.rp : 1;
-    const long ntiles = P.rp <= 32 ? (P.nballs + bpt - 1) / bpt : P.nballs * P.tpu;
-    if (ntiles > 0x7FFFFFFFl) return 0;
-    P.ntiles = (int)ntiles;
+    if (max_tiles > 0x0FFFFFFFl) return 0;
 #define SA_RW(K0, N1, K1, N2, K2, N3_, NW_, WPE_, WGS)                                              \
     if (KS0 == K0 && NT1 == N1 && KS1 == K1 && NT2 == N2 && KS2 == K2 && NT3 == N3_) {             \
-        *st = c == 1 ? launch_rw<K0, N1, K1, N2, K2, N3_, NW_, WPE_, 1>(P, WGS, stream)             \
-                     : launch_rw<K0, N1, K1, N2, K2, N3_, NW_, WPE_, 0>(P, WGS, stream);            \
+        *st = c == 1 ? launch_rw<K0, N1, K1, N2, K2, N3_, NW_, WPE_, 1>(P, max_tiles, WGS, stream)             \
+                     : launch_rw<K0, N1, K1, N2, K2, N3_, NW_, WPE_, 0>(P, max_tiles, WGS, stream);            \
         return 1;                                                                                   \
     }
     SA_RW(1, 1, 1, 1, 1, 1, 4, 4, 4)      // 4 -> 16 -> 16 -> 32      (layer1 scales 0/1, configs[0])
@@ -711,9 +644,7 @@ int sa_rowwave_try(int b, int n, int m, int ns, int c, const float *xyz, const f
     static const bool stream_enabled = !(getenv("SA_MLP_ROWSTREAM") && atoi(getenv("SA_MLP_ROWSTREAM")) == 0);
 #define SA_RS(K0, N1, K1, N2, K2, N3_, NW_, WPE_, WGS, D_)                                          \
     if (stream_enabled && contiguous && c != 1 && KS0 == K0 && NT1 == N1 && KS1 == K1 && NT2 == N2 && KS2 == K2 && NT3 == N3_) { \
-        *st = P.rp >= 32 ? launch_rs<K0, N1, K1, N2, K2, N3_, NW_, WPE_, 0, D_, 1>(P, WGS, stream)   \
-            : (P.rp == 16 ? launch_rs<K0, N1, K1, N2, K2, N3_, NW_, WPE_, 0, D_, 2>(P, WGS, stream)  \
-                          : launch_rs<K0, N1, K1, N2, K2, N3_, NW_, WPE_, 0, D_, 4>(P, WGS, stream)); \
+        *st = launch_rs<K0, N1, K1, N2, K2, N3_, NW_, WPE_, 0, D_>(P, max_tiles, WGS, stream);       \
         return 1;                                                                                   \
     }
     // 8 waves (2 per SIMD, 256 registers each), 1 workgroup per CU; staging depth as the register budget allows

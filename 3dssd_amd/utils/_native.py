@@ -29,7 +29,8 @@ SIGNATURES = {
     "sa_calc_square_dist_split_ws": [_c_int] * 5 + [_vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sa_query_ball_point_multi": [_c_int] * 4 + [_vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _vp],
     "sa_query_ball_point_grid": [_c_int] * 4 + [_vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _vp, _vp],
-    "sa_group_mlp_max": [_c_int] * 5 + [_vp] * 5 + [_c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp],
+    "sa_group_mlp_max": [_c_int] * 5 + [_vp] * 5 + [_c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp,
+                         ctypes.c_size_t, _c_int, _vp],
     "sa_dense": [_c_long, _c_int, _c_int, _vp, _vp, _vp, _c_int, _vp, _vp],
     "sa_decode_anchor_free": [_c_int] * 4 + [_vp] * 7,
     "sa_boxes_to_bev": [_c_long, _vp, _vp, _vp],
@@ -80,6 +81,8 @@ def lib():
             fn.restype = _c_int
         h.sa_query_ball_point_grid_ws_bytes.argtypes = [_c_int, _c_int, _c_int]     # the one non-status function
         h.sa_query_ball_point_grid_ws_bytes.restype = ctypes.c_size_t
+        h.sa_group_mlp_max_ws_bytes.argtypes = [_c_int] * 3
+        h.sa_group_mlp_max_ws_bytes.restype = ctypes.c_size_t
         h.sa_calc_square_dist_ws_bytes.argtypes = [_c_int] * 5
         h.sa_calc_square_dist_ws_bytes.restype = ctypes.c_size_t
         h.sa_host_crc32c.argtypes = [_vp, ctypes.c_size_t, ctypes.c_uint32]          # host helper: returns the CRC
@@ -99,3 +102,10 @@ def check(status, what):
 def current_stream():
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+def mlp_plan_ws(b, m, ns, device):
+    """Device scratch for the row plan of one sa_group_mlp_max call: (int32 tensor, size in bytes)."""
+    import torch
+    nbytes = int(lib().sa_group_mlp_max_ws_bytes(int(b), int(m), int(ns)))
+    return torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=device), nbytes

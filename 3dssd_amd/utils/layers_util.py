@@ -26,6 +26,8 @@ from .tf_ops.grouping.tf_grouping import query_ball_point, query_ball_point_dila
 # config (configs/kitti/3dssd/3dssd.yaml:39,44); set by the backbone driver.
 AGGREGATION_SA_FEATURE = True
 # frames with at least this many points go through the grid ball query (csrc/ballquery_grid.hip)
+# sa_group_mlp_max flags: 0 = evaluate only the distinct rows of every ball (default), 1 = all nsample rows (A/B)
+MLP_PLAN_FLAGS = int(__import__("os").environ.get("SA_MLP_DENSE_PLAN", "0"))
 GRID_BALL_QUERY_MIN_N = int(__import__("os").environ.get("SA_GRID_BQ_MIN_N", "512"))
 MAX_TRANSLATE_RANGE = (-3.0, -2.0, -3.0)
 
@@ -211,10 +213,12 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
             dims = (ctypes.c_int * (nl + 1))(*([c_feat + 3] + [l.N for l in ls]))
             wp = (ctypes.c_void_p * nl)(*[l.w.data_ptr() for l in ls])
             bp = (ctypes.c_void_p * nl)(*[l.bias.data_ptr() for l in ls])
+            plan, plan_bytes = N.mlp_plan_ws(bs, m, int(nsample_list[i]), dev)    # row plan: distinct rows only
             st = lib.sa_group_mlp_max(bs, n_all, m, int(nsample_list[i]), c_feat, xyz.data_ptr(),
                                       points.data_ptr(), new_xyz.data_ptr(), idx_list[i].data_ptr(),
                                       cnt_list[i].data_ptr(), nl, dims, wp, bp,
-                                      new_points_concat.data_ptr(), ctot, off, stream)
+                                      new_points_concat.data_ptr(), ctot, off, plan.data_ptr(), plan_bytes,
+                                      MLP_PLAN_FLAGS, stream)
             N.check(st, "group_mlp_max")
             off += ls[-1].N
         if AGGREGATION_SA_FEATURE:                                          # :184-185

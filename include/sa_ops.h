@@ -110,10 +110,16 @@ int sa_query_ball_point_grid(int b, int n, int m, int nbands, const float *rmin,
  * (conv1x1 + folded BN + ReLU), max over nsample, empty-ball mask (layers_util.py:157-181).
  * dims[0] = c+3, dims[l+1] = output channels of layer l; wpack[l]/bias[l] device pointers in the
  * layouts documented in 3dssd_amd/csrc/mlp.hip; out[(b*m+j)*out_stride + out_off + ch]. */
+ * Only the DISTINCT rows of a ball are evaluated: the ball query pads a ball of cnt < nsample points with copies of
+ * its first hit (tf_grouping_g.cu:245-248), those rows give identical outputs and the max ignores them -- same
+ * result bit for bit, a fraction of the work on KITTI-like clouds (3dssd_amd/csrc/mlp_plan.h).  ws: caller-owned
+ * device scratch of sa_group_mlp_max_ws_bytes(b, m, ns) bytes (the per-call row plan).  flags bit 0: evaluate all
+ * nsample rows of every ball instead (A/B measurements). */
+unsigned long sa_group_mlp_max_ws_bytes(int b, int m, int ns);
 int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float *xyz, const float *feat,
                      const float *new_xyz, const int *idx, const int *cnt, int nl, const int *dims,
                      const void *const *wpack, const float *const *bias, float *out, int out_stride,
-                     int out_off, sa_stream_t stream);
+                     int out_off, void *ws, unsigned long ws_bytes, int flags, sa_stream_t stream);
 
 /* y[rows,N] = act(x[rows,K] W + b): tf_util.conv1d 1x1 + folded BN (tf_util.py:51-124). */
 int sa_dense(long rows, int K, int N, const float *x, const void *wpack, const float *bias, int relu,

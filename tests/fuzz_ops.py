@@ -138,6 +138,9 @@ def case_mlp(rng):
     new_xyz = np.ascontiguousarray(xyz[:, rng.integers(0, n, m)] + rng.normal(0, 0.1, (b, m, 3)), np.float32)
     idx = rng.integers(0, n, (b, m, ns)).astype(np.int32)
     cnt = rng.integers(0, ns + 1, (b, m)).astype(np.int32)
+    dense = int(rng.integers(0, 2))                  # 1: all nsample rows count; 0: ball-query format (rows padded
+    if not dense:                                    # with the first hit), only the distinct rows are evaluated
+        idx = np.where(np.arange(ns)[None, None, :] >= np.maximum(cnt, 1)[:, :, None], idx[:, :, :1], idx)
     cin = [c + 3] + dims[:-1]
     ws = [rng.normal(0, 1.0 / np.sqrt(k), (k, o)).astype(np.float32) for k, o in zip(cin, dims)]
     bs = [rng.normal(0, 0.1, o).astype(np.float32) for o in dims]
@@ -146,10 +149,11 @@ def case_mlp(rng):
     dm = (ctypes.c_int * (nl + 1))(*([c + 3] + dims))
     tx, tn, ti, tc = t(xyz), t(new_xyz), t(idx), t(cnt)
     tf = t(feat) if c else None
+    plan, plan_bytes = N.mlp_plan_ws(b, m, ns, dev)
     st = N.lib().sa_group_mlp_max(b, n, m, ns, c, tx.data_ptr(), tf.data_ptr() if c else None, tn.data_ptr(), ti.data_ptr(),
                                   tc.data_ptr(), nl, dm, (ctypes.c_void_p * nl)(*[l.w.data_ptr() for l in layers]),
                                   (ctypes.c_void_p * nl)(*[l.bias.data_ptr() for l in layers]), out.data_ptr(), dims[-1], 0,
-                                  N.current_stream())
+                                  plan.data_ptr(), plan_bytes, dense, N.current_stream())
     if st != 0:
         return "group_mlp_max status %d %s" % (st, (b, n, m, c, ns, dims))
     torch.cuda.synchronize()
@@ -293,6 +297,9 @@ def case_mlp_big(rng):
     new_xyz = np.ascontiguousarray(xyz[:, rng.integers(0, n, m)], np.float32)
     idx = rng.integers(0, n, (b, m, ns)).astype(np.int32)
     cnt = rng.integers(0, ns + 1, (b, m)).astype(np.int32)
+    dense = int(rng.integers(0, 2))                  # 1: all nsample rows count; 0: ball-query format (rows padded
+    if not dense:                                    # with the first hit), only the distinct rows are evaluated
+        idx = np.where(np.arange(ns)[None, None, :] >= np.maximum(cnt, 1)[:, :, None], idx[:, :, :1], idx)
     cin = [c + 3] + dims[:-1]
     ws = [rng.normal(0, 1.0 / np.sqrt(k), (k, o)).astype(np.float32) for k, o in zip(cin, dims)]
     bs = [rng.normal(0, 0.1, o).astype(np.float32) for o in dims]
@@ -300,10 +307,11 @@ def case_mlp_big(rng):
     nl = 3
     out = torch.empty((b, m, dims[-1]), dtype=torch.float32, device=dev)
     tx, tn, ti, tc, tf = t(xyz), t(new_xyz), t(idx), t(cnt), t(feat)
+    plan, plan_bytes = N.mlp_plan_ws(b, m, ns, dev)
     st = N.lib().sa_group_mlp_max(b, n, m, ns, c, tx.data_ptr(), tf.data_ptr(), tn.data_ptr(), ti.data_ptr(), tc.data_ptr(), nl,
                                   (ctypes.c_int * 4)(*([c + 3] + dims)), (ctypes.c_void_p * nl)(*[l.w.data_ptr() for l in layers]),
                                   (ctypes.c_void_p * nl)(*[l.bias.data_ptr() for l in layers]), out.data_ptr(), dims[-1], 0,
-                                  N.current_stream())
+                                  plan.data_ptr(), plan_bytes, dense, N.current_stream())
     if st != 0:
         return "group_mlp_max(big) status %d" % st
     torch.cuda.synchronize()

@@ -288,7 +288,16 @@ def _rand_layers(rng, dims):
     return ws, bs
 
 
-def _run_group_mlp(gpu, xyz, feat, new_xyz, idx, cnt, ws, bs, contiguous=True):
+def _pad_like_ball_query(idx, cnt):
+    """The contract of sa_group_mlp_max's default (compact) mode is the ball query's output format: a row of idx
+    holds cnt distinct hits and is padded with its FIRST hit up to nsample (tf_grouping_g.cu:245-248)."""
+    idx = idx.copy()
+    ns = idx.shape[2]
+    pad = np.arange(ns)[None, None, :] >= np.maximum(cnt, 1)[:, :, None]
+    return np.where(pad, idx[:, :, :1], idx)
+
+
+def _run_group_mlp(gpu, xyz, feat, new_xyz, idx, cnt, ws, bs, contiguous=True, flags=0):
     import ctypes
     N = pkg("utils._native")
     Wt = pkg("utils.weights")
@@ -303,11 +312,13 @@ def _run_group_mlp(gpu, xyz, feat, new_xyz, idx, cnt, ws, bs, contiguous=True):
     dims = (ctypes.c_int * (nl + 1))(*([c + 3] + [l.N for l in layers]))
     tx, tn, ti, tc = _t(xyz, gpu), _t(new_xyz, gpu), _t(idx, gpu), _t(cnt, gpu)
     tf = _t(feat, gpu) if feat is not None else None
+    plan, plan_bytes = N.mlp_plan_ws(b, m, ns, gpu)
     st = N.lib().sa_group_mlp_max(b, n, m, ns, c, tx.data_ptr(), tf.data_ptr() if tf is not None else None,
                                   tn.data_ptr(), ti.data_ptr(), tc.data_ptr(), nl, dims,
                                   (ctypes.c_void_p * nl)(*[l.w.data_ptr() for l in layers]),
                                   (ctypes.c_void_p * nl)(*[l.bias.data_ptr() for l in layers]),
-                                  out.data_ptr(), layers[-1].N + 5, 2, N.current_stream())
+                                  out.data_ptr(), layers[-1].N + 5, 2,
+                                  plan.data_ptr(), plan_bytes, flags, N.current_stream())
     assert st == 0
     torch.cuda.synchronize()
     o = out.cpu().numpy()
@@ -329,11 +340,21 @@ def test_group_mlp_max(gpu, oracle, c, ns, dims):
     cnt = rng.integers(0, ns + 1, (b, m)).astype(np.int32)
     cnt[:, ::7] = 0                                           # empty balls -> zero output
     ws, bs = _rand_layers(rng, [c + 3] + dims)
-    got = _run_group_mlp(gpu, xyz, feat, new_xyz, idx, cnt, ws, bs)
+    # arbitrary idx rows: every one of the nsample rows counts (dense plan, flags = 1)
+    got = _run_group_mlp(gpu, xyz, feat, new_xyz, idx, cnt, ws, bs, flags=1)
     ref = oracle.group_mlp_max(xyz, feat, new_xyz, idx, cnt, ws, bs)
     err = np.abs(got - ref).max() / np.abs(ref).max()
     assert err < MLP_TOL, "relative error %g" % err
     assert (got[cnt == 0] == 0).all()
+    # ball-query-format idx rows (padded with the first hit): only the distinct rows are evaluated (default) and
+    # the result is BIT-IDENTICAL to evaluating all of them
+    pidx = _pad_like_ball_query(idx, cnt)
+    ref = oracle.group_mlp_max(xyz, feat, new_xyz, pidx, cnt, ws, bs)
+    got = _run_group_mlp(gpu, xyz, feat, new_xyz, pidx, cnt, ws, bs)
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    assert err < MLP_TOL, "relative error %g (compact plan)" % err
+    assert (got[cnt == 0] == 0).all()
+    assert np.array_equal(got, _run_group_mlp(gpu, xyz, feat, new_xyz, pidx, cnt, ws, bs, flags=1))
 
 
 @pytest.mark.parametrize("c,ns,dims,m", [(1, 8, [16, 16, 32], 45), (1, 16, [32, 32, 64], 45), (1, 20, [16, 16, 32], 33),
@@ -358,11 +379,21 @@ def test_group_mlp_max_rowwave_shapes(gpu, oracle, c, ns, dims, m):
     cnt = rng.integers(0, ns + 1, (b, m)).astype(np.int32)
     cnt[:, ::5] = 0
     ws, bs = _rand_layers(rng, [c + 3] + dims)
-    got = _run_group_mlp(gpu, xyz, feat, new_xyz, idx, cnt, ws, bs)
+    # arbitrary idx rows: every one of the nsample rows counts (dense plan, flags = 1)
+    got = _run_group_mlp(gpu, xyz, feat, new_xyz, idx, cnt, ws, bs, flags=1)
     ref = oracle.group_mlp_max(xyz, feat, new_xyz, idx, cnt, ws, bs)
     err = np.abs(got - ref).max() / np.abs(ref).max()
     assert err < MLP_TOL, "relative error %g" % err
     assert (got[cnt == 0] == 0).all()
+    # ball-query-format idx rows (padded with the first hit): only the distinct rows are evaluated (default) and
+    # the result is BIT-IDENTICAL to evaluating all of them
+    pidx = _pad_like_ball_query(idx, cnt)
+    ref = oracle.group_mlp_max(xyz, feat, new_xyz, pidx, cnt, ws, bs)
+    got = _run_group_mlp(gpu, xyz, feat, new_xyz, pidx, cnt, ws, bs)
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    assert err < MLP_TOL, "relative error %g (compact plan)" % err
+    assert (got[cnt == 0] == 0).all()
+    assert np.array_equal(got, _run_group_mlp(gpu, xyz, feat, new_xyz, pidx, cnt, ws, bs, flags=1))
 
 
 def test_group_mlp_max_separately_allocated_layers(gpu, oracle):
@@ -375,8 +406,12 @@ def test_group_mlp_max_separately_allocated_layers(gpu, oracle):
     idx = rng.integers(0, n, (b, m, ns)).astype(np.int32)
     cnt = rng.integers(1, ns + 1, (b, m)).astype(np.int32)
     ws, bs = _rand_layers(rng, [c + 3, 128, 128, 256])
-    got = _run_group_mlp(gpu, xyz, feat, new_xyz, idx, cnt, ws, bs, contiguous=False)
+    got = _run_group_mlp(gpu, xyz, feat, new_xyz, idx, cnt, ws, bs, contiguous=False, flags=1)
     ref = oracle.group_mlp_max(xyz, feat, new_xyz, idx, cnt, ws, bs)
+    assert np.abs(got - ref).max() / np.abs(ref).max() < MLP_TOL
+    pidx = _pad_like_ball_query(idx, cnt)
+    got = _run_group_mlp(gpu, xyz, feat, new_xyz, pidx, cnt, ws, bs, contiguous=False)
+    ref = oracle.group_mlp_max(xyz, feat, new_xyz, pidx, cnt, ws, bs)
     assert np.abs(got - ref).max() / np.abs(ref).max() < MLP_TOL
 
 

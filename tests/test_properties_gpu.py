@@ -162,10 +162,11 @@ def test_grouped_mlp_is_permutation_invariant_inside_a_ball(gpu, c, ns, dims):
     def run(ix):
         out = torch.empty((b, m, dims[-1]), dtype=torch.float32, device=gpu)
         dm = (ctypes.c_int * (nl + 1))(*([c + 3] + dims))
+        plan, plan_bytes = N.mlp_plan_ws(b, m, ns, gpu)
         st = N.lib().sa_group_mlp_max(b, n, m, ns, c, xyz.data_ptr(), feat.data_ptr(), new_xyz.data_ptr(), ix.data_ptr(),
                                       cnt.data_ptr(), nl, dm, (ctypes.c_void_p * nl)(*[l.w.data_ptr() for l in layers]),
                                       (ctypes.c_void_p * nl)(*[l.bias.data_ptr() for l in layers]), out.data_ptr(),
-                                      dims[-1], 0, N.current_stream())
+                                      dims[-1], 0, plan.data_ptr(), plan_bytes, 0, N.current_stream())
         assert st == 0
         torch.cuda.synchronize()
         return out
