@@ -867,7 +867,7 @@ __global__ void vote_translate_kernel(long total, const float *__restrict__ xyz,
 // plain store; only balls of more than 32 distinct rows are split (atomic max on a row zeroed here).  Next fit is a
 // sequential rule; it is evaluated in parallel as a scan over FUNCTIONS phase -> (phase, advance) (phase = fill of
 // the current tile, 0..3): a thread folds its 8 balls for each of the 4 start phases, waves scan by composition.
-constexpr int kPlanThreads = 256, kPlanBallsPerThread = 8;
+constexpr int kPlanThreads = 1024, kPlanBallsPerThread = 8;
 
 struct PlanFn { int t[4]; };     // t[p] = advance << 2 | end phase, for start phase p
 __device__ __forceinline__ int plan_fn_at(const PlanFn &f, int p) {
@@ -891,101 +891,117 @@ __device__ __forceinline__ int plan_place(int g, int &ph) {
     return pad;
 }
 
-__global__ void mlp_plan_reset_kernel(int *hdr) {
-    if (threadIdx.x < sa::kPlanHeaderInts) hdr[threadIdx.x] = 0;
-}
+// One workgroup per scale walks the scale's balls in chunks of 8192 (1024 threads x 8 balls), carrying the packing
+// state from chunk to chunk: no atomics, no counter to reset between calls, the same plan on every run.
+constexpr int kPlanMaxScales = 4;
+struct PlanJob {
+    const int *cnt;
+    int *hdr, *gran;
+    int ns, out_off, N;
+};
+struct PlanJobs {
+    PlanJob j[kPlanMaxScales];
+    int nballs, dense, out_stride;
+    float *out;
+};
 
-__global__ __launch_bounds__(kPlanThreads) void mlp_plan_kernel(const int *__restrict__ cnt, int nballs, int ns, int dense,
-                                                                int *__restrict__ hdr, int *__restrict__ gran,
-                                                                float *__restrict__ out, int out_stride, int out_off, int N) {
-    __shared__ int wfn[kPlanThreads / 64][4];
-    __shared__ int base_s, nsplit_s;
+__global__ __launch_bounds__(kPlanThreads) void mlp_plan_kernel(PlanJobs J) {
+    constexpr int NWV = kPlanThreads / 64;
+    __shared__ int wfn[NWV][4];
+    __shared__ int nsplit_s;
     __shared__ int split_ball[kPlanThreads * kPlanBallsPerThread];
+    const PlanJob job = J.j[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) nsplit_s = 0;
-    const int ball0 = (blockIdx.x * kPlanThreads + tid) * kPlanBallsPerThread;
-    int g[kPlanBallsPerThread], rows = 0;
+    const int nballs = J.nballs, ns = job.ns;
+    int base = 0;                                       // advance << 2 | phase in front of the current chunk
+    int rows_acc = 0, nsplit_acc = 0;
+    for (int chunk0 = 0; chunk0 < nballs; chunk0 += kPlanThreads * kPlanBallsPerThread) {
+        if (tid == 0) nsplit_s = 0;
+        const int ball0 = chunk0 + tid * kPlanBallsPerThread;
+        int g[kPlanBallsPerThread], rows = 0;
 #pragma unroll
-    for (int k = 0; k < kPlanBallsPerThread; ++k) {
-        const int ball = ball0 + k;
-        int c = 0;
-        if (ball < nballs) { c = cnt[ball]; c = c < 1 ? 1 : (c > ns ? ns : c); if (dense) c = ns; }
-        g[k] = (c + 7) >> 3;
-        rows += c;
-    }
-    PlanFn f;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        int ph = p, adv = 0;
-#pragma unroll
-        for (int k = 0; k < kPlanBallsPerThread; ++k)
-            if (g[k] > 0) { adv += plan_place(g[k], ph); adv += g[k]; }
-        f.t[p] = (adv << 2) | ph;
-    }
-    PlanFn incl = f;                                    // inclusive scan by composition over the wave
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        PlanFn o;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) o.t[p] = __shfl_up(incl.t[p], d);
-        if (lane >= d) incl = plan_fn_compose(o, incl);
-    }
-    int rsum = rows;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) rsum += __shfl_xor(rsum, d);
-    if (lane == 63) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) wfn[w][p] = incl.t[p];
-    }
-    __syncthreads();
-    // the workgroup starts tile-aligned (phase 0): state in front of this wave, then in front of this thread
-    int st = 0;                                         // advance << 2 | phase
-    int btot = 0;
-#pragma unroll
-    for (int i = 0; i < kPlanThreads / 64; ++i) {
-        const int y = wfn[i][btot & 3];
-        const int nx = (((btot >> 2) + (y >> 2)) << 2) | (y & 3);
-        if (i < w) st = nx;
-        btot = nx;
-    }
-    const int total = ((btot >> 2) + 3) & ~3;           // whole tiles per workgroup
-    if (tid == 0) base_s = atomicAdd(&hdr[0], total);   // order of the workgroups' ranges is irrelevant to the results
-    if (lane == 0 && rsum) atomicAdd(&hdr[2], rsum);
-    {
-        PlanFn excl;                                    // exclusive prefix of this thread inside its wave
-#pragma unroll
-        for (int p = 0; p < 4; ++p) { const int v = __shfl_up(incl.t[p], 1); excl.t[p] = lane == 0 ? p : v; }
-        const int y = plan_fn_at(excl, st & 3);
-        st = (((st >> 2) + (y >> 2)) << 2) | (y & 3);
-    }
-    __syncthreads();
-    int pos = base_s + (st >> 2), ph = st & 3;
-#pragma unroll
-    for (int k = 0; k < kPlanBallsPerThread; ++k) {
-        if (g[k] > 0) {
+        for (int k = 0; k < kPlanBallsPerThread; ++k) {
             const int ball = ball0 + k;
-            const int pad = plan_place(g[k], ph);
-            for (int j = 0; j < pad; ++j) gran[pos + j] = -1;
-            pos += pad;
-            const int split = g[k] > 4 ? 1 : 0;
-            for (int j = 0; j < g[k]; ++j) gran[pos + j] = (ball << 7) | (j << 1) | split;
-            pos += g[k];
-            if (split) split_ball[atomicAdd(&nsplit_s, 1)] = ball;
+            int c = 0;
+            if (ball < nballs) { c = job.cnt[ball]; c = c < 1 ? 1 : (c > ns ? ns : c); if (J.dense) c = ns; }
+            g[k] = (c + 7) >> 3;
+            rows += c;
         }
+        PlanFn f;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            int ph = p, adv = 0;
+#pragma unroll
+            for (int k = 0; k < kPlanBallsPerThread; ++k)
+                if (g[k] > 0) { adv += plan_place(g[k], ph); adv += g[k]; }
+            f.t[p] = (adv << 2) | ph;
+        }
+        PlanFn incl = f;                                // inclusive scan by composition over the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            PlanFn o;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) o.t[p] = __shfl_up(incl.t[p], d);
+            if (lane >= d) incl = plan_fn_compose(o, incl);
+        }
+        int rsum = rows;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) rsum += __shfl_xor(rsum, d);
+        if (lane == 63) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) wfn[w][p] = incl.t[p];
+        }
+        if (lane == 0) rows_acc += rsum;                // lane 0 of every wave: summed at the end through wfn
+        __syncthreads();
+        int st = base, bend = base;                     // state in front of this wave / behind the chunk
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            const int y = wfn[i][bend & 3];
+            bend = (((bend >> 2) + (y >> 2)) << 2) | (y & 3);
+            if (i < w) st = bend;
+        }
+        {
+            PlanFn excl;                                // exclusive prefix of this thread inside its wave
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { const int v = __shfl_up(incl.t[p], 1); excl.t[p] = lane == 0 ? p : v; }
+            const int y = plan_fn_at(excl, st & 3);
+            st = (((st >> 2) + (y >> 2)) << 2) | (y & 3);
+        }
+        int pos = st >> 2, ph = st & 3;
+#pragma unroll
+        for (int k = 0; k < kPlanBallsPerThread; ++k) {
+            if (g[k] > 0) {
+                const int ball = ball0 + k;
+                const int pad = plan_place(g[k], ph);
+                for (int j = 0; j < pad; ++j) job.gran[pos + j] = -1;
+                pos += pad;
+                const int split = g[k] > 4 ? 1 : 0;
+                for (int j = 0; j < g[k]; ++j) job.gran[pos + j] = (ball << 7) | (j << 1) | split;
+                pos += g[k];
+                if (split) split_ball[atomicAdd(&nsplit_s, 1)] = ball;
+            }
+        }
+        __syncthreads();
+        // rows of split balls are zeroed (their partial maxima meet through an atomic max): all threads, coalesced
+        const int nsp = nsplit_s;
+        for (int i = 0; i < nsp; ++i) {
+            float *o = J.out + (size_t)split_ball[i] * J.out_stride + job.out_off;
+            for (int c = tid; c < job.N; c += kPlanThreads) o[c] = 0.0f;
+        }
+        nsplit_acc += nsp;
+        base = bend;
+        __syncthreads();
     }
-    // the last thread that placed something pads the workgroup's range to whole tiles
-    if (tid == kPlanThreads - 1) {
-        const int end = base_s + total;
-        for (int q = base_s + (btot >> 2); q < end; ++q) gran[q] = -1;
-    }
+    // header: granules (padded to whole tiles with invalid entries), split balls, distinct rows
+    if (lane == 0) wfn[w][0] = rows_acc;
     __syncthreads();
-    // rows of split balls are zeroed (their partial maxima meet through an atomic max): all threads, coalesced
-    const int nsp = nsplit_s;
-    for (int i = 0; i < nsp; ++i) {
-        float *o = out + (size_t)split_ball[i] * out_stride + out_off;
-        for (int c = tid; c < N; c += kPlanThreads) o[c] = 0.0f;
+    if (tid == 0) {
+        const int used = base >> 2, total = (used + 3) & ~3;
+        for (int q = used; q < total; ++q) job.gran[q] = -1;
+        int rows = 0;
+        for (int i = 0; i < NWV; ++i) rows += wfn[i][0];
+        job.hdr[0] = total; job.hdr[1] = nsplit_acc; job.hdr[2] = rows; job.hdr[3] = 0;
     }
-    if (tid == 0 && nsp) atomicAdd(&hdr[1], nsp);
 }
 
 int roundup(int x, int q) { return (x + q - 1) / q * q; }
@@ -999,11 +1015,10 @@ int sa_rowwave_try(int b, int n, int m, int ns, int c, const float *xyz, const f
                    const int *plan_gran, long max_tiles, hipStream_t stream, int *st);
 
 // Upper bound of the plan length: next fit never leaves two consecutive tiles with a combined fill <= 4 granules, so
-// the list is shorter than twice the granules + one tile per 2048-ball workgroup of the plan kernel (its alignment).
+// the list is shorter than twice the granules (+ the padding of the last tile).
 static long sa_plan_max_granules(long nballs, int ns) {
     const long g = nballs * ((ns + 7) / 8);
-    const long wgs = (nballs + kPlanThreads * kPlanBallsPerThread - 1) / (kPlanThreads * kPlanBallsPerThread);
-    return (ns <= 8 ? g : 2 * g) + 4 * wgs + 8;
+    return (ns <= 8 ? g : 2 * g) + 8;
 }
 
 // Bytes of caller-owned scratch sa_group_mlp_max needs for the row plan of one scale (header + one int per granule
@@ -1013,12 +1028,37 @@ extern "C" size_t sa_group_mlp_max_ws_bytes(int b, int m, int ns) {
     return (size_t)sa::kPlanHeaderInts * sizeof(int) + ((size_t)sa_plan_max_granules((long)b * m, ns) + 8) * sizeof(int);
 }
 
+// Row plans of ALL scales of an SA layer in one launch (one workgroup per scale).  cnt[i]: pts_cnt of scale i
+// [b, m]; ws[i]: scratch of sa_group_mlp_max_ws_bytes(b, m, ns[i]) bytes; out / out_stride / out_off[i] / nout[i]:
+// where scale i's pooled channels go (rows of balls with more than 32 distinct rows are zeroed here).  The
+// sa_group_mlp_max calls of the layer then pass the same ws[i] and flags | 2.
+extern "C" int sa_group_mlp_plan(int b, int m, int nscale, const int *ns, const int *const *cnt, void *const *ws,
+                                 float *out, int out_stride, const int *out_off, const int *nout, int flags,
+                                 hipStream_t stream) {
+    if (b <= 0 || m <= 0 || nscale < 1 || nscale > kPlanMaxScales || !ns || !cnt || !ws || !out || !out_off || !nout)
+        return SA_ERR_INVALID;
+    const long nballs = (long)b * m;
+    if (nballs >= (1l << 24)) return SA_ERR_UNSUPPORTED;
+    PlanJobs J{};
+    for (int i = 0; i < nscale; ++i) {
+        if (ns[i] <= 0 || !cnt[i] || !ws[i] || nout[i] <= 0) return SA_ERR_INVALID;
+        if (ns[i] > 8 * sa::kPlanMaxOrd) return SA_ERR_UNSUPPORTED;
+        J.j[i].cnt = cnt[i]; J.j[i].hdr = (int *)ws[i]; J.j[i].gran = (int *)ws[i] + sa::kPlanHeaderInts;
+        J.j[i].ns = ns[i]; J.j[i].out_off = out_off[i]; J.j[i].N = nout[i];
+    }
+    J.nballs = (int)nballs; J.dense = flags & 1; J.out_stride = out_stride; J.out = out;
+    hipLaunchKernelGGL(mlp_plan_kernel, dim3(nscale), dim3(kPlanThreads), 0, stream, J);
+    SA_CHECK_LAUNCH();
+    return SA_OK;
+}
+
 // One scale of an SA layer.  Layer l: wpack[l] (device, fragment-packed hi/lo bf16, see header),
 // bias[l] (device, fp32, zero-padded to a multiple of 32), dims[0] = C+3, dims[l+1] = output channels.
 // out[(b*m + j)*out_stride + out_off + c] receives the pooled channel c.  Additional to the reference
 // API (the reference has no fused op).  ws: sa_group_mlp_max_ws_bytes(b, m, ns) bytes of device scratch (the row
 // plan; contents are private to the call).  flags bit 0: dense plan -- every ball is evaluated on all nsample rows
 // like the reference does (A/B measurements); default: only the distinct rows of a ball (mlp_plan.h), same results.
+// flags bit 1: the plan in ws was built by sa_group_mlp_plan for this layer (skips the per-scale plan launch).
 extern "C" int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float *xyz, const float *feat,
                                 const float *new_xyz, const int *idx, const int *cnt, int nl,
                                 const int *dims, const void *const *wpack, const float *const *bias,
@@ -1037,12 +1077,12 @@ extern "C" int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float 
     const long max_tiles = (gmax + 3) / 4;
     if (max_tiles > 0x0FFFFFFFl) return SA_ERR_UNSUPPORTED;
     int *hdr = (int *)ws, *gran = hdr + sa::kPlanHeaderInts;
-    // ---- the row plan of this call
-    {
-        hipLaunchKernelGGL(mlp_plan_reset_kernel, dim3(1), dim3(64), 0, stream, hdr);
-        const int per = kPlanThreads * kPlanBallsPerThread;
-        hipLaunchKernelGGL(mlp_plan_kernel, dim3((unsigned)((nballs + per - 1) / per)), dim3(kPlanThreads), 0, stream,
-                           cnt, (int)nballs, ns, flags & 1, hdr, gran, out, out_stride, out_off, dims[nl]);
+    // ---- the row plan of this call (unless sa_group_mlp_plan built the plans of the whole layer already)
+    if (!(flags & 2)) {
+        PlanJobs J{};
+        J.j[0].cnt = cnt; J.j[0].hdr = hdr; J.j[0].gran = gran; J.j[0].ns = ns; J.j[0].out_off = out_off; J.j[0].N = dims[nl];
+        J.nballs = (int)nballs; J.dense = flags & 1; J.out_stride = out_stride; J.out = out;
+        hipLaunchKernelGGL(mlp_plan_kernel, dim3(1), dim3(kPlanThreads), 0, stream, J);
         SA_CHECK_LAUNCH();
     }
     {

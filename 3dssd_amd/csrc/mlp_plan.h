@@ -8,12 +8,13 @@
 // evaluate only the distinct rows, in GRANULES of 8 rows (one quarter of a 32-row MFMA tile; the D layout of
 // v_mfma_f32_32x32x16 puts rows 8q..8q+7 into registers 4q..4q+3 of the two lane halves, so a granule's maximum is
 // three v_max + one v_permlane32_swap whatever the ball boundaries are):
-//   mlp_plan_kernel   ball i -> g_i = ceil(clamp(cnt_i, 1, ns) / 8) granules, packed densely (prefix sum inside a
-//                     workgroup, one atomic per workgroup for its base) into the list gran[]; entry =
-//                     ball << 7 | ordinal << 1 | split.  `split` marks a ball whose granules straddle a 32-row tile
-//                     boundary (always when g_i > 4): its partial maxima meet through an atomic max on the output,
-//                     which the plan kernel has zeroed (relu(max + bias) >= 0, so the bit patterns order like the
-//                     floats and max commutes with the monotone relu(. + bias)).
+//   mlp_plan_kernel   ball i -> g_i = ceil(clamp(cnt_i, 1, ns) / 8) granules, placed "next fit" into 32-row tiles (a
+//                     ball of <= 4 granules never straddles a tile boundary; the rest of a tile is padded with
+//                     invalid entries) by a scan over phase -> (phase, advance) functions, one workgroup per
+//                     scale, no atomics; list gran[], entry = ball << 7 | ordinal << 1 | split.  `split` marks a
+//                     ball of more than 32 distinct rows: its partial maxima meet through an atomic max on the
+//                     output, which the plan kernel has zeroed (relu(max + bias) >= 0, so the bit patterns order
+//                     like the floats and max commutes with the monotone relu(. + bias)).
 //   MLP kernels       tile t = granules 4t .. 4t+3, read the list instead of computing (ball, sample) from the tile
 //                     index; after the last layer the granule maxima of a ball's run inside the tile are combined
 //                     with wave-uniform branches and written (plain store, or atomic max for split balls).

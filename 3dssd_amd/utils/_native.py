@@ -31,6 +31,7 @@ SIGNATURES = {
     "sa_query_ball_point_grid": [_c_int] * 4 + [_vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _vp, _vp],
     "sa_group_mlp_max": [_c_int] * 5 + [_vp] * 5 + [_c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp,
                          ctypes.c_size_t, _c_int, _vp],
+    "sa_group_mlp_plan": [_c_int] * 3 + [_vp, _vp, _vp, _vp, _c_int, _vp, _vp, _c_int, _vp],
     "sa_dense": [_c_long, _c_int, _c_int, _vp, _vp, _vp, _c_int, _vp, _vp],
     "sa_decode_anchor_free": [_c_int] * 4 + [_vp] * 7,
     "sa_boxes_to_bev": [_c_long, _vp, _vp, _vp],

@@ -27,6 +27,19 @@ from .tf_ops.grouping.tf_grouping import query_ball_point, query_ball_point_dila
 AGGREGATION_SA_FEATURE = True
 # frames with at least this many points go through the grid ball query (csrc/ballquery_grid.hip)
 # sa_group_mlp_max flags: 0 = evaluate only the distinct rows of every ball (default), 1 = all nsample rows (A/B)
+# Where the D-FPS half of an 'FS' layer (and of a two-range layer) runs, SA_DFPS_SIDE_STREAM:
+#   2 (default)  on a helper stream, forked AFTER the F-FPS chain was enqueued and joined right behind it.  The two
+#                halves still run back to back, but in a captured graph the D-FPS node sits on its own branch; with 16
+#                graphs in flight this form measured 8.3k frames/s against 6.5k with everything on one stream (0, 3).
+#   1            forked BEFORE the F-FPS chain: the two serial chains overlap, one batch's latency drops from 5.25 to
+#                4.9 ms, but the throughput with 16 graphs in flight HALVES (4.2k frames/s: parallel branches of many
+#                graphs compete for the hardware queues).  The right choice for single-frame latency.
+#   0 / 3        no helper stream (D-FPS first / F-FPS first);   4: every FPS kernel on the helper stream (= 2).
+DFPS_SIDE_STREAM = int(__import__("os").environ.get("SA_DFPS_SIDE_STREAM", "2"))
+# timing experiments only (tools/ablate.sh): comma-separated kernel classes whose launches are SKIPPED (results are
+# then garbage): mlp:<scope>, dense, sqdist, fpsdist, dfps:<n>, bq, plan
+_ABLATE = set(filter(None, __import__("os").environ.get("SA_ABLATE", "").split(",")))
+PLAN_LOG = None     # set to a list to collect (b, m, nsample, MACs per row, plan tensor) of every fused-MLP call
 MLP_PLAN_FLAGS = int(__import__("os").environ.get("SA_MLP_DENSE_PLAN", "0"))
 GRID_BALL_QUERY_MIN_N = int(__import__("os").environ.get("SA_GRID_BQ_MIN_N", "512"))
 MAX_TRANSLATE_RANGE = (-3.0, -2.0, -3.0)
@@ -36,6 +49,8 @@ def _dense(x, layer, relu):
     """tf_util.conv1d 1x1 (+ folded BN) (+ ReLU) on [..., K] -> [..., N]."""
     rows = x.numel() // layer.K
     y = torch.empty(x.shape[:-1] + (layer.N,), dtype=torch.float32, device=x.device)
+    if "dense" in _ABLATE:
+        return y
     st = N.lib().sa_dense(rows, layer.K, layer.N, x.data_ptr(), layer.w.data_ptr(), layer.bias.data_ptr(),
                           1 if relu else 0, y.data_ptr(), N.current_stream())
     N.check(st, "dense")
@@ -68,18 +83,48 @@ def _ffps_into(npoint, tmp_xyz, tmp_points, out, col, idx_off):
     # packed form: the operand is laid out once in the matrix kernel's LDS image, tiles are staged by plain copies
     ws = torch.empty((lib.sa_calc_square_dist_ws_bytes(b, n, n, 3 + c1, 1) + 3) // 4, dtype=torch.float32,
                      device=tmp_xyz.device)
-    st = lib.sa_calc_square_dist_split_ws(b, n, n, 3, c1, tmp_xyz.data_ptr(), tmp_points.data_ptr(),
-                                          tmp_xyz.data_ptr(), tmp_points.data_ptr(), dist.data_ptr(), ws.data_ptr(),
-                                          N.current_stream())
+    st = 0 if "sqdist" in _ABLATE else lib.sa_calc_square_dist_split_ws(
+        b, n, n, 3, c1, tmp_xyz.data_ptr(), tmp_points.data_ptr(), tmp_xyz.data_ptr(), tmp_points.data_ptr(),
+        dist.data_ptr(), ws.data_ptr(), N.current_stream())
     N.check(st, "calc_square_dist")
     temp = torch.empty((b, n), dtype=torch.float32, device=dist.device) if n > 16384 else None
-    st = lib.sa_fps_with_distance_ex(b, n, npoint, dist.data_ptr(),
-                                     temp.data_ptr() if temp is not None else None,
-                                     out.data_ptr() + 4 * col, out.shape[1], idx_off, N.current_stream())
-    N.check(st, "farthest_point_sample_with_distance")
+
+    def chain():
+        if "fpsdist" in _ABLATE:
+            return
+        st = lib.sa_fps_with_distance_ex(b, n, npoint, dist.data_ptr(),
+                                         temp.data_ptr() if temp is not None else None,
+                                         out.data_ptr() + 4 * col, out.shape[1], idx_off, N.current_stream())
+        N.check(st, "farthest_point_sample_with_distance")
+    _run_chain(chain)
+
+
+def _run_chain(fn):
+    """A long serial FPS kernel.  Mode 4: on the helper stream between two events (fork / join) instead of in line."""
+    if DFPS_SIDE_STREAM != 4:
+        return fn()
+    main = torch.cuda.current_stream()
+    side = _side_stream(main)
+    ev = torch.cuda.Event()
+    ev.record(main)
+    side.wait_event(ev)
+    with torch.cuda.stream(side):
+        fn()
+    ev2 = torch.cuda.Event()
+    ev2.record(side)
+    main.wait_event(ev2)
 
 
 _SIDE_STREAMS = {}
+_IDENTITY_IDX = {}
+
+
+def _identity_idx(bs, start, cnt, dev):
+    """[bs, cnt] int32 tensor of start .. start+cnt-1 in every row (read-only, shared between calls)."""
+    key = (bs, start, cnt, str(dev))
+    if key not in _IDENTITY_IDX:
+        _IDENTITY_IDX[key] = torch.arange(start, start + cnt, dtype=torch.int32, device=dev)[None].repeat(bs, 1).contiguous()
+    return _IDENTITY_IDX[key]
 
 
 def _side_stream(main):
@@ -95,9 +140,14 @@ def _side_stream(main):
 def _dfps_into(npoint, tmp_xyz, out, col, idx_off):
     b, n, c = tmp_xyz.shape
     temp = torch.empty((b, n), dtype=torch.float32, device=tmp_xyz.device) if (c != 3 or n > 16384) else None
-    st = N.lib().sa_fps_ex(b, n, c, npoint, tmp_xyz.data_ptr(), temp.data_ptr() if temp is not None else None,
-                           out.data_ptr() + 4 * col, out.shape[1], idx_off, N.current_stream())
-    N.check(st, "farthest_point_sample")
+
+    def chain():
+        if ("dfps:%d" % n) in _ABLATE:
+            return
+        st = N.lib().sa_fps_ex(b, n, c, npoint, tmp_xyz.data_ptr(), temp.data_ptr() if temp is not None else None,
+                               out.data_ptr() + 4 * col, out.shape[1], idx_off, N.current_stream())
+        N.check(st, "farthest_point_sample")
+    _run_chain(chain)
 
 
 def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_training, bn_decay, bn,
@@ -135,39 +185,55 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
         total += cnt
         last += fps_sample_range
     former_n = former_fps_idx.shape[1] if former_fps_idx is not None else 0
-    fps_idx = torch.empty((bs, total + former_n), dtype=torch.int32, device=dev)
+    only_identity = len(plan) == 1 and plan[0][0] == "identity" and former_n == 0
+    if only_identity:
+        # identity sampling (npoint == range size / vote centres): a cached constant index tensor, no kernel
+        fps_idx = _identity_idx(bs, plan[0][1], plan[0][3], dev)
+        plan_iter = []
+    else:
+        fps_idx = torch.empty((bs, total + former_n), dtype=torch.int32, device=dev)
+        plan_iter = plan
     col = 0
     has_f = any(k in ("FS", "F-FPS") for k, _s, _e, _c in plan)
     has_d = any(k in ("FS", "D-FPS") for k, _s, _e, _c in plan)
     main = torch.cuda.current_stream()
-    side = _side_stream(main) if (has_f and has_d) else None
-    keep = []
-    for kind, start, end, cnt in plan:
+    side = _side_stream(main) if (has_f and has_d and DFPS_SIDE_STREAM in (1, 2)) else None
+    # Pass 1 (main stream): the range slices every sampler reads.  Then ONE fork: the D-FPS halves go to the side
+    # stream BEFORE the F-FPS chains (distance matrix + matrix FPS) are enqueued on the main stream, so the two
+    # serial chains of a layer really run side by side (each keeps one CU per frame busy).
+    work = []
+    for kind, start, end, cnt in plan_iter:
         if kind == "identity":
             fps_idx[:, col:col + cnt] = torch.arange(start, start + cnt, dtype=torch.int32, device=dev)[None]
         else:
             whole = (start == 0 and end == n_all)
             tmp_xyz = xyz if whole else xyz[:, start:end].contiguous()
-            keep.append(tmp_xyz)
-            d_col, d_n = None, 0
+            tmp_points = None
             if kind in ("FS", "F-FPS"):
                 tmp_points = points if whole else points[:, start:end].contiguous()
-                npt = cnt // 2 if kind == "FS" else cnt
-                _ffps_into(npt, tmp_xyz, tmp_points, fps_idx, col, start)   # F-FPS indices first
-                if kind == "FS":
-                    d_col, d_n = col + npt, npt
-            else:
-                d_col, d_n = col, cnt
-            if d_col is not None:
-                if side is not None:
-                    ev = torch.cuda.Event()
-                    ev.record(main)
-                    side.wait_event(ev)
-                    with torch.cuda.stream(side):
-                        _dfps_into(d_n, tmp_xyz, fps_idx, d_col, start)
-                else:
-                    _dfps_into(d_n, tmp_xyz, fps_idx, d_col, start)
+            work.append((kind, start, cnt, col, tmp_xyz, tmp_points))
         col += cnt
+    if DFPS_SIDE_STREAM in (2, 3):
+        for kind, start, cnt, c0, tmp_xyz, tmp_points in work:
+            if kind in ("FS", "F-FPS"):
+                _ffps_into(cnt // 2 if kind == "FS" else cnt, tmp_xyz, tmp_points, fps_idx, c0, start)
+    if side is not None:
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
+    for kind, start, cnt, c0, tmp_xyz, tmp_points in work:                  # D-FPS parts (:97,106)
+        if kind in ("FS", "D-FPS"):
+            d_n = cnt // 2 if kind == "FS" else cnt
+            d_col = c0 + d_n if kind == "FS" else c0                        # 'FS': [F-FPS idx || D-FPS idx] (:96-98)
+            if side is not None:
+                with torch.cuda.stream(side):
+                    _dfps_into(d_n, tmp_xyz, fps_idx, d_col, start)
+            else:
+                _dfps_into(d_n, tmp_xyz, fps_idx, d_col, start)
+    for kind, start, cnt, c0, tmp_xyz, tmp_points in work:                  # F-FPS parts (:94-96,102-104)
+        if kind in ("FS", "F-FPS") and DFPS_SIDE_STREAM not in (2, 3):
+            npt = cnt // 2 if kind == "FS" else cnt
+            _ffps_into(npt, tmp_xyz, tmp_points, fps_idx, c0, start)
     if side is not None:
         ev = torch.cuda.Event()
         ev.record(side)
@@ -176,7 +242,10 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
         fps_idx[:, col:] = T.i32_cuda(former_fps_idx, "former_fps_idx")
 
     ctr_src = T.f32_cuda(vote_ctr, "vote_ctr") if vote_ctr is not None else xyz
-    new_xyz = gather_point(ctr_src, fps_idx)                                # :116-119
+    if only_identity and plan[0][1] == 0 and plan[0][3] == ctr_src.shape[1]:
+        new_xyz = ctr_src                                                   # gather with the identity: the tensor itself
+    else:
+        new_xyz = gather_point(ctr_src, fps_idx)                            # :116-119
     m = new_xyz.shape[1]
     lib = N.lib()
     stream = N.current_stream()
@@ -191,7 +260,13 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
         nsa = (ctypes.c_int * nscale)(*[int(v) for v in nsample_list])
         idxp = (ctypes.c_void_p * nscale)(*[t.data_ptr() for t in idx_list])
         cntp = (ctypes.c_void_p * nscale)(*[t.data_ptr() for t in cnt_list])
-        if n_all >= GRID_BALL_QUERY_MIN_N and nscale <= 4:
+        if "bq" in _ABLATE:
+            st = 0
+            for t_ in cnt_list:
+                t_.fill_(1)
+            for t_ in idx_list:
+                t_.zero_()
+        elif n_all >= GRID_BALL_QUERY_MIN_N and nscale <= 4:
             # large frames: per-frame x-z grid, candidates from the 3 x 3 cells around each centre (same outputs)
             ws = torch.empty((lib.sa_query_ball_point_grid_ws_bytes(bs, n_all, m) + 3) // 4, dtype=torch.int32, device=dev)
             st = lib.sa_query_ball_point_grid(bs, n_all, m, nscale, rmin, rmax, nsa, 1 if dilated_group else 0,
@@ -206,6 +281,18 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
         ctot = sum(ls[-1].N for ls in layers)
         new_points_concat = torch.empty((bs, m, ctot), dtype=torch.float32, device=dev)
         c_feat = points.shape[2]
+        # row plans of all scales in one launch: only the distinct rows of every ball are evaluated (mlp_plan.h)
+        plans = [N.mlp_plan_ws(bs, m, int(ns), dev) for ns in nsample_list]
+        offs, acc = [], 0
+        for ls in layers:
+            offs.append(acc)
+            acc += ls[-1].N
+        have_plans = nscale <= 4
+        if have_plans and "plan" not in _ABLATE:
+            st = lib.sa_group_mlp_plan(bs, m, nscale, nsa, cntp, (ctypes.c_void_p * nscale)(*[p[0].data_ptr() for p in plans]),
+                                       new_points_concat.data_ptr(), ctot, (ctypes.c_int * nscale)(*offs),
+                                       (ctypes.c_int * nscale)(*[ls[-1].N for ls in layers]), MLP_PLAN_FLAGS, stream)
+            N.check(st, "group_mlp_plan")
         off = 0
         for i in range(nscale):
             ls = layers[i]
@@ -213,13 +300,18 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
             dims = (ctypes.c_int * (nl + 1))(*([c_feat + 3] + [l.N for l in ls]))
             wp = (ctypes.c_void_p * nl)(*[l.w.data_ptr() for l in ls])
             bp = (ctypes.c_void_p * nl)(*[l.bias.data_ptr() for l in ls])
-            plan, plan_bytes = N.mlp_plan_ws(bs, m, int(nsample_list[i]), dev)    # row plan: distinct rows only
+            plan, plan_bytes = plans[i]
+            if ("mlp:%s" % scope) in _ABLATE or ("mlp:%s:%d" % (scope, i)) in _ABLATE:
+                off += ls[-1].N
+                continue
             st = lib.sa_group_mlp_max(bs, n_all, m, int(nsample_list[i]), c_feat, xyz.data_ptr(),
                                       points.data_ptr(), new_xyz.data_ptr(), idx_list[i].data_ptr(),
                                       cnt_list[i].data_ptr(), nl, dims, wp, bp,
                                       new_points_concat.data_ptr(), ctot, off, plan.data_ptr(), plan_bytes,
-                                      MLP_PLAN_FLAGS, stream)
+                                      MLP_PLAN_FLAGS | (2 if have_plans else 0), stream)
             N.check(st, "group_mlp_max")
+            if PLAN_LOG is not None:                                        # bench.py: rows evaluated per scale
+                PLAN_LOG.append((bs, m, int(nsample_list[i]), sum(dims[j] * dims[j + 1] for j in range(nl)), plan))
             off += ls[-1].N
         if AGGREGATION_SA_FEATURE:                                          # :184-185
             agg = vs.layer(scope + "/ensemble", bn)

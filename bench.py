@@ -1,8 +1,9 @@
 """Throughput benchmark of the SA hot path: point-cloud frames/s through the full 3DSSD SA backbone
 (configs/kitti/3dssd/3dssd.yaml rows 1-6), KITTI-shape synthetic frames (16384 x 4), batch 8 per GPU.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1 without torchrun: spawns the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --workload configs2|configs4             (the other single-GPU configurations of BASELINE.json)
 
 A "step" is one batch of 8 frames per GPU through the backbone, device-resident in and out.  Steps are
 issued round-robin on --streams HIP streams (frames in flight: FPS is a serial chain that keeps only one
@@ -15,6 +16,8 @@ import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,7 +34,7 @@ import torch
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E, MI355X_MICROARCH.md
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA
 VALU_F32_PEAK_TF = 157.3
-CUS_USED_FPS = 8            # FPS runs one workgroup per frame: batch 8 -> 8 of 256 CUs
+TRAFFIC_PROFILE = os.path.join("profiles", "r02_traffic.json")   # committed rocprofv3 PMC pass (tools/gpu_prof.sh)
 
 
 def pkg(name):
@@ -65,7 +68,7 @@ class TimingProxy:
 def _algorithmic(name, a):
     """(flops, bytes, label) of one C-ABI call from its scalar arguments (SURVEY.md 8d conventions:
     inputs read once, outputs written once)."""
-    if name == "sa_fps_ex":
+    if name in ("sa_fps_ex", "sa_farthest_point_sample"):
         b, n, c, m = a[0:4]
         return (3 * c + 2) * b * (m - 1) * n, b * (n * c * 4 + m * 4), "fps n=%d->%d c=%d" % (n, m, c)
     if name == "sa_fps_with_distance_ex":
@@ -96,15 +99,18 @@ def _algorithmic(name, a):
     return 0, 0, name
 
 
-def profile_stages(net, pts, iters):
-    """Average duration of every kernel of one backbone step, measured live with events."""
+def profile_stages(fn, iters):
+    """Average duration of every C-ABI call of one step (`fn()`), measured live with events on the launch stream.
+    Eager launches on ONE stream: these are kernel durations, not the overlapped multi-stream step time."""
+    if iters <= 0:
+        return []
     native = pkg("utils._native")
     real = native.lib()
     proxy = TimingProxy(real)
     native._LIB = proxy
     try:
         for _ in range(iters):
-            net(pts)
+            fn()
         torch.cuda.synchronize()
     finally:
         native._LIB = real
@@ -132,13 +138,19 @@ def profile_stages(net, pts, iters):
     return stages
 
 
+def _profile_json():
+    try:
+        return json.load(open(os.path.join(ROOT, TRAFFIC_PROFILE)))
+    except Exception:
+        return None
+
+
 def _pmc_traffic(stage):
-    """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC pass
-    (profiles/r01_traffic.json, made by tools/gpu_prof.sh + tools/summarize_prof.py: FETCH_SIZE doubled per the
-    gfx950 note of MI355X_MICROARCH.md + WRITE_SIZE).  Only for kernels whose template instance is unique to
-    the stage; None otherwise or when the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if not os.path.exists(path):
+    """HBM bytes per launch of the stage's kernel from the COMMITTED rocprofv3 PMC pass (profiles/, made by
+    tools/gpu_prof.sh + tools/summarize_prof.py: FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md +
+    WRITE_SIZE).  A snapshot keyed by kernel name, NOT collected in this run; None when the file is absent."""
+    d = _profile_json()
+    if d is None:
         return None
     label = stage["label"]
     name = None
@@ -157,20 +169,16 @@ def _pmc_traffic(stage):
             ppt *= 2
         name = "fpsdist_reg_kernel<%d>" % ppt
     try:
-        d = json.load(open(path))
         return int(d[name]["hbm_bytes_per_launch"]) if name in d else None
     except Exception:
         return None
 
 
 def _pmc_mlp_util():
-    """MFMA utilisation of the grouped-MLP kernels from the committed PMC pass (profiles/r01_traffic.json):
-    sum of SQ_VALU_MFMA_BUSY_CYCLES over sum of (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), per launch, over the MLP
-    kernels of one step.  None when the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    try:
-        d = json.load(open(path))
-    except Exception:
+    """MFMA utilisation of the grouped-MLP kernels from the committed PMC pass: sum of SQ_VALU_MFMA_BUSY_CYCLES over
+    sum of (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), per launch, over the MLP kernels of one step."""
+    d = _profile_json()
+    if d is None:
         return None
     busy = cap = 0.0
     per_kernel = {}
@@ -182,10 +190,10 @@ def _pmc_mlp_util():
     if cap <= 0:
         return None
     return dict(mfma_util=round(busy / cap, 4), per_kernel=per_kernel,
-                source="profiles/r01_traffic.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE)")
+                source="committed profile %s (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE), not this run" % TRAFFIC_PROFILE)
 
 
-def roofline_of(stage):
+def roofline_of(stage, frames):
     k = stage["kernel"]
     if k in ("sa_group_mlp_max", "sa_dense", "sa_calc_square_dist_split", "sa_calc_square_dist_split_ws"):
         peak = MFMA_BF16_PEAK_TF if not k.startswith("sa_calc_square_dist") else VALU_F32_PEAK_TF
@@ -193,28 +201,30 @@ def roofline_of(stage):
         return dict(kernel=stage["label"], bound="mfma", achieved=a, peak=peak, unit="TFLOP/s",
                     frac=round(a / peak, 5), traffic=None)
     a = stage.get("gbs", 0.0)
+    tr = _pmc_traffic(stage)
     r = dict(kernel=stage["label"], bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s",
-             frac=round(a / HBM_PEAK_GBS, 6), traffic=_pmc_traffic(stage),
-             algorithmic_bytes=int(stage["mbytes"] * 1e6))
-    if k.startswith("sa_fps"):
-        # FPS is a serial dependent chain on ONE CU per frame: neither HBM- nor MFMA-bound;
-        # the fp32 VALU rate is the meaningful ceiling, quoted beside the (tiny) algorithmic HBM figure.
-        r["note"] = ("latency/VALU-bound serial chain; valu_tflops counts the reference's n*(m-1) pair evaluations "
-                     "(the wave-bucket kernel used for n >= 8192 skips ~94% of them, bit-identically)")
-        r["valu_tflops"] = stage.get("tflops", 0.0)
-        r["valu_frac"] = round(stage.get("tflops", 0.0) / VALU_F32_PEAK_TF, 5)
-        # one workgroup (one CU) per frame by construction: fraction of the fp32 VALU peak of the CUs it can use
-        r["cus_used"] = CUS_USED_FPS
-        r["valu_frac_of_cus_used"] = round(stage.get("tflops", 0.0) / (VALU_F32_PEAK_TF * CUS_USED_FPS / 256.0), 4)
+             frac=round(a / HBM_PEAK_GBS, 6), traffic=tr,
+             traffic_source=("committed profile %s, not collected in this run" % TRAFFIC_PROFILE) if tr is not None else None,
+             algorithmic_bytes=int(stage["mbytes"] * 1e6), avg_launch_ms=stage.get("avg_ms"))
+    if k.startswith("sa_fps") or k == "sa_farthest_point_sample":
+        # FPS is a serial dependent chain on ONE CU per frame: neither HBM- nor MFMA-bound; what
+        # bounds it is the latency of one pick.
+        n = int(stage["label"].split("n=")[1].split("->")[0])
+        m = int(stage["label"].split("->")[1].split()[0])
+        r["note"] = ("latency-bound serial chain (one workgroup = one CU per frame, m-1 dependent picks): the HBM "
+                     "fraction is tiny by nature; us_per_pick is the figure of merit")
+        r["us_per_pick"] = round(stage.get("avg_ms", 0.0) * 1e3 / max(m - 1, 1), 4)
+        r["cus_used"] = frames
+        r["reference_pair_evaluations"] = frames * (m - 1) * n
     return r
 
 
-def cpu_baseline(arch, params, batch, budget_s=20.0):
+def cpu_baseline(arch, params, batch, points, budget_s=20.0):
     """The CPU oracle (a scalar C/OpenMP restatement of the reference kernels; the reference has no CPU
     path of its own) on `batch` frames of the same workload, repeated until ~budget_s."""
     from oracle import sa_oracle as O
     cfgs, syn = pkg("configs"), pkg("synthetic")
-    pts = syn.kitti_like_batch(batch)
+    pts = syn.kitti_like_batch(batch, n=points)
     O.lib()
     t0 = time.time()
     reps = 0
@@ -225,44 +235,97 @@ def cpu_baseline(arch, params, batch, budget_s=20.0):
         if dt > budget_s * 0.6 or reps >= 4:
             break
     return dict(value=round(reps * batch / dt, 4), unit="frames/s", cores=os.cpu_count() or 1, kind="port",
-                sample="%d x %d frames of the same 16384-pt workload through oracle.sa_backbone "
-                       "(OpenMP over frames/queries), %.1f s" % (reps, batch, dt))
+                sample="%d x %d frames of the same %d-pt workload through oracle.sa_backbone "
+                       "(OpenMP over frames/queries), %.1f s" % (reps, batch, points, dt))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=128)
-    ap.add_argument("--warmup", type=int, default=24)
-    ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step (BASELINE.json configs[1])")
-    ap.add_argument("--points", type=int, default=16384)
-    ap.add_argument("--streams", type=int, default=16, help="HIP streams the steps are issued on")
-    ap.add_argument("--profile-iters", type=int, default=3)
-    ap.add_argument("--graphs", type=int, default=1, help="1 (default): capture one hipGraph per stream and replay it; 0: eager launches")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------------ launch
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
-    sh = pkg("sharding")
-    rank, local_rank, world = sh.init()
-    assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    pkg("utils._native").lib()
+
+def self_spawn(args):
+    """`python bench.py --gpus N` outside torchrun: re-exec under torch.distributed.run with one rank per GPU
+    (the N in-graph towers of lib/core/trainer.py:120-155 become N processes)."""
+    if not args.launch_check:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            sys.exit("bench.py --gpus %d: only %d GPU(s) visible on this node -- refusing to run fewer ranks than "
+                     "requested" % (args.gpus, have))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def launch_check(args, sh):
+    """Launch path only (CPU-capable, gloo when no GPU): spawn, rendezvous, world == --gpus, one reduction."""
+    rank, local_rank, world = sh.init(backend=None if torch.cuda.is_available() else "gloo")
+    assert world == args.gpus, "launched with WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
+    frames = sh.frames_of_rank(0, args.batch * world, rank, world)
+    sh.barrier()
+    t_max, total = sh.reduce_timing(1.0 + rank, len(frames))
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "frames_total": total, "t_max": t_max}))
+    sh.barrier()
+
+
+# ------------------------------------------------------------------------------------------------ workloads
+def timed_region(sh, dev, run, steps, warmup, frames_per_step):
+    run(warmup)
+    torch.cuda.synchronize()
+    sh.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = run(steps)
+    host_issue_ms = (time.perf_counter() - t0) / steps * 1e3
+    torch.cuda.synchronize()
+    sh.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t_max, frames_total = sh.reduce_timing(elapsed, steps * frames_per_step, device=dev)
+    return t_max, frames_total, host_issue_ms, outs
+
+
+def mlp_row_stats(net, pts):
+    """Rows of the grouped tensor per step: nominal (m x nsample, what the reference's conv2d evaluates), distinct
+    (sum of clamp(cnt, 1, ns)) and evaluated (8-row granules of the plan), from the plan headers of one eager step."""
+    lu = pkg("utils.layers_util")
+    lu.PLAN_LOG = []
+    net(pts)
+    torch.cuda.synchronize()
+    log, lu.PLAN_LOG = lu.PLAN_LOG, None
+    nominal = distinct = evaluated = 0
+    fl_nom = fl_eval = 0.0
+    for (b, m, ns, macs, plan) in log:
+        h = plan[:4].cpu().tolist()
+        nominal += b * m * ns
+        distinct += h[2]
+        evaluated += h[0] * 8
+        fl_nom += 2.0 * b * m * ns * macs
+        fl_eval += 2.0 * h[0] * 8 * macs
+    return dict(nominal=nominal, distinct=distinct, evaluated=evaluated,
+                evaluated_frac=round(evaluated / max(nominal, 1), 4),
+                gflop_nominal=round(fl_nom / 1e9, 3), gflop_evaluated=round(fl_eval / 1e9, 3))
+
+
+def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
     cfgs, syn = pkg("configs"), pkg("synthetic")
     arch = cfgs.KITTI_3DSSD_ARCH
     params = syn.random_backbone_params(arch)
     net = pkg("backbone").SABackbone(arch, params, dev, cfgs.KITTI_MAX_TRANSLATE_RANGE)
-
     # this rank's frames: global frame f -> rank f mod world (weak scaling: `batch` frames per GPU)
     frames = sh.frames_of_rank(0, args.batch * world, rank, world)
-    pts = torch.from_numpy(np.stack([syn.kitti_like_frame(f, args.points) for f in frames])).to(dev)
-
-    global CUS_USED_FPS
-    CUS_USED_FPS = len(frames)          # one FPS workgroup (one CU) per frame
+    pts = torch.from_numpy(np.stack([syn.kitti_like_frame(f, points) for f in frames])).to(dev)
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
-
     graphs = None
-    if args.graphs:
+    use_graphs = bool(args.graphs) and graphs_ok
+    if use_graphs:
         # one captured hipGraph per stream (launch-bound host loop -> one replay per step); every graph
         # owns its intermediate and output buffers, the input frames are static
         for _ in range(2):
@@ -289,20 +352,8 @@ def main():
                     outs.append((xl[-1], fl[-1]))
         return outs
 
-    run(args.warmup)
-    torch.cuda.synchronize()
-    sh.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    outs = run(args.steps)
-    host_issue_ms = (time.perf_counter() - t0) / args.steps * 1e3
-    torch.cuda.synchronize()
-    sh.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    t_max, frames_total = sh.reduce_timing(elapsed, args.steps * len(frames), device=dev)
+    t_max, frames_total, host_issue_ms, outs = timed_region(sh, dev, run, args.steps, args.warmup, len(frames))
     assert outs[-1][1].shape == (len(frames), 256, 512)
-
     # single-stream latency of one batch (no overlap), for the record
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -310,12 +361,29 @@ def main():
         net(pts)
     torch.cuda.synchronize()
     latency_ms = (time.perf_counter() - t1) / 3 * 1e3
-
-    if rank == 0:
-        stages = profile_stages(net, pts, args.profile_iters)
-        tot = {}
-        for s in stages:
-            tot[s["label"]] = s["avg_ms"] * s["calls_per_step"]
+    if rank != 0:
+        return None
+    stages = profile_stages(lambda: net(pts), args.profile_iters)
+    rows = mlp_row_stats(net, pts)
+    ms_step = t_max / args.steps * 1e3
+    line = {
+        "metric": "point-cloud frames/sec through full SA backbone, KITTI 16384-pt" if points == 16384 else
+                  "point-cloud frames/sec through full SA backbone, %d-pt frames" % points,
+        "value": round(frames_total / t_max, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16 (split hi/lo, 3 MFMA passes, fp32 accumulate) for the grouped MLP; fp32 for FPS / ball query",
+        "data": "synthetic KITTI-shape frames (seeded), random-init weights",
+        "config": {"workload": "%s: full 3DSSD SA backbone (3dssd.yaml rows 1-6), %d-pt frames, batch=%d per GPU"
+                               % (tag, points, args.batch),
+                   "frames_per_step_per_gpu": len(frames), "streams": len(streams),
+                   "sharding": "frame f -> rank f mod N, no data-path collective"},
+        "single_stream_batch_latency_ms": round(latency_ms, 3),
+        "host_issue_ms_per_step": round(host_issue_ms, 3),
+        "hip_graphs": use_graphs,
+        "mlp_rows_per_step": rows,
+    }
+    if stages:
         dom = max(stages, key=lambda s: s["avg_ms"] * s["calls_per_step"])
         mlp = [s for s in stages if s["kernel"] == "sa_group_mlp_max"]
         mlp_ms = sum(s["avg_ms"] * s["calls_per_step"] for s in mlp)
@@ -323,39 +391,125 @@ def main():
         bq = [s for s in stages if s["kernel"] in ("sa_query_ball_point_multi", "sa_query_ball_point_grid")]
         bq_ms = sum(s["avg_ms"] * s["calls_per_step"] for s in bq)
         bq_mb = sum(s["mbytes"] * s["calls_per_step"] for s in bq)
-        line = {
-            "metric": "point-cloud frames/sec through full SA backbone, KITTI 16384-pt",
-            "value": round(frames_total / t_max, 2),
-            "unit": "frames/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(t_max / args.steps * 1e3, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "bf16 (split hi/lo, 3 MFMA passes, fp32 accumulate) for the grouped MLP; fp32 for FPS / ball query",
-            "data": "synthetic KITTI-shape frames (seeded), random-init weights",
-            "config": {"workload": "configs[1]: full 3DSSD SA backbone (3dssd.yaml rows 1-6), %d-pt frames, batch=%d per GPU"
-                                   % (args.points, args.batch),
-                       "frames_per_step_per_gpu": len(frames), "streams": len(streams),
-                       "sharding": "frame f -> rank f mod N, no data-path collective"},
-            "single_stream_batch_latency_ms": round(latency_ms, 3),
-            "host_issue_ms_per_step": round(host_issue_ms, 3),
-            "hip_graphs": bool(args.graphs),
-            "roofline": roofline_of(dom),
-            "roofline_grouped_mlp": {"bound": "mfma", "achieved": round(mlp_fl / mlp_ms, 3) if mlp_ms else 0.0,
-                                     "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
-                                     "frac": round(mlp_fl / mlp_ms / MFMA_BF16_PEAK_TF, 5) if mlp_ms else 0.0,
-                                     "note": "algorithmic fp32-equivalent flops; the split-bf16 form issues 3x as many MFMA flops",
-                                     "pmc": _pmc_mlp_util()},
-            "roofline_ball_query": {"bound": "hbm", "achieved": round(bq_mb / bq_ms, 2) if bq_ms else 0.0,
-                                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": round(bq_mb / bq_ms / HBM_PEAK_GBS, 6) if bq_ms else 0.0},
-            "stages": stages,
-        }
-        if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(arch, params, min(args.batch, 8))
+        gflop_step = sum(s["gflop"] * s["calls_per_step"] for s in stages if s["kernel"] in ("sa_group_mlp_max", "sa_dense"))
+        mb_step = sum(s["mbytes"] * s["calls_per_step"] for s in stages)
+        line["roofline"] = roofline_of(dom, len(frames))
+        line["whole_step"] = {
+            "mlp_gflop_algorithmic": round(gflop_step, 2),
+            "mfma_tflops": round(gflop_step / ms_step, 2), "mfma_frac_of_bf16_peak": round(gflop_step / ms_step / MFMA_BF16_PEAK_TF, 5),
+            "algorithmic_mbytes": round(mb_step, 2), "hbm_gbs": round(mb_step / ms_step, 2),
+            "hbm_frac": round(mb_step / ms_step / HBM_PEAK_GBS, 5),
+            "note": "algorithmic work of one step (SURVEY 8d) / ms_per_step of the overlapped multi-stream run"}
+        line["roofline_grouped_mlp"] = {
+            "bound": "mfma", "achieved": round(mlp_fl / mlp_ms, 3) if mlp_ms else 0.0, "peak": MFMA_BF16_PEAK_TF,
+            "unit": "TFLOP/s", "frac": round(mlp_fl / mlp_ms / MFMA_BF16_PEAK_TF, 5) if mlp_ms else 0.0,
+            "evaluated_tflops": round(rows["gflop_evaluated"] / mlp_ms, 3) if mlp_ms else 0.0,
+            "note": "achieved = the reference's m x nsample rows (SURVEY 8d, 30.9 GFLOP/frame) / single-stream kernel "
+                    "time incl. the row-plan kernels; evaluated_tflops counts only the rows the kernels run (distinct "
+                    "rows of each ball, 8-row granules); the split-bf16 form issues 3x as many MFMA flops as either",
+            "pmc": _pmc_mlp_util()}
+        line["roofline_ball_query"] = {
+            "bound": "hbm", "achieved": round(bq_mb / bq_ms, 2) if bq_ms else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(bq_mb / bq_ms / HBM_PEAK_GBS, 6) if bq_ms else 0.0,
+            "north_star_target_40pct_hbm": "not met / not applicable on the benchmarked path: group_point is fused "
+                                           "into the MLP gather (the 87 MB/frame grouped tensor is never written), and "
+                                           "the grid ball query moves 19 MB per launch and is latency-bound, not "
+                                           "bandwidth-bound"}
+        line["stages"] = stages
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(arch, params, min(args.batch, 8), points)
+    return line
+
+
+def workload_ffps_isolated(args, sh, rank, world, dev):
+    """BASELINE.json configs[2]: feature-distance FPS isolated, [32, 16384, 3+64] -> 4096 per frame (the fused
+    on-the-fly form, SURVEY 8d: the matrix form would need a 1.07 GB matrix per frame)."""
+    S, syn = pkg("utils.tf_ops.sampling.tf_sampling"), pkg("synthetic")
+    batch, n, c, m = 32, 16384, 67, 4096
+    rng = np.random.default_rng(20260925)
+    frames = sh.frames_of_rank(0, batch * world, rank, world)
+    xyz = np.stack([syn.kitti_like_frame(f, n)[:, :3] for f in frames])
+    feat = rng.normal(0, 0.5, (len(frames), n, c - 3)).astype(np.float32)
+    pts = torch.from_numpy(np.concatenate([xyz, feat], 2)).to(dev)
+
+    def run(k):
+        return [S.farthest_point_sample(m, pts) for _ in range(k)]
+
+    t_max, frames_total, host_issue_ms, outs = timed_region(sh, dev, run, args.steps, args.warmup, len(frames))
+    assert outs[-1].shape == (len(frames), m)
+    if rank != 0:
+        return None
+    stages = profile_stages(lambda: S.farthest_point_sample(m, pts), max(1, min(args.profile_iters, 2)))
+    line = {"metric": "frames/sec through feature-distance FPS 16384->4096 (3+64 channels), isolated",
+            "value": round(frames_total / t_max, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(t_max / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic KITTI-shape xyz + N(0,0.5) features (seeded)",
+            "config": {"workload": "configs[2]: F-FPS isolated, [%d,%d,%d] -> %d per frame, batch=%d per GPU" % (batch, n, c, m, batch),
+                       "frames_per_step_per_gpu": len(frames)},
+            "host_issue_ms_per_step": round(host_issue_ms, 3)}
+    if stages:
+        line["roofline"] = roofline_of(max(stages, key=lambda s: s["avg_ms"]), len(frames))
+        line["stages"] = stages
+    if not args.no_cpu_baseline:
+        from oracle import sa_oracle as O
+        O.lib()
+        nb = min(len(frames), os.cpu_count() or 1, 32)
+        sub = pts[:nb].cpu().numpy()
+        t0 = time.time()
+        O.farthest_point_sample(m, sub)
+        dt = time.time() - t0
+        line["cpu_baseline"] = dict(value=round(nb / dt, 4), unit="frames/s", cores=min(os.cpu_count() or 1, nb), kind="port",
+                                    sample="%d frames of the same workload through oracle.farthest_point_sample "
+                                           "(OpenMP over frames), %.1f s" % (nb, dt))
+    return line
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="configs1", choices=["configs1", "configs2", "configs4"],
+                    help="BASELINE.json configs[1] (default, the metric's configuration), configs[2], configs[4]")
+    ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step")
+    ap.add_argument("--points", type=int, default=None)
+    ap.add_argument("--streams", type=int, default=None, help="HIP streams the steps are issued on")
+    ap.add_argument("--profile-iters", type=int, default=3)
+    ap.add_argument("--graphs", type=int, default=1, help="1 (default): capture one hipGraph per stream and replay it; 0: eager launches")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--launch-check", action="store_true", help="exercise only the launch path (works without a GPU)")
+    args = ap.parse_args()
+    assert args.gpus >= 1
+    defaults = {"configs1": dict(steps=128, warmup=24, batch=8, points=16384, streams=16),
+                "configs2": dict(steps=4, warmup=1, batch=32, points=16384, streams=1),
+                "configs4": dict(steps=16, warmup=4, batch=16, points=65536, streams=4)}[args.workload]
+    for k, v in defaults.items():
+        if getattr(args, k) is None:
+            setattr(args, k, v)
+
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        self_spawn(args)                                # does not return
+
+    sh = pkg("sharding")
+    if args.launch_check:
+        return launch_check(args, sh)
+    rank, local_rank, world = sh.init()
+    assert world == args.gpus, ("bench.py --gpus %d but WORLD_SIZE=%d: launch with `python bench.py --gpus N` or "
+                                "torch.distributed.run --nproc-per-node N" % (args.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
+    assert local_rank < torch.cuda.device_count(), "rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count())
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    pkg("utils._native").lib()
+
+    if args.workload == "configs1":
+        line = workload_backbone(args, sh, rank, world, dev, args.points, True, "configs[1]")
+    elif args.workload == "configs4":
+        # 65536-pt frames: layer-1 FPS is the cooperative multi-workgroup kernel, which cannot be graph-captured
+        line = workload_backbone(args, sh, rank, world, dev, args.points, False, "configs[4]")
+    else:
+        line = workload_ffps_isolated(args, sh, rank, world, dev)
+    if rank == 0:
         print(json.dumps(line))
     sh.barrier()
 

@@ -116,6 +116,11 @@ int sa_query_ball_point_grid(int b, int n, int m, int nbands, const float *rmin,
  * device scratch of sa_group_mlp_max_ws_bytes(b, m, ns) bytes (the per-call row plan).  flags bit 0: evaluate all
  * nsample rows of every ball instead (A/B measurements). */
 unsigned long sa_group_mlp_max_ws_bytes(int b, int m, int ns);
+/* The row plans of all scales of a layer in ONE launch: cnt[i] = pts_cnt of scale i, ws[i] = that scale's scratch,
+ * out_off[i] / nout[i] = where scale i's channels go in out.  The layer's sa_group_mlp_max calls then pass
+ * flags | 2 (plan already built). */
+int sa_group_mlp_plan(int b, int m, int nscale, const int *ns, const int *const *cnt, void *const *ws, float *out,
+                      int out_stride, const int *out_off, const int *nout, int flags, sa_stream_t stream);
 int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float *xyz, const float *feat,
                      const float *new_xyz, const int *idx, const int *cnt, int nl, const int *dims,
                      const void *const *wpack, const float *const *bias, float *out, int out_stride,

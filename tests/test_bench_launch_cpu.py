@@ -1,0 +1,39 @@
+"""`python bench.py --gpus N` launches N ranks itself (one process per GPU, lib/core/trainer.py:120-155's N towers)
+and refuses to run fewer than asked.  The launch path is exercised here on the CPU (gloo rendezvous on 127.0.0.1)."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+
+def _run(*flags):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(flags), capture_output=True, text=True,
+                          env=env, timeout=300)
+
+
+def test_self_spawn_launches_the_requested_number_of_ranks():
+    r = _run("--gpus", "2", "--launch-check")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["launch_check"] is True and line["n_gpus"] == 2
+    assert line["frames_total"] == 16 and line["t_max"] == 2.0      # 8 frames per rank; max over ranks of 1 + rank
+
+
+def test_more_gpus_than_visible_fails_loudly():
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    r = _run("--gpus", str(have + 2), "--steps", "1", "--warmup", "0")
+    assert r.returncode != 0
+    assert "GPU(s) visible" in (r.stderr + r.stdout)
+
+
+def test_world_size_must_match_gpus_flag():
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--launch-check"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1 but --gpus 4" in r.stderr
