@@ -41,7 +41,7 @@ DFPS_SIDE_STREAM = int(__import__("os").environ.get("SA_DFPS_SIDE_STREAM", "2"))
 _ABLATE = set(filter(None, __import__("os").environ.get("SA_ABLATE", "").split(",")))
 PLAN_LOG = None     # set to a list to collect (b, m, nsample, MACs per row, plan tensor) of every fused-MLP call
 MLP_PLAN_FLAGS = int(__import__("os").environ.get("SA_MLP_DENSE_PLAN", "0"))
-GRID_BALL_QUERY_MIN_N = int(__import__("os").environ.get("SA_GRID_BQ_MIN_N", "512"))
+GRID_BALL_QUERY_MIN_N = int(__import__("os").environ.get("SA_GRID_BQ_MIN_N", "2048"))
 MAX_TRANSLATE_RANGE = (-3.0, -2.0, -3.0)
 
 
@@ -127,11 +127,11 @@ def _identity_idx(bs, start, cnt, dev):
     return _IDENTITY_IDX[key]
 
 
-def _side_stream(main):
-    """One helper stream per issuing stream: D-FPS runs there while the F-FPS chain (distance matrix +
+def _side_stream(main, which=0):
+    """Helper streams per issuing stream: D-FPS runs there while the F-FPS chain (distance matrix +
     FPS on it) runs on the issuing stream -- the two halves of 'FS' / of a two-range layer are
     independent (layers_util.py:93-106)."""
-    key = (main.device, main.cuda_stream)
+    key = (main.device, main.cuda_stream, which)
     if key not in _SIDE_STREAMS:
         _SIDE_STREAMS[key] = torch.cuda.Stream(device=main.device)
     return _SIDE_STREAMS[key]
