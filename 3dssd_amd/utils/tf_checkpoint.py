@@ -15,7 +15,8 @@ string table) from its published description:
   BundleEntryProto: 1 dtype, 2 shape (TensorShapeProto: repeated field 2 {1: size}), 3 shard_id, 4 offset, 5 size,
       6 crc32c (fixed32, masked), 7 slices (partitioned variables -- not supported here).
 
-Format parity is UNPINNED: no TensorFlow-written checkpoint exists in this environment to read; the reader is checked
+Format parity is UNPINNED against TensorFlow itself: no TensorFlow-written checkpoint exists in this environment to read.  The reader is checked
+against a complete two-shard bundle assembled byte by byte from the format description inside the test (independent of the writer),
 against the writer below, against the CRC-32C known-answer vectors, and against hand-assembled blocks
 (tests/test_tf_checkpoint.py).  Everything is host-side numpy; the arrays go on to `VariableStore` (weights.py).
 """

@@ -124,3 +124,77 @@ def test_velodyne_files_to_kitti_result_files(gpu, tmp_path):
         x1, y1, x2, y2 = map(float, f[4:8])
         assert 0 <= x1 <= x2 <= 1224 and 0 <= y1 <= y2 <= 370
         assert 0.0 <= float(f[15]) <= 1.0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Against the REFERENCE'S OWN numpy functions (lib/utils/kitti_util.py, lib/utils/points_filter.py, the resampling
+# statements of kitti_dataloader.py:137-151): tests/golden/kitti_input_ref.npz, written by
+# tests/golden/make_golden_kitti.py, which imports them from /root/reference under stub tensorflow / cv2 modules.
+import hashlib
+import os
+
+
+@pytest.fixture(scope="module")
+def ref():
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kitti_input_ref.npz")
+    assert os.path.exists(path), "tests/golden/kitti_input_ref.npz missing (tests/golden/make_golden_kitti.py)"
+    return np.load(path)
+
+
+def _sha(a):
+    return hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _scan(ref):
+    rng = np.random.default_rng(int(ref["scan_seed"]))
+    n = int(ref["scan_n"])
+    scan = np.stack([rng.uniform(0, 80, n), rng.uniform(-40, 40, n), rng.uniform(-2.5, 1.0, n), rng.uniform(0, 1, n)], -1).astype(np.float32)
+    assert _sha(scan) == str(ref["scan_sha1"])
+    return scan
+
+
+def test_calibration_and_projections_equal_the_reference(ref, tmp_path):
+    K = pkg("dataset.kitti_input")
+    p = tmp_path / "000000.txt"
+    p.write_text(str(ref["calib_txt"]))
+    calib = K.Calibration(str(p))
+    assert np.array_equal(calib.P, ref["P"]) and np.array_equal(calib.V2C, ref["V2C"]) and np.array_equal(calib.R0, ref["R0"])
+    scan = _scan(ref)
+    rect = calib.project_velo_to_rect(scan[:, :3])
+    uv = calib.project_rect_to_image(rect)
+    assert np.array_equal(rect[:256], ref["rect_head"]) and _sha(rect) == str(ref["rect_sha1"])     # same numpy ops: bit-equal
+    assert np.array_equal(uv[:256], ref["uv_head"]) and _sha(uv) == str(ref["uv_sha1"])
+
+
+def test_crop_masks_and_kept_indices_equal_the_reference(ref, tmp_path):
+    K = pkg("dataset.kitti_input")
+    p = tmp_path / "000000.txt"
+    p.write_text(str(ref["calib_txt"]))
+    calib = K.Calibration(str(p))
+    scan = _scan(ref)
+    h, w = [int(v) for v in ref["image_shape"]]
+    rect = calib.project_velo_to_rect(scan[:, :3])
+    n = len(scan)
+    assert np.array_equal(K.point_filter_in_image(rect, calib, h, w), np.unpackbits(ref["mask_image"])[:n].astype(bool))
+    assert np.array_equal(K.point_filter_extents(rect, K.KITTI_POINT_CLOUD_RANGE), np.unpackbits(ref["mask_extents"])[:n].astype(bool))
+    crop = K.crop_frame(scan, calib, (h, w))
+    keep = ref["keep"]
+    assert crop.shape == (len(keep), 4)
+    assert np.array_equal(crop[:, :3], rect[keep]) and np.array_equal(crop[:, 3], scan[keep, 3].astype(np.float64))
+    edge = ref["edge_pts"]
+    assert np.array_equal(K.point_filter_extents(edge, K.KITTI_POINT_CLOUD_RANGE), ref["edge_extents"])
+    assert np.array_equal(K.point_filter_in_image(edge, calib, h, w), ref["edge_image"])
+
+
+@pytest.mark.parametrize("name", ["many", "few", "exact"])
+def test_resample_draws_equal_the_reference_statements(ref, name):
+    """kitti_dataloader.py:137-151 executed from the reference's own text with np.random.seed(s); resample() with a
+    legacy RandomState(s) makes the same calls in the same order -> the same rows, duplicates included."""
+    K = pkg("dataset.kitti_input")
+    n, seed = int(ref["resample_%s_n" % name]), int(ref["resample_%s_seed" % name])
+    pts = np.arange(n * 4, dtype=np.float64).reshape(n, 4)
+    got = K.resample(pts, K.KITTI_POINTS_NUM, rng=np.random.RandomState(seed))
+    idx = ref["resample_%s_idx" % name]
+    assert got.shape == (K.KITTI_POINTS_NUM, 4) and np.array_equal(got, pts[idx])
+    if name == "few":
+        assert len(np.unique(idx)) == n and len(idx) - n == K.KITTI_POINTS_NUM - n      # every point once + duplicates

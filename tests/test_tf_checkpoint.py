@@ -61,7 +61,7 @@ def _variables(rng, n_layers=40):
     return v
 
 
-def test_round_trip_multi_block_and_filters(tmp_path):
+def test_round_trip_with_own_writer_multi_block_and_filters(tmp_path):
     C = pkg("utils.tf_checkpoint")
     rng = np.random.default_rng(1)
     v = _variables(rng)
@@ -87,7 +87,7 @@ def test_round_trip_multi_block_and_filters(tmp_path):
     assert C.latest_checkpoint(str(tmp_path)) is None
 
 
-def test_corruption_is_detected(tmp_path):
+def test_corruption_of_files_from_own_writer_is_detected(tmp_path):
     C = pkg("utils.tf_checkpoint")
     v = _variables(np.random.default_rng(2), n_layers=6)
     prefix = str(tmp_path / "model")
@@ -116,7 +116,7 @@ def test_corruption_is_detected(tmp_path):
         C.load_checkpoint(prefix)
 
 
-def test_backbone_variables_through_a_checkpoint(tmp_path):
+def test_backbone_variables_through_a_checkpoint_from_own_writer(tmp_path):
     """The reference's variable names (layers_util.py:175, tf_util.py:96,111,439-442) written as a checkpoint with
     Adam slots, read back, folded: bitwise the same (W', b') as from the in-memory dict."""
     C, W = pkg("utils.tf_checkpoint"), pkg("utils.weights")
@@ -136,3 +136,87 @@ def test_backbone_variables_through_a_checkpoint(tmp_path):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     w, b = W.fold_conv_bn(store.params, "vote/vote_offsets", bn=False)
     assert w.shape[1] == 3
+
+
+def test_hand_assembled_two_shard_bundle_with_restart_points(tmp_path):
+    """A complete bundle assembled BYTE BY BYTE here from the published format (TensorFlow tensor_bundle.cc /
+    table_builder.cc), without any of the module's writer functions: a data block whose second restart point starts an
+    uncompressed key, keys prefix-compressed against their predecessor in between, a header entry announcing TWO
+    shards, entries that point into `.data-00000-of-00002` and `.data-00001-of-00002`, an index block with one
+    separator key, the 48-byte footer.  Pins the READER against the spec as far as this sandbox allows (no
+    TensorFlow-written file exists here; checksums use the module's CRC-32C, itself pinned by the RFC 3720 vectors)."""
+    C = pkg("utils.tf_checkpoint")
+
+    def varint(v):
+        out = bytearray()
+        while True:
+            b = v & 0x7F
+            v >>= 7
+            out.append(b | (0x80 if v else 0))
+            if not v:
+                return bytes(out)
+
+    def entry_proto(dtype, shape, shard, offset, size, crc):
+        dims = b"".join(b"\x12" + varint(len(d)) + d for d in (b"\x08" + varint(x) for x in shape))
+        out = b"\x08" + varint(dtype) + b"\x12" + varint(len(dims)) + dims
+        if shard:
+            out += b"\x18" + varint(shard)
+        if offset:
+            out += b"\x20" + varint(offset)
+        return out + b"\x28" + varint(size) + b"\x35" + struct.pack("<I", crc)
+
+    def masked(raw):
+        c = C.crc32c(raw)
+        return (((c >> 15) | (c << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+
+    a = np.arange(12, dtype=np.float32).reshape(3, 4) * 0.5              # shard 0, offset 0
+    b = np.array([7, -3, 2 ** 40], np.int64)                             # shard 1, offset 16 (after 16 junk bytes)
+    c = np.array(2.5, np.float32)                                        # shard 0, offset 48, scalar (no dims)
+    shard0 = a.tobytes() + c.tobytes()
+    shard1 = b"\xEE" * 16 + b.tobytes()
+    vals = {b"": b"\x08\x02\x1a\x02\x08\x01",                          # BundleHeaderProto: num_shards 2, version{producer 1}
+            b"layer1/conv0_0/biases": entry_proto(1, [3, 4], 0, 0, 48, masked(a.tobytes())),
+            b"layer1/conv0_0/steps": entry_proto(9, [3], 1, 16, 24, masked(b.tobytes())),
+            b"layer2/scale": entry_proto(1, [], 0, 48, 4, masked(c.tobytes()))}
+    keys = sorted(vals)
+    # data block, restart interval 2: entries 0 and 2 are restart points (full keys), 1 and 3 prefix-compressed
+    blk, restarts, prev = bytearray(), [], b""
+    for i, k in enumerate(keys):
+        shared = 0
+        if i % 2 == 0:
+            restarts.append(len(blk))
+        else:
+            while shared < min(len(prev), len(k)) and prev[shared] == k[shared]:
+                shared += 1
+        blk += varint(shared) + varint(len(k) - shared) + varint(len(vals[k])) + k[shared:] + vals[k]
+        prev = k
+    assert restarts[1] > 0 and blk[restarts[1]] == 0                      # the second restart entry shares 0 bytes
+    blk += b"".join(struct.pack("<I", r) for r in restarts) + struct.pack("<I", len(restarts))
+    data_block = bytes(blk)
+    f = bytearray(data_block + b"\x00" + struct.pack("<I", masked(data_block + b"\x00")))
+    meta_off = len(f)                                                     # empty metaindex block
+    meta = struct.pack("<II", 0, 1)
+    f += meta + b"\x00" + struct.pack("<I", masked(meta + b"\x00"))
+    idx_off = len(f)
+    handle = varint(0) + varint(len(data_block))
+    sep = b"m"                                                            # any key >= the last key of the data block
+    iblk = varint(0) + varint(len(sep)) + varint(len(handle)) + sep + handle + struct.pack("<II", 0, 1)
+    f += iblk + b"\x00" + struct.pack("<I", masked(iblk + b"\x00"))
+    foot = varint(meta_off) + varint(len(meta)) + varint(idx_off) + varint(len(iblk))
+    f += foot + b"\x00" * (40 - len(foot)) + struct.pack("<Q", 0xDB4775248B80FB57)
+    prefix = str(tmp_path / "model.ckpt-7")
+    open(prefix + ".index", "wb").write(bytes(f))
+    open(prefix + ".data-00000-of-00002", "wb").write(shard0)
+    open(prefix + ".data-00001-of-00002", "wb").write(shard1)
+    assert [k for k, _ in C.read_table(prefix + ".index")] == keys
+    assert C.list_variables(prefix) == [("layer1/conv0_0/biases", (3, 4), np.float32), ("layer1/conv0_0/steps", (3,), np.int64),
+                                        ("layer2/scale", (), np.float32)]
+    got = C.load_checkpoint(prefix)
+    assert np.array_equal(got["layer1/conv0_0/biases"], a) and np.array_equal(got["layer1/conv0_0/steps"], b)
+    assert got["layer2/scale"].shape == () and got["layer2/scale"] == np.float32(2.5)
+    # a flipped byte in the second shard is caught by the per-tensor checksum
+    bad = bytearray(shard1)
+    bad[20] ^= 1
+    open(prefix + ".data-00001-of-00002", "wb").write(bytes(bad))
+    with pytest.raises(ValueError, match="checksum"):
+        C.load_checkpoint(prefix)
