@@ -32,6 +32,9 @@ class PostProcessor:
         """pred_anchors_3d [bs,n,1,7] or [bs,n,7] (class-agnostic boxes of the anchor-free head), pred_score
         [bs,n,cls].  Appends pred_3d_bbox [bs,cls*max_out,7], pred_3d_score, pred_3d_cls_category, plus the raw
         nms_idx / nms_cnt."""
+        T.require(pred_anchors_3d.dim() == 3 or (pred_anchors_3d.dim() == 4 and pred_anchors_3d.shape[2] == 1),
+                  "PostProcessor: class-aware boxes [bs,n,cls,7] are not supported (the anchor-free head is "
+                  "class-agnostic: [bs,n,1,7] or [bs,n,7])")
         boxes = pred_anchors_3d.reshape(pred_anchors_3d.shape[0], pred_anchors_3d.shape[1], 7).contiguous()
         bs, n, _ = boxes.shape
         if bev is None:

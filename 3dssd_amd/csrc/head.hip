@@ -91,7 +91,14 @@ __global__ __launch_bounds__(64) void nms_bev_kernel(int n, int C, int max_out, 
     while (npad < n) npad <<= 1;
     for (int i = lane; i < npad; i += 64) {
         unsigned long long k = ~0ull;
-        if (i < n) k = ((unsigned long long)(~__float_as_uint(sc[(size_t)i * C])) << 32) | (unsigned)i;   // scores >= 0
+        if (i < n) {
+            // descending score, ascending index: order-preserving float -> uint map (sign bit set: flip all bits,
+            // else flip the sign bit), complemented; any finite score, negative ones included, sorts correctly
+            unsigned u = __float_as_uint(sc[(size_t)i * C]);
+            u = u == 0x80000000u ? 0u : u;                 // -0.0 == +0.0: the index decides, as in a float compare
+            const unsigned asc = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+            k = ((unsigned long long)(~asc) << 32) | (unsigned)i;
+        }
         s_key[i] = k;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

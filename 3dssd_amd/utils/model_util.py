@@ -7,11 +7,14 @@ from .tf_ops import _tensor as T
 from . import _native as N
 
 
-def calc_square_dist(a, b, norm=False):
+def calc_square_dist(a, b, norm=True):
     """a: [bs, npoint, c], b: [bs, ndataset, c] -> [bs, npoint, ndataset] = |a|^2 + |b|^2 - 2 a.b
-    (channel sums as ascending fmaf chains; see csrc/sqdist.hip).  norm=True (sqrt / c, never used on
-    the SA path) is not provided."""
-    T.require(not norm, "calc_square_dist: only norm=False is implemented (the SA path never uses norm=True)")
+    (channel sums as ascending fmaf chains; see csrc/sqdist.hip).  The default is the reference's (norm=True:
+    sqrt / c, model_util.py:144,156-159), which is NOT provided -- the SA path always passes norm=False
+    (layers_util.py:95,103) -- so a caller relying on the default is told instead of silently getting the
+    unnormalised matrix."""
+    T.require(not norm, "calc_square_dist: only norm=False is implemented; pass norm=False explicitly "
+                        "(the reference's default norm=True is sqrt(dist)/c, which the SA path never uses)")
     a = T.f32_cuda(a, "a")
     b = T.f32_cuda(b, "b")
     T.require(a.dim() == 3 and b.dim() == 3 and a.shape[0] == b.shape[0] and a.shape[2] == b.shape[2],

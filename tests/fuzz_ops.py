@@ -121,7 +121,7 @@ def case_sqdist(rng):
     bb = a if (n == m and rng.integers(0, 2)) else rng.normal(0, 1, (b, m, c)).astype(np.float32)
     ta = t(a)
     tb = ta if bb is a else t(bb)
-    return eq("calc_square_dist", M.calc_square_dist(ta, tb), O.calc_square_dist(a, bb), (b, n, m, c, bb is a))
+    return eq("calc_square_dist", M.calc_square_dist(ta, tb, norm=False), O.calc_square_dist(a, bb), (b, n, m, c, bb is a))
 
 
 def case_mlp(rng):
@@ -278,12 +278,12 @@ def case_sqdist_big(rng):
     c = int(rng.choice([67, 131, 35, 7, 64]))
     a = rng.normal(0, 1, (b, n, c)).astype(np.float32)
     ta = t(a)
-    e = eq("calc_square_dist(sym big)", M.calc_square_dist(ta, ta), O.calc_square_dist(a, a), (b, n, c))
+    e = eq("calc_square_dist(sym big)", M.calc_square_dist(ta, ta, norm=False), O.calc_square_dist(a, a), (b, n, c))
     if e:
         return e
     m = int(rng.choice([300, 512, 1111]))
     bb = rng.normal(0, 1, (b, m, c)).astype(np.float32)
-    return eq("calc_square_dist(big)", M.calc_square_dist(ta, t(bb)), O.calc_square_dist(a, bb), (b, n, m, c))
+    return eq("calc_square_dist(big)", M.calc_square_dist(ta, t(bb), norm=False), O.calc_square_dist(a, bb), (b, n, m, c))
 
 
 def case_mlp_big(rng):

@@ -117,6 +117,24 @@ def test_nms_bev_matches_oracle(gpu, H, b, n, C, thr, K):
 
 
 @pytest.mark.gpu
+def test_nms_negative_scores_sort_like_floats(gpu, H):
+    """pred_score is an arbitrary float tensor for the public op (logits, not only sigmoid outputs): negative values
+    must order like floats (~bits only orders non-negative scores)."""
+    P = pkg("builder.postprocessor")
+    rng = np.random.default_rng(5)
+    n = 200
+    ctr = rng.uniform(0, 30, (1, n, 2)).astype(f32)
+    half = rng.uniform(0.5, 3.0, (1, n, 2)).astype(f32)
+    bev = np.concatenate([ctr - half, ctr + half], -1).astype(f32)
+    scores = rng.normal(0, 2, (1, n, 1)).astype(f32)
+    scores[0, 3] = -0.0
+    scores[0, 4] = 0.0
+    idx, cnt = P.PostProcessor(0, 1, 100, 0.3).nms(_t(bev, gpu), _t(scores, gpu))
+    ref = H.non_max_suppression(bev[0], scores[0, :, 0], 100, 0.3)
+    assert int(cnt[0, 0]) == len(ref) and np.array_equal(idx.cpu().numpy()[0, 0, :len(ref)], ref)
+
+
+@pytest.mark.gpu
 def test_nms_kat_on_gpu(gpu):
     P = pkg("builder.postprocessor")
     boxes = np.array([[[0, 0, 2, 2], [1, 1, 3, 3], [0, 0, 2, 2.2], [5, 5, 6, 6], [2, 2, 1, 1]]], f32)
