@@ -34,6 +34,9 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kNW = 8;             // waves per workgroup
@@ -81,6 +84,37 @@ __device__ __forceinline__ f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
                                                    __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+__device__ __forceinline__ f32x16 mfma_f16(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a),
+                                                  __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// Operand precision of a scale, PR (chosen on the host per scale, utils/weights.py):
+//   3  split bf16: hi/lo planes of activations and weights, three MFMA passes per k-step (~5e-6 of the fp32 oracle)
+//   1  fp16: one plane, one pass (v_cvt_pk_f16_f32 rounds to nearest even, v_mfma_f32_32x32x16_f16, fp32 accumulate);
+//      used for the scales whose every contraction is >= 256 wide (layer4 of 3dssd.yaml), measured 3-5e-4 of the fp32
+//      oracle through the three stacked layers against the 1e-3 bar.  Half the LDS, weight bytes and fragment
+//      registers, a third of the matrix passes, one converter instruction per pair instead of six.
+constexpr __host__ __device__ int grp_bytes(int PR) { return PR == 3 ? 32 : 16; }   // one 8-channel group of an LDS row
+constexpr __host__ __device__ int wblk(int PR) { return PR == 3 ? 128 : 64; }       // uint4 per (tile, k-step) of weights
+
+__device__ __forceinline__ unsigned cvt2_f16(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
+__device__ __forceinline__ uint4 cvt8_f16(const float (&v)[8]) {
+    return make_uint4(cvt2_f16(v[0], v[1]), cvt2_f16(v[2], v[3]), cvt2_f16(v[4], v[5]), cvt2_f16(v[6], v[7]));
+}
+// acc += W x for one k-step: a_* = the MFMA A operand planes, b_* = the B operand planes
+template <int PR, bool WFIRST>
+__device__ __forceinline__ void mma_step(f32x16 &acc, uint4 wh, uint4 wl, uint4 xh, uint4 xl) {
+    if (PR == 3) {
+        if (WFIRST) { acc = mfma_bf16(wh, xh, acc); acc = mfma_bf16(wl, xh, acc); acc = mfma_bf16(wh, xl, acc); }
+        else { acc = mfma_bf16(xh, wh, acc); acc = mfma_bf16(xh, wl, acc); acc = mfma_bf16(xl, wh, acc); }
+    } else {
+        acc = WFIRST ? mfma_f16(wh, xh, acc) : mfma_f16(xh, wh, acc);
+    }
+}
 
 // 8 fp32 -> hi/lo bf16 planes, 16 bytes each
 __device__ __forceinline__ void split8(const float (&v)[8], uint4 &hi, uint4 &lo) {
@@ -91,22 +125,45 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4 &hi, uint4 &lo
     lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
 }
 
+// 8 consecutive channels of a row -> their LDS group (hi/lo planes, or one fp16 plane)
+template <int PR>
+__device__ __forceinline__ void store_group(unsigned char *dst, const float (&v)[8]) {
+    if (PR == 3) {
+        uint4 hi, lo;
+        split8(v, hi, lo);
+        *(uint4 *)dst = hi;
+        *(uint4 *)(dst + 16) = lo;
+    } else {
+        *(uint4 *)dst = cvt8_f16(v);
+    }
+}
+// 4 consecutive channels (one accumulator quad after ReLU) -> half a group
+template <int PR>
+__device__ __forceinline__ void store_quad(unsigned char *dst, const float (&v)[4]) {
+    if (PR == 3) {
+        unsigned h[4], l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sa::bf16_split(v[e], h[e], l[e]);
+        *(uint2 *)dst = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+        *(uint2 *)(dst + 16) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+    } else {
+        *(uint2 *)dst = make_uint2(cvt2_f16(v[0], v[1]), cvt2_f16(v[2], v[3]));
+    }
+}
 
 // acc[tt] += sum_ks (hi*hi + lo*hi + hi*lo) for the TG output tiles starting at gb.  WFIRST: weights are the
 // MFMA A operand (D^T form) else the activations are (D form).  Weight fragments (global, L2-resident) and
 // activation fragments (LDS) of k-step ks+1 are requested before the MFMAs of k-step ks are issued, so the
 // matrix pipe works under the load latency instead of behind it.
-#ifndef SA_MLP_PREFETCH
 #define SA_MLP_PREFETCH 1
-#endif
-template <int TG, bool WFIRST>
+template <int TG, bool WFIRST, int PR>
 __device__ __forceinline__ void mma_k_loop(f32x16 (&acc)[TG], const unsigned char *arow, const LayerDesc &L,
                                            int gb, int lane) {
+    constexpr int WB = wblk(PR), KSB = 2 * grp_bytes(PR);     // uint4 per weight block, LDS bytes per k-step of a row
     const uint4 *wbase[TG];
 #pragma unroll
     for (int tt = 0; tt < TG; ++tt)
-        wbase[tt] = L.w + ((size_t)(min(gb + tt, L.NT - 1) * L.KS) * 2) * 64 + lane;
-#if SA_MLP_PREFETCH
+        wbase[tt] = L.w + ((size_t)(min(gb + tt, L.NT - 1) * L.KS)) * WB + lane;
     // Batched k-steps: the weight (L2) and activation (LDS) fragments of KB consecutive k-steps are requested
     // together, then their MFMAs run back to back: one L2 round trip (~600-700 cycles measured) per KB k-steps
     // instead of one per k-step (a k-step is only 96 x TG cycles of MFMA issue).  The sched_barrier keeps hipcc
@@ -114,63 +171,31 @@ __device__ __forceinline__ void mma_k_loop(f32x16 (&acc)[TG], const unsigned cha
 #ifndef SA_MLP_KB1
 #define SA_MLP_KB1 4
 #endif
-    constexpr int KB = TG >= 4 ? 1 : (TG == 2 ? (SA_MLP_KB1 >= 2 ? 2 : 1) : SA_MLP_KB1);
+    constexpr int KB = (TG >= 4 ? 1 : (TG == 2 ? (SA_MLP_KB1 >= 2 ? 2 : 1) : SA_MLP_KB1)) * (PR == 1 ? 2 : 1);
     for (int ks0 = 0; ks0 < L.KS; ks0 += KB) {
         uint4 wh[KB][TG], wl[KB][TG], ah[KB], al[KB];
 #pragma unroll
         for (int d = 0; d < KB; ++d) {
             const int ks = ks0 + d < L.KS ? ks0 + d : L.KS - 1;
 #pragma unroll
-            for (int tt = 0; tt < TG; ++tt) { wh[d][tt] = wbase[tt][ks * 128]; wl[d][tt] = wbase[tt][ks * 128 + 64]; }
-            ah[d] = *(const uint4 *)(arow + ks * 64);
-            al[d] = *(const uint4 *)(arow + ks * 64 + 16);
+            for (int tt = 0; tt < TG; ++tt) {
+                wh[d][tt] = wbase[tt][ks * WB];
+                if (PR == 3) wl[d][tt] = wbase[tt][ks * WB + 64];
+            }
+            ah[d] = *(const uint4 *)(arow + ks * KSB);
+            if (PR == 3) al[d] = *(const uint4 *)(arow + ks * KSB + 16);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int d = 0; d < KB; ++d) {
             if (ks0 + d < L.KS) {
 #pragma unroll
-                for (int tt = 0; tt < TG; ++tt) {
-                    if (gb + tt < L.NT) {
-                        if (WFIRST) {
-                            acc[tt] = mfma_bf16(wh[d][tt], ah[d], acc[tt]);
-                            acc[tt] = mfma_bf16(wl[d][tt], ah[d], acc[tt]);
-                            acc[tt] = mfma_bf16(wh[d][tt], al[d], acc[tt]);
-                        } else {
-                            acc[tt] = mfma_bf16(ah[d], wh[d][tt], acc[tt]);
-                            acc[tt] = mfma_bf16(ah[d], wl[d][tt], acc[tt]);
-                            acc[tt] = mfma_bf16(al[d], wh[d][tt], acc[tt]);
-                        }
-                    }
-                }
+                for (int tt = 0; tt < TG; ++tt)
+                    if (gb + tt < L.NT) mma_step<PR, WFIRST>(acc[tt], wh[d][tt], wl[d][tt], ah[d], al[d]);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-#else
-#ifdef SA_MLP_KUNROLL
-#pragma unroll SA_MLP_KUNROLL
-#endif
-    for (int ks = 0; ks < L.KS; ++ks) {
-        const uint4 ah = *(const uint4 *)(arow + ks * 64);
-        const uint4 al = *(const uint4 *)(arow + ks * 64 + 16);
-#pragma unroll
-        for (int tt = 0; tt < TG; ++tt) {
-            if (gb + tt < L.NT) {
-                const uint4 wh = wbase[tt][ks * 128], wl = wbase[tt][ks * 128 + 64];
-                if (WFIRST) {
-                    acc[tt] = mfma_bf16(wh, ah, acc[tt]);
-                    acc[tt] = mfma_bf16(wl, ah, acc[tt]);
-                    acc[tt] = mfma_bf16(wh, al, acc[tt]);
-                } else {
-                    acc[tt] = mfma_bf16(ah, wh, acc[tt]);
-                    acc[tt] = mfma_bf16(ah, wl, acc[tt]);
-                    acc[tt] = mfma_bf16(al, wh, acc[tt]);
-                }
-            }
-        }
-    }
-#endif
 }
 
 
@@ -208,7 +233,7 @@ __device__ __forceinline__ void gather8(const MlpParams &P, long pt, long ball, 
 //  * the full 8-channel feature groups (two aligned float4 loads, identical for every lane: no divergence)
 //    are separated from the short tail (left-over feature channels + relative xyz + zero padding), which
 //    only 32..128 slots execute.
-template <int ROWS, int NTHR>
+template <int ROWS, int NTHR, int PR>
 __device__ __forceinline__ void gather_tile(const MlpParams &P, unsigned char *buf, int stride, int item,
                                             int ngran, int G0, int tid) {
     asm volatile("" : "+v"(tid));
@@ -238,13 +263,7 @@ __device__ __forceinline__ void gather_tile(const MlpParams &P, unsigned char *b
         const float4 f0 = *(const float4 *)(P.feat + pt * P.C + g * 8);
         const float4 f1 = *(const float4 *)(P.feat + pt * P.C + g * 8 + 4);
         const float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-        uint4 hi, lo;
-        split8(v, hi, lo);
-        unsigned char *dst = buf + row * stride + g * 32;
-        if (live) {
-            *(uint4 *)dst = hi;
-            *(uint4 *)(dst + 16) = lo;
-        }
+        if (live) store_group<PR>(buf + row * stride + g * grp_bytes(PR), v);
     }
     const int GT = G0 - GF;                                 // tail groups per row (1 or 2; all of them if C%4 != 0)
     const int totT = ROWS * GT;
@@ -276,22 +295,17 @@ __device__ __forceinline__ void gather_tile(const MlpParams &P, unsigned char *b
             const int x = g * 8 + e - P.C;
             v[e] = x < 0 ? fv[e] : (x == 0 ? px : (x == 1 ? py : (x == 2 ? pz : 0.0f)));
         }
-        uint4 hi, lo;
-        split8(v, hi, lo);
-        unsigned char *dst = buf + row * stride + g * 32;
-        if (live) {
-            *(uint4 *)dst = hi;
-            *(uint4 *)(dst + 16) = lo;
-        }
+        if (live) store_group<PR>(buf + row * stride + g * grp_bytes(PR), v);
     }
 }
 
 // ---- hidden layer, D^T form: out[row][cout] = relu(bias + sum_k W[k][cout] * in[row][k]) ----------
-template <int TG, int NW>
+template <int TG, int NW, int PR>
 __device__ __forceinline__ void layer_hidden(const unsigned char *in, int strideIn, unsigned char *outb,
                                              int strideOut, const LayerDesc &L, int lane, int w) {
+    constexpr int GB = grp_bytes(PR);
     const int half = lane >> 5, col = lane & 31;
-    const unsigned char *arow = in + col * strideIn + half * 32;
+    const unsigned char *arow = in + col * strideIn + half * GB;
     for (int gb = w * TG; gb < L.NT; gb += NW * TG) {
         f32x16 acc[TG];
 #pragma unroll
@@ -304,22 +318,17 @@ __device__ __forceinline__ void layer_hidden(const unsigned char *in, int stride
                 acc[tt][4 * q + 2] = bv.z; acc[tt][4 * q + 3] = bv.w;
             }
         }
-        mma_k_loop<TG, true>(acc, arow, L, gb, lane);
+        mma_k_loop<TG, true, PR>(acc, arow, L, gb, lane);
 #pragma unroll
         for (int tt = 0; tt < TG; ++tt) {
             if (gb + tt < L.NT) {
-                unsigned char *orow = outb + col * strideOut + (gb + tt) * 128 + 8 * half;
+                unsigned char *orow = outb + col * strideOut + (gb + tt) * 4 * GB + 8 * half;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    unsigned h[4], l[4];
+                    float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v = acc[tt][4 * q + e];
-                        v = v > 0.0f ? v : 0.0f;
-                        sa::bf16_split(v, h[e], l[e]);
-                    }
-                    *(uint2 *)(orow + q * 32) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-                    *(uint2 *)(orow + q * 32 + 16) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+                    for (int e = 0; e < 4; ++e) v[e] = sa::fmax_nn(acc[tt][4 * q + e], 0.0f);
+                    store_quad<PR>(orow + q * GB, v);
                 }
             }
         }
@@ -327,19 +336,19 @@ __device__ __forceinline__ void layer_hidden(const unsigned char *in, int stride
 }
 
 // ---- last layer, D form + max over the rows of each ball; bias/ReLU/mask are applied at write-out ---
-template <int TG, int NW>
+template <int TG, int NW, int PR>
 __device__ __forceinline__ void layer_last(const unsigned char *in, int strideIn, const LayerDesc &L,
                                            const MlpParams &P, const int (&ent)[4], const int (&cn)[4], int lane,
                                            int w) {
     const int half = lane >> 5, col = lane & 31;
-    const unsigned char *arow = in + col * strideIn + half * 32;
+    const unsigned char *arow = in + col * strideIn + half * grp_bytes(PR);
     for (int gb = w * TG; gb < L.NT; gb += NW * TG) {
         f32x16 acc[TG];
 #pragma unroll
         for (int tt = 0; tt < TG; ++tt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tt][r] = 0.0f;
-        mma_k_loop<TG, false>(acc, arow, L, gb, lane);
+        mma_k_loop<TG, false, PR>(acc, arow, L, gb, lane);
 #pragma unroll
         for (int tt = 0; tt < TG; ++tt) {
             if (gb + tt < L.NT) {
@@ -370,7 +379,7 @@ __device__ __forceinline__ int pick_tg(int NT) {
 // one 512-thread workgroup per item).  NW = 1: narrow layers (layer1/layer2 of 3dssd.yaml) where one
 // wave runs the whole stack on its own item -- no cross-wave barrier, 8x more items in flight per CU to
 // hide the idx -> point gather latency.
-template <int NW>
+template <int NW, int PR>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? SA_MLP_WPE8 : 4) void group_mlp_max_kernel(MlpParams P) {
     constexpr int kThr = NW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -388,7 +397,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? SA_MLP_WPE8 : 4) void group_mlp_
         SA_COUNT(1);
         // ---- gather the [32 rows x cin] input tile (features first, then relative xyz:
         //      layers_util.py:160-165) into bufA as hi/lo bf16
-        gather_tile<kRows, kThr>(P, bufA, P.strideA, item, ngran, G0, tid);
+        gather_tile<kRows, kThr, PR>(P, bufA, P.strideA, item, ngran, G0, tid);
         // the tile's plan entries and ball counts, wave-uniform
         int ent[4], cn[4];
 #pragma unroll
@@ -406,10 +415,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? SA_MLP_WPE8 : 4) void group_mlp_
             const int si = (l & 1) ? P.strideB : P.strideA, so = (l & 1) ? P.strideA : P.strideB;
             switch (pick_tg<NW>(P.L[l].NT)) {
 #if SA_MLP_MAXTG >= 4
-                case 4: layer_hidden<4, NW>(in, si, ob, so, P.L[l], lane, w); break;
+                case 4: layer_hidden<4, NW, PR>(in, si, ob, so, P.L[l], lane, w); break;
 #endif
-                case 2: layer_hidden<2, NW>(in, si, ob, so, P.L[l], lane, w); break;
-                default: layer_hidden<1, NW>(in, si, ob, so, P.L[l], lane, w); break;
+                case 2: layer_hidden<2, NW, PR>(in, si, ob, so, P.L[l], lane, w); break;
+                default: layer_hidden<1, NW, PR>(in, si, ob, so, P.L[l], lane, w); break;
             }
             __syncthreads();
         }
@@ -421,10 +430,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? SA_MLP_WPE8 : 4) void group_mlp_
             const int si = (l & 1) ? P.strideB : P.strideA;
             switch (pick_tg<NW>(LL.NT)) {
 #if SA_MLP_MAXTG >= 4
-                case 4: layer_last<4, NW>(in, si, LL, P, ent, cn, lane, w); break;
+                case 4: layer_last<4, NW, PR>(in, si, LL, P, ent, cn, lane, w); break;
 #endif
-                case 2: layer_last<2, NW>(in, si, LL, P, ent, cn, lane, w); break;
-                default: layer_last<1, NW>(in, si, LL, P, ent, cn, lane, w); break;
+                case 2: layer_last<2, NW, PR>(in, si, LL, P, ent, cn, lane, w); break;
+                default: layer_last<1, NW, PR>(in, si, LL, P, ent, cn, lane, w); break;
             }
         }
         __syncthreads();
@@ -451,13 +460,14 @@ struct WideParams {
 };
 
 // hidden layer (D^T form) for output tiles [tile_lo, tile_hi), written at column (tile - tile_lo) * 32
-template <int TG>
+template <int TG, int PR>
 __device__ __forceinline__ void wide_hidden(const unsigned char *in, int strideIn, unsigned char *outb,
                                             int strideOut, const LayerDesc &L, int tile_lo, int tile_hi,
                                             int lane, int w) {
     asm volatile("" : "+v"(lane));
+    constexpr int GB = grp_bytes(PR), WB = wblk(PR), KSB = 2 * GB;
     const int half = lane >> 5, col = lane & 31;
-    const unsigned char *arow0 = in + col * strideIn + half * 32;
+    const unsigned char *arow0 = in + col * strideIn + half * GB;
     const unsigned char *arow1 = arow0 + 32 * strideIn;
     for (int gb = tile_lo + w * TG; gb < tile_hi; gb += kNW * TG) {
         f32x16 acc[TG][2];
@@ -465,7 +475,7 @@ __device__ __forceinline__ void wide_hidden(const unsigned char *in, int strideI
 #pragma unroll
         for (int tt = 0; tt < TG; ++tt) {
             const int ct = min(gb + tt, tile_hi - 1);
-            wbase[tt] = L.w + ((size_t)(ct * L.KS) * 2) * 64 + lane;
+            wbase[tt] = L.w + ((size_t)(ct * L.KS)) * WB + lane;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 bv = *(const float4 *)(L.bias + ct * 32 + 8 * q + 4 * half);
@@ -476,16 +486,19 @@ __device__ __forceinline__ void wide_hidden(const unsigned char *in, int strideI
                 }
             }
         }
-        constexpr int D = TG == 2 ? 2 : 4;
+        constexpr int D = (TG == 2 ? 2 : 4) * (PR == 1 ? 2 : 1);     // weight fragments in flight (k-steps ahead)
         uint4 wq[D][TG][2];
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             const int kd = d < L.KS ? d : L.KS - 1;
 #pragma unroll
-            for (int tt = 0; tt < TG; ++tt) { wq[d][tt][0] = wbase[tt][kd * 128]; wq[d][tt][1] = wbase[tt][kd * 128 + 64]; }
+            for (int tt = 0; tt < TG; ++tt) {
+                wq[d][tt][0] = wbase[tt][kd * WB];
+                if (PR == 3) wq[d][tt][1] = wbase[tt][kd * WB + 64];
+            }
         }
-        uint4 ah0 = *(const uint4 *)(arow0), al0 = *(const uint4 *)(arow0 + 16);
-        uint4 ah1 = *(const uint4 *)(arow1), al1 = *(const uint4 *)(arow1 + 16);
+        uint4 ah0 = *(const uint4 *)(arow0), al0, ah1 = *(const uint4 *)(arow1), al1;
+        if (PR == 3) { al0 = *(const uint4 *)(arow0 + 16); al1 = *(const uint4 *)(arow1 + 16); }
         for (int ks0 = 0; ks0 < L.KS; ks0 += D) {
 #pragma unroll
             for (int d = 0; d < D; ++d) {
@@ -496,22 +509,32 @@ __device__ __forceinline__ void wide_hidden(const unsigned char *in, int strideI
                     for (int tt = 0; tt < TG; ++tt) { wh[tt] = wq[d][tt][0]; wl[tt] = wq[d][tt][1]; }
                     const int kw = ks + D < L.KS ? ks + D : L.KS - 1;
 #pragma unroll
-                    for (int tt = 0; tt < TG; ++tt) { wq[d][tt][0] = wbase[tt][kw * 128]; wq[d][tt][1] = wbase[tt][kw * 128 + 64]; }
+                    for (int tt = 0; tt < TG; ++tt) {
+                        wq[d][tt][0] = wbase[tt][kw * WB];
+                        if (PR == 3) wq[d][tt][1] = wbase[tt][kw * WB + 64];
+                    }
                     const int kn = ks + 1 < L.KS ? ks + 1 : ks;
-                    const uint4 nah0 = *(const uint4 *)(arow0 + kn * 64), nal0 = *(const uint4 *)(arow0 + kn * 64 + 16);
-                    const uint4 nah1 = *(const uint4 *)(arow1 + kn * 64), nal1 = *(const uint4 *)(arow1 + kn * 64 + 16);
+                    const uint4 nah0 = *(const uint4 *)(arow0 + kn * KSB), nah1 = *(const uint4 *)(arow1 + kn * KSB);
+                    uint4 nal0, nal1;
+                    if (PR == 3) { nal0 = *(const uint4 *)(arow0 + kn * KSB + 16); nal1 = *(const uint4 *)(arow1 + kn * KSB + 16); }
 #pragma unroll
                     for (int tt = 0; tt < TG; ++tt) {
                         if (gb + tt < tile_hi) {
-                            acc[tt][0] = mfma_bf16(wh[tt], ah0, acc[tt][0]);
-                            acc[tt][1] = mfma_bf16(wh[tt], ah1, acc[tt][1]);
-                            acc[tt][0] = mfma_bf16(wl[tt], ah0, acc[tt][0]);
-                            acc[tt][1] = mfma_bf16(wl[tt], ah1, acc[tt][1]);
-                            acc[tt][0] = mfma_bf16(wh[tt], al0, acc[tt][0]);
-                            acc[tt][1] = mfma_bf16(wh[tt], al1, acc[tt][1]);
+                            if (PR == 3) {
+                                acc[tt][0] = mfma_bf16(wh[tt], ah0, acc[tt][0]);
+                                acc[tt][1] = mfma_bf16(wh[tt], ah1, acc[tt][1]);
+                                acc[tt][0] = mfma_bf16(wl[tt], ah0, acc[tt][0]);
+                                acc[tt][1] = mfma_bf16(wl[tt], ah1, acc[tt][1]);
+                                acc[tt][0] = mfma_bf16(wh[tt], al0, acc[tt][0]);
+                                acc[tt][1] = mfma_bf16(wh[tt], al1, acc[tt][1]);
+                            } else {
+                                acc[tt][0] = mfma_f16(wh[tt], ah0, acc[tt][0]);
+                                acc[tt][1] = mfma_f16(wh[tt], ah1, acc[tt][1]);
+                            }
                         }
                     }
-                    ah0 = nah0; al0 = nal0; ah1 = nah1; al1 = nal1;
+                    ah0 = nah0; ah1 = nah1;
+                    if (PR == 3) { al0 = nal0; al1 = nal1; }
                 }
             }
         }
@@ -520,18 +543,13 @@ __device__ __forceinline__ void wide_hidden(const unsigned char *in, int strideI
             if (gb + tt < tile_hi) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    unsigned char *orow = outb + (j * 32 + col) * strideOut + (gb + tt - tile_lo) * 128 + 8 * half;
+                    unsigned char *orow = outb + (j * 32 + col) * strideOut + (gb + tt - tile_lo) * 4 * GB + 8 * half;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        unsigned h[4], l[4];
+                        float v[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float v = acc[tt][j][4 * q + e];
-                            v = v > 0.0f ? v : 0.0f;
-                            sa::bf16_split(v, h[e], l[e]);
-                        }
-                        *(uint2 *)(orow + q * 32) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-                        *(uint2 *)(orow + q * 32 + 16) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+                        for (int e = 0; e < 4; ++e) v[e] = sa::fmax_nn(acc[tt][j][4 * q + e], 0.0f);
+                        store_quad<PR>(orow + q * GB, v);
                     }
                 }
             }
@@ -541,27 +559,31 @@ __device__ __forceinline__ void wide_hidden(const unsigned char *in, int strideI
 
 // last layer (D form), k-steps [ks_lo, ks_hi) of the input whose columns start at k-step ks_lo in `in`;
 // wave w owns output tiles w, w+8, ... (TGL of them), accumulators persist across calls
-template <int TGL>
+template <int TGL, int PR>
 __device__ __forceinline__ void wide_last_partial(f32x16 (&acc)[TGL][2], const unsigned char *in, int strideIn,
                                                   const LayerDesc &L, int ks_lo, int ks_hi, int lane, int w) {
     asm volatile("" : "+v"(lane));
+    constexpr int GB = grp_bytes(PR), WB = wblk(PR), KSB = 2 * GB;
     const int half = lane >> 5, col = lane & 31;
-    const unsigned char *arow0 = in + col * strideIn + half * 32;
+    const unsigned char *arow0 = in + col * strideIn + half * GB;
     const unsigned char *arow1 = arow0 + 32 * strideIn;
     const uint4 *wbase[TGL];
 #pragma unroll
     for (int tt = 0; tt < TGL; ++tt)
-        wbase[tt] = L.w + ((size_t)(min(w + kNW * tt, L.NT - 1) * L.KS) * 2) * 64 + lane;
-    constexpr int D = TGL >= 4 ? 1 : (TGL == 2 ? 2 : 4);
+        wbase[tt] = L.w + ((size_t)(min(w + kNW * tt, L.NT - 1) * L.KS)) * WB + lane;
+    constexpr int D = (TGL >= 4 ? 1 : (TGL == 2 ? 2 : 4)) * (PR == 1 ? 2 : 1);
     uint4 wq[D][TGL][2];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
         const int kd = ks_lo + d < ks_hi ? ks_lo + d : ks_hi - 1;
 #pragma unroll
-        for (int tt = 0; tt < TGL; ++tt) { wq[d][tt][0] = wbase[tt][kd * 128]; wq[d][tt][1] = wbase[tt][kd * 128 + 64]; }
+        for (int tt = 0; tt < TGL; ++tt) {
+            wq[d][tt][0] = wbase[tt][kd * WB];
+            if (PR == 3) wq[d][tt][1] = wbase[tt][kd * WB + 64];
+        }
     }
-    uint4 ah0 = *(const uint4 *)(arow0), al0 = *(const uint4 *)(arow0 + 16);
-    uint4 ah1 = *(const uint4 *)(arow1), al1 = *(const uint4 *)(arow1 + 16);
+    uint4 ah0 = *(const uint4 *)(arow0), al0, ah1 = *(const uint4 *)(arow1), al1;
+    if (PR == 3) { al0 = *(const uint4 *)(arow0 + 16); al1 = *(const uint4 *)(arow1 + 16); }
     for (int ks0 = ks_lo; ks0 < ks_hi; ks0 += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
@@ -572,28 +594,38 @@ __device__ __forceinline__ void wide_last_partial(f32x16 (&acc)[TGL][2], const u
                 for (int tt = 0; tt < TGL; ++tt) { wh[tt] = wq[d][tt][0]; wl[tt] = wq[d][tt][1]; }
                 const int kw = ks + D < ks_hi ? ks + D : ks_hi - 1;
 #pragma unroll
-                for (int tt = 0; tt < TGL; ++tt) { wq[d][tt][0] = wbase[tt][kw * 128]; wq[d][tt][1] = wbase[tt][kw * 128 + 64]; }
+                for (int tt = 0; tt < TGL; ++tt) {
+                    wq[d][tt][0] = wbase[tt][kw * WB];
+                    if (PR == 3) wq[d][tt][1] = wbase[tt][kw * WB + 64];
+                }
                 const int kn = (ks + 1 < ks_hi ? ks + 1 : ks) - ks_lo;
-                const uint4 nah0 = *(const uint4 *)(arow0 + kn * 64), nal0 = *(const uint4 *)(arow0 + kn * 64 + 16);
-                const uint4 nah1 = *(const uint4 *)(arow1 + kn * 64), nal1 = *(const uint4 *)(arow1 + kn * 64 + 16);
+                const uint4 nah0 = *(const uint4 *)(arow0 + kn * KSB), nah1 = *(const uint4 *)(arow1 + kn * KSB);
+                uint4 nal0, nal1;
+                if (PR == 3) { nal0 = *(const uint4 *)(arow0 + kn * KSB + 16); nal1 = *(const uint4 *)(arow1 + kn * KSB + 16); }
 #pragma unroll
                 for (int tt = 0; tt < TGL; ++tt) {
                     if (w + kNW * tt < L.NT) {
-                        acc[tt][0] = mfma_bf16(ah0, wh[tt], acc[tt][0]);
-                        acc[tt][1] = mfma_bf16(ah1, wh[tt], acc[tt][1]);
-                        acc[tt][0] = mfma_bf16(ah0, wl[tt], acc[tt][0]);
-                        acc[tt][1] = mfma_bf16(ah1, wl[tt], acc[tt][1]);
-                        acc[tt][0] = mfma_bf16(al0, wh[tt], acc[tt][0]);
-                        acc[tt][1] = mfma_bf16(al1, wh[tt], acc[tt][1]);
+                        if (PR == 3) {
+                            acc[tt][0] = mfma_bf16(ah0, wh[tt], acc[tt][0]);
+                            acc[tt][1] = mfma_bf16(ah1, wh[tt], acc[tt][1]);
+                            acc[tt][0] = mfma_bf16(ah0, wl[tt], acc[tt][0]);
+                            acc[tt][1] = mfma_bf16(ah1, wl[tt], acc[tt][1]);
+                            acc[tt][0] = mfma_bf16(al0, wh[tt], acc[tt][0]);
+                            acc[tt][1] = mfma_bf16(al1, wh[tt], acc[tt][1]);
+                        } else {
+                            acc[tt][0] = mfma_f16(ah0, wh[tt], acc[tt][0]);
+                            acc[tt][1] = mfma_f16(ah1, wh[tt], acc[tt][1]);
+                        }
                     }
                 }
-                ah0 = nah0; al0 = nal0; ah1 = nah1; al1 = nal1;
+                ah0 = nah0; ah1 = nah1;
+                if (PR == 3) { al0 = nal0; al1 = nal1; }
             }
         }
     }
 }
 
-template <int TGL>
+template <int TGL, int PR>
 __device__ __forceinline__ void wide_item_layers(const WideParams &WP, unsigned char *bufA, unsigned char *bufB,
                                                  const int (&ent)[2][4], const int (&cn)[2][4], int lane, int w) {
     const MlpParams &P = WP.M;
@@ -604,8 +636,8 @@ __device__ __forceinline__ void wide_item_layers(const WideParams &WP, unsigned 
         const unsigned char *in = (l & 1) ? bufB : bufA;
         unsigned char *ob = (l & 1) ? bufA : bufB;
         const int si = (l & 1) ? P.strideB : P.strideA, so = (l & 1) ? P.strideA : P.strideB;
-        if (P.L[l].NT >= 2 * kNW) wide_hidden<2>(in, si, ob, so, P.L[l], 0, P.L[l].NT, lane, w);
-        else wide_hidden<1>(in, si, ob, so, P.L[l], 0, P.L[l].NT, lane, w);
+        if (P.L[l].NT >= 2 * kNW) wide_hidden<2, PR>(in, si, ob, so, P.L[l], 0, P.L[l].NT, lane, w);
+        else wide_hidden<1, PR>(in, si, ob, so, P.L[l], 0, P.L[l].NT, lane, w);
         __syncthreads();
     }
     f32x16 acc[TGL][2];
@@ -616,7 +648,7 @@ __device__ __forceinline__ void wide_item_layers(const WideParams &WP, unsigned 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tt][j][r] = 0.0f;
     if (nl == 1) {
-        wide_last_partial<TGL>(acc, bufA, P.strideA, LL, 0, LL.KS, lane, w);
+        wide_last_partial<TGL, PR>(acc, bufA, P.strideA, LL, 0, LL.KS, lane, w);
     } else {
         const int l = nl - 2;                         // last hidden layer, produced in column chunks
         const unsigned char *in = (l & 1) ? bufB : bufA;
@@ -627,11 +659,11 @@ __device__ __forceinline__ void wide_item_layers(const WideParams &WP, unsigned 
             const int t_hi = min(P.L[l].NT, t_lo + WP.tiles_per_chunk);
             if (c > 0) __syncthreads();               // previous chunk fully consumed before it is overwritten
             // with 128 accumulator registers live (TGL == 4) only the one-tile form fits the register file
-            if (TGL < 4 && t_hi - t_lo >= 2 * kNW) wide_hidden<2>(in, si, ob, so, P.L[l], t_lo, t_hi, lane, w);
-            else wide_hidden<1>(in, si, ob, so, P.L[l], t_lo, t_hi, lane, w);
+            if (TGL < 4 && t_hi - t_lo >= 2 * kNW) wide_hidden<2, PR>(in, si, ob, so, P.L[l], t_lo, t_hi, lane, w);
+            else wide_hidden<1, PR>(in, si, ob, so, P.L[l], t_lo, t_hi, lane, w);
             __syncthreads();
             const int ks_lo = t_lo * 2, ks_hi = min(LL.KS, t_hi * 2);
-            if (ks_lo < ks_hi) wide_last_partial<TGL>(acc, ob, so, LL, ks_lo, ks_hi, lane, w);
+            if (ks_lo < ks_hi) wide_last_partial<TGL, PR>(acc, ob, so, LL, ks_lo, ks_hi, lane, w);
         }
     }
     // pooling + write-out: row tile j covers rows 32j..32j+31 of the item = plan tile 2*item + j
@@ -653,6 +685,7 @@ __device__ __forceinline__ void wide_item_layers(const WideParams &WP, unsigned 
     }
 }
 
+template <int PR>
 __global__ __launch_bounds__(kThreads, 2) void group_mlp_wide_kernel(WideParams WP) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const MlpParams &P = WP.M;
@@ -666,7 +699,7 @@ __global__ __launch_bounds__(kThreads, 2) void group_mlp_wide_kernel(WideParams 
     const int tgl = (LL.NT + kNW - 1) / kNW;
 
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-        gather_tile<kWRows, kThreads>(P, bufA, P.strideA, item, ngran, G0, tid);
+        gather_tile<kWRows, kThreads, PR>(P, bufA, P.strideA, item, ngran, G0, tid);
         int ent[2][4], cn[2][4];
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
@@ -675,9 +708,9 @@ __global__ __launch_bounds__(kThreads, 2) void group_mlp_wide_kernel(WideParams 
             cn[g >> 2][g & 3] = __builtin_amdgcn_readfirstlane(e >= 0 ? P.cnt[sa::plan_ball(e)] : 0);
         }
         __syncthreads();
-        if (tgl <= 1) wide_item_layers<1>(WP, bufA, bufB, ent, cn, lane, w);
-        else if (tgl <= 2) wide_item_layers<2>(WP, bufA, bufB, ent, cn, lane, w);
-        else wide_item_layers<4>(WP, bufA, bufB, ent, cn, lane, w);
+        if (tgl <= 1) wide_item_layers<1, PR>(WP, bufA, bufB, ent, cn, lane, w);
+        else if (tgl <= 2) wide_item_layers<2, PR>(WP, bufA, bufB, ent, cn, lane, w);
+        else wide_item_layers<4, PR>(WP, bufA, bufB, ent, cn, lane, w);
         __syncthreads();
     }
 }
@@ -780,7 +813,7 @@ __device__ __forceinline__ void dense_body(const DenseParams &P, unsigned char *
                 const uint4 *wb[TG];
 #pragma unroll
                 for (int tt = 0; tt < TG; ++tt)
-                    wb[tt] = L.w + ((size_t)(min(gb + tt, L.NT - 1) * L.KS + ks0) * 2) * 64 + lane;
+                    wb[tt] = L.w + ((size_t)(min(gb + tt, L.NT - 1) * L.KS + ks0)) * 128 + lane;
                 for (int ksb = 0; ksb < nks; ksb += KB) {
                     uint4 wh[KB][TG], wl[KB][TG], ah[KB], al[KB];
 #pragma unroll
@@ -1059,6 +1092,8 @@ extern "C" int sa_group_mlp_plan(int b, int m, int nscale, const int *ns, const 
 // plan; contents are private to the call).  flags bit 0: dense plan -- every ball is evaluated on all nsample rows
 // like the reference does (A/B measurements); default: only the distinct rows of a ball (mlp_plan.h), same results.
 // flags bit 1: the plan in ws was built by sa_group_mlp_plan for this layer (skips the per-scale plan launch).
+// flags bit 2: wpack[] holds single-plane fp16 fragments (utils/weights.py precision "fp16") and the scale is
+// evaluated with one fp16 MFMA pass per k-step instead of the three split-bf16 passes.
 extern "C" int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float *xyz, const float *feat,
                                 const float *new_xyz, const int *idx, const int *cnt, int nl,
                                 const int *dims, const void *const *wpack, const float *const *bias,
@@ -1085,12 +1120,14 @@ extern "C" int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float 
         hipLaunchKernelGGL(mlp_plan_kernel, dim3(1), dim3(kPlanThreads), 0, stream, J);
         SA_CHECK_LAUNCH();
     }
-    {
+    const bool fp16 = (flags & 4) != 0;
+    if (!fp16) {
         int st = SA_OK;
         if (sa_rowwave_try(b, n, m, ns, c, xyz, feat, new_xyz, idx, cnt, nl, dims, wpack, bias, out, out_stride,
                            out_off, hdr, gran, max_tiles, stream, &st))
             return st;
     }
+    const int abytes = fp16 ? 2 : 4;               // LDS bytes per activation channel (one fp16 plane / hi + lo bf16)
     MlpParams P{};
     P.xyz = xyz; P.feat = feat; P.new_xyz = new_xyz; P.idx = idx; P.cnt = cnt; P.out = out;
     P.n = n; P.m = m; P.ns = ns; P.C = c; P.nballs = nballs;
@@ -1109,13 +1146,13 @@ extern "C" int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float 
             if (l & 1) { if (wd > wA) wA = wd; } else { if (wd > wB) wB = wd; }
         }
     }
-    P.strideA = wA * 4 + 16;
-    P.strideB = wB * 4 + 16;
+    P.strideA = wA * abytes + 16;
+    P.strideB = wB * abytes + 16;
     P.lds_bytes = kRows * (P.strideA + P.strideB);
     const size_t lds = (size_t)P.lds_bytes;
     if (lds > 160 * 1024) return SA_ERR_UNSUPPORTED;
     if (lds > 48 * 1024) {   // opt in to large dynamic LDS; a refusal surfaces at the launch check below
-        (void)hipFuncSetAttribute((const void *)group_mlp_max_kernel<kNW>,
+        (void)hipFuncSetAttribute(fp16 ? (const void *)group_mlp_max_kernel<kNW, 1> : (const void *)group_mlp_max_kernel<kNW, 3>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipGetLastError();
     }
@@ -1126,7 +1163,8 @@ extern "C" int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float 
     const bool narrow = max_nt <= narrow_nt && lds <= 40 * 1024;   // default: <= 128 output channels everywhere
     if (narrow) {
         const int grid = (int)(nitems < 65536 ? nitems : 65536);
-        hipLaunchKernelGGL(group_mlp_max_kernel<1>, dim3(grid), dim3(64), lds, stream, P);
+        if (fp16) hipLaunchKernelGGL((group_mlp_max_kernel<1, 1>), dim3(grid), dim3(64), lds, stream, P);
+        else hipLaunchKernelGGL((group_mlp_max_kernel<1, 3>), dim3(grid), dim3(64), lds, stream, P);
         SA_CHECK_LAUNCH();
         return SA_OK;
     }
@@ -1146,19 +1184,20 @@ extern "C" int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float 
                 const int wd = (l == nl - 2 ? tpc : P.L[l].NT) * 32;
                 if (l & 1) { if (wd > wwA) wwA = wd; } else { if (wd > wwB) wwB = wd; }
             }
-            WP.M.strideA = wwA * 4 + 16;
-            WP.M.strideB = wwB * 4 + 16;
+            WP.M.strideA = wwA * abytes + 16;
+            WP.M.strideB = wwB * abytes + 16;
             WP.M.lds_bytes = kWRows * (WP.M.strideA + WP.M.strideB);
             const size_t wlds = (size_t)WP.M.lds_bytes;
             if (wlds <= 156 * 1024) {
                 WP.tiles_per_chunk = tpc;
                 WP.nchunks = nt_h > 0 ? (nt_h + tpc - 1) / tpc : 1;
-                (void)hipFuncSetAttribute((const void *)group_mlp_wide_kernel,
+                (void)hipFuncSetAttribute(fp16 ? (const void *)group_mlp_wide_kernel<1> : (const void *)group_mlp_wide_kernel<3>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);
                 (void)hipGetLastError();
                 const long witems = (max_tiles + 1) / 2;
                 const int grid = (int)(witems < 16384 ? witems : 16384);
-                hipLaunchKernelGGL(group_mlp_wide_kernel, dim3(grid), dim3(kThreads), wlds, stream, WP);
+                if (fp16) hipLaunchKernelGGL(group_mlp_wide_kernel<1>, dim3(grid), dim3(kThreads), wlds, stream, WP);
+                else hipLaunchKernelGGL(group_mlp_wide_kernel<3>, dim3(grid), dim3(kThreads), wlds, stream, WP);
                 SA_CHECK_LAUNCH();
                 return SA_OK;
             }
@@ -1167,7 +1206,8 @@ extern "C" int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float 
     }
     {
         const int grid = (int)(nitems < 16384 ? nitems : 16384);
-        hipLaunchKernelGGL(group_mlp_max_kernel<kNW>, dim3(grid), dim3(kThreads), lds, stream, P);
+        if (fp16) hipLaunchKernelGGL((group_mlp_max_kernel<kNW, 1>), dim3(grid), dim3(kThreads), lds, stream, P);
+        else hipLaunchKernelGGL((group_mlp_max_kernel<kNW, 3>), dim3(grid), dim3(kThreads), lds, stream, P);
     }
     SA_CHECK_LAUNCH();
     return SA_OK;

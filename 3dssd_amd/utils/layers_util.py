@@ -308,7 +308,7 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
                                       points.data_ptr(), new_xyz.data_ptr(), idx_list[i].data_ptr(),
                                       cnt_list[i].data_ptr(), nl, dims, wp, bp,
                                       new_points_concat.data_ptr(), ctot, off, plan.data_ptr(), plan_bytes,
-                                      MLP_PLAN_FLAGS | (2 if have_plans else 0), stream)
+                                      MLP_PLAN_FLAGS | (2 if have_plans else 0) | W.scale_flags(ls), stream)
             N.check(st, "group_mlp_max")
             if PLAN_LOG is not None:                                        # bench.py: rows evaluated per scale
                 PLAN_LOG.append((bs, m, int(nsample_list[i]), sum(dims[j] * dims[j + 1] for j in range(nl)), plan))

@@ -39,18 +39,44 @@ def bf16_to_f32(h):
     return (h.astype(np.uint32) << 16).view(np.float32)
 
 
-def pack_layer(w, bias):
-    """Fragment-order hi/lo bf16 packing of W'[K,N] (see csrc/mlp.hip header) + zero-padded bias.
+# Operand precision of a grouped-MLP scale (csrc/mlp.hip, "Operand precision"):
+#   "bf16x3"  every fp32 operand as hi + lo bf16, three MFMA passes per k-step (~5e-6 of the fp32 oracle)
+#   "fp16"    one fp16 plane, one pass: measured 3-5e-4 of the fp32 oracle through three stacked layers where every
+#             contraction is >= 256 wide (layer4 of 3dssd.yaml), up to 9e-4 on the 4..32-wide scales of layer1 --
+#             hence the rule below.  SA_MLP_PRECISION = auto (default) | bf16x3 | fp16 overrides it for A/B runs.
+FP16_MIN_K = 256
+FP16_MAX_ABS = 6.0e4
 
-    Returns (packed uint16 [NT, KS, 2, 64, 8], bias fp32 [NT*32])."""
+
+def scale_precision(ws):
+    """Precision of one scale from its folded weight matrices [K, N] (rule above); fp16 is refused when a weight
+    would overflow it."""
+    import os
+    mode = os.environ.get("SA_MLP_PRECISION", "auto")
+    if mode == "bf16x3":
+        return "bf16x3"
+    fits = all(float(np.abs(w).max()) < FP16_MAX_ABS for w in ws)
+    if mode == "fp16":
+        return "fp16" if fits else "bf16x3"
+    return "fp16" if fits and all(w.shape[0] >= FP16_MIN_K for w in ws) else "bf16x3"
+
+
+def pack_layer(w, bias, precision="bf16x3"):
+    """Fragment-order packing of W'[K,N] (see csrc/mlp.hip header) + zero-padded bias.
+
+    Returns (packed uint16 [NT, KS, P, 64, 8], bias fp32 [NT*32]); P = 2 (hi, lo bf16 planes) for "bf16x3",
+    P = 1 (fp16, round to nearest even) for "fp16"."""
     K, N = w.shape
     KS, NT = (K + 15) // 16, (N + 31) // 32
     wp = np.zeros((KS * 16, NT * 32), np.float32)
     wp[:K, :N] = w
-    hi = bf16_rne(wp)
-    lo = bf16_rne(wp - bf16_to_f32(hi))
-    arr = np.zeros((NT, KS, 2, 64, 8), np.uint16)
-    for plane, src in enumerate((hi, lo)):
+    if precision == "fp16":
+        planes = (wp.astype(np.float16).view(np.uint16),)
+    else:
+        hi = bf16_rne(wp)
+        planes = (hi, bf16_rne(wp - bf16_to_f32(hi)))
+    arr = np.zeros((NT, KS, len(planes), 64, 8), np.uint16)
+    for plane, src in enumerate(planes):
         s = src.reshape(KS, 2, 8, NT, 32)                      # [ks][half][e][ct][col]
         arr[:, :, plane] = s.transpose(3, 0, 1, 4, 2).reshape(NT, KS, 64, 8)   # lane = 32*half + col
     bp = np.zeros(NT * 32, np.float32)
@@ -59,31 +85,42 @@ def pack_layer(w, bias):
 
 
 class PackedLayer:
-    __slots__ = ("K", "N", "w", "bias")
+    __slots__ = ("K", "N", "w", "bias", "precision")
 
-    def __init__(self, w, bias, device, _packed=None):
+    def __init__(self, w, bias, device, _packed=None, precision="bf16x3"):
         self.K, self.N = int(w.shape[0]), int(w.shape[1])
+        self.precision = precision
         if _packed is not None:                      # views into a buffer shared with the other layers of a scale
             self.w, self.bias = _packed
             return
-        arr, bp = pack_layer(w, bias)
+        arr, bp = pack_layer(w, bias, precision)
         self.w = torch.from_numpy(arr.view(np.int16).reshape(-1)).to(device)
         self.bias = torch.from_numpy(bp).to(device)
 
 
-def pack_scale(ws, bs, device):
+def pack_scale(ws, bs, device, precision=None):
     """The layers of one MLP scale packed back to back in ONE device buffer (layer l+1 starts where layer l
     ends): the streamed-weight kernel of csrc/mlp_rowwave.hip walks them as a single linear stream.  Every
-    kernel accepts these layers; separately allocated PackedLayers simply never take the streamed path."""
-    packed = [pack_layer(w, b) for w, b in zip(ws, bs)]
+    kernel accepts these layers; separately allocated PackedLayers simply never take the streamed path.
+    precision: "bf16x3" | "fp16" | None (= scale_precision(ws)); one precision per scale."""
+    precision = precision or scale_precision(ws)
+    packed = [pack_layer(w, b, precision) for w, b in zip(ws, bs)]
     flat = np.concatenate([arr.view(np.int16).reshape(-1) for arr, _ in packed])
     buf = torch.from_numpy(flat).to(device)
     out, off = [], 0
     for (arr, bp), w in zip(packed, ws):
         n = arr.size
-        out.append(PackedLayer(w, None, device, _packed=(buf[off:off + n], torch.from_numpy(bp).to(device))))
+        out.append(PackedLayer(w, None, device, _packed=(buf[off:off + n], torch.from_numpy(bp).to(device)), precision=precision))
         off += n
     return out
+
+
+def scale_flags(layers):
+    """The sa_group_mlp_max flag bits that describe how `layers` (one scale) were packed: bit 2 = fp16 planes."""
+    precs = {l.precision for l in layers}
+    if len(precs) != 1:
+        raise ValueError("the layers of a scale must share one operand precision, got %s" % sorted(precs))
+    return 4 if precs == {"fp16"} else 0
 
 
 class VariableStore:
@@ -116,12 +153,12 @@ class VariableStore:
             self._cache[key] = PackedLayer(w, b, self.device)
         return self._cache[key]
 
-    def scale(self, scopes, bn=True):
-        """The conv layers of one MLP scale, packed contiguously (pack_scale)."""
-        key = (tuple(scopes), bool(bn))
+    def scale(self, scopes, bn=True, precision=None):
+        """The conv layers of one MLP scale, packed contiguously (pack_scale) at the scale's operand precision."""
+        key = (tuple(scopes), bool(bn), precision)
         if key not in self._cache:
             folded = [fold_conv_bn(self.params, sc, bn) for sc in scopes]
-            self._cache[key] = pack_scale([w for w, _ in folded], [b for _, b in folded], self.device)
+            self._cache[key] = pack_scale([w for w, _ in folded], [b for _, b in folded], self.device, precision)
         return self._cache[key]
 
 

@@ -297,7 +297,7 @@ def _pad_like_ball_query(idx, cnt):
     return np.where(pad, idx[:, :, :1], idx)
 
 
-def _run_group_mlp(gpu, xyz, feat, new_xyz, idx, cnt, ws, bs, contiguous=True, flags=0):
+def _run_group_mlp(gpu, xyz, feat, new_xyz, idx, cnt, ws, bs, contiguous=True, flags=0, precision=None):
     import ctypes
     N = pkg("utils._native")
     Wt = pkg("utils.weights")
@@ -306,7 +306,8 @@ def _run_group_mlp(gpu, xyz, feat, new_xyz, idx, cnt, ws, bs, contiguous=True, f
     c = 0 if feat is None else feat.shape[2]
     # one buffer per scale (the library's own host side does the same); contiguous=False: separately allocated
     # layers, which must still work (they take the non-streamed kernels)
-    layers = Wt.pack_scale(ws, bs, gpu) if contiguous else [Wt.PackedLayer(w, bb, gpu) for w, bb in zip(ws, bs)]
+    layers = Wt.pack_scale(ws, bs, gpu, precision) if contiguous else [Wt.PackedLayer(w, bb, gpu) for w, bb in zip(ws, bs)]
+    flags |= Wt.scale_flags(layers)
     nl = len(layers)
     out = torch.full((b, m, layers[-1].N + 5), -7.0, dtype=torch.float32, device=gpu)   # strided output
     dims = (ctypes.c_int * (nl + 1))(*([c + 3] + [l.N for l in layers]))
@@ -394,6 +395,35 @@ def test_group_mlp_max_rowwave_shapes(gpu, oracle, c, ns, dims, m):
     assert err < MLP_TOL, "relative error %g (compact plan)" % err
     assert (got[cnt == 0] == 0).all()
     assert np.array_equal(got, _run_group_mlp(gpu, xyz, feat, new_xyz, pidx, cnt, ws, bs, flags=1))
+
+
+@pytest.mark.parametrize("c,ns,dims,m", [(256, 16, [256, 256, 512], 300), (256, 32, [256, 512, 1024], 300),
+                                         (64, 32, [64, 64, 128], 45), (5, 8, [24], 45), (0, 48, [16, 32, 48], 45)])
+def test_group_mlp_max_operand_precisions(gpu, oracle, c, ns, dims, m):
+    # both operand precisions of the fused kernels (csrc/mlp.hip "Operand precision") on the same inputs: split bf16
+    # (three passes) stays ~1e-5 of the fp32 oracle; fp16 (one pass) stays inside the 1e-3 bar on the wide (layer4)
+    # shapes it is selected for by utils/weights.scale_precision, and is still correct code on any other shape (the
+    # looser bound there is why the rule does not select it)
+    rng = np.random.default_rng(c * 7 + ns + m)
+    b, n = 2, 600
+    xyz = _cloud(rng, b, n, scale=4.0)
+    feat = rng.normal(0, 1, (b, n, c)).astype(np.float32) if c > 0 else None
+    new_xyz = xyz[:, rng.integers(0, n, m)] + rng.normal(0, 0.1, (b, m, 3)).astype(np.float32)
+    idx = rng.integers(0, n, (b, m, ns)).astype(np.int32)
+    cnt = rng.integers(0, ns + 1, (b, m)).astype(np.int32)
+    pidx = _pad_like_ball_query(idx, cnt)
+    ws, bs = _rand_layers(rng, [c + 3] + dims)
+    ref = oracle.group_mlp_max(xyz, feat, new_xyz, pidx, cnt, ws, bs)
+    Wt = pkg("utils.weights")
+    wide = all(w.shape[0] >= Wt.FP16_MIN_K for w in ws)
+    assert Wt.scale_precision(ws) == ("fp16" if wide else "bf16x3")
+    for precision, bar in (("bf16x3", 5e-5), ("fp16", MLP_TOL if wide else 3e-3)):
+        got = _run_group_mlp(gpu, xyz, feat, new_xyz, pidx, cnt, ws, bs, precision=precision)
+        err = np.abs(got - ref).max() / np.abs(ref).max()
+        print("precision %s dims %s: %.2e of the fp32 oracle" % (precision, [c + 3] + dims, err))
+        assert err < bar, "%s: relative error %g" % (precision, err)
+        assert (got[cnt == 0] == 0).all()
+        assert np.array_equal(got, _run_group_mlp(gpu, xyz, feat, new_xyz, pidx, cnt, ws, bs, flags=1, precision=precision))
 
 
 def test_group_mlp_max_separately_allocated_layers(gpu, oracle):

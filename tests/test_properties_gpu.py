@@ -166,7 +166,7 @@ def test_grouped_mlp_is_permutation_invariant_inside_a_ball(gpu, c, ns, dims):
         st = N.lib().sa_group_mlp_max(b, n, m, ns, c, xyz.data_ptr(), feat.data_ptr(), new_xyz.data_ptr(), ix.data_ptr(),
                                       cnt.data_ptr(), nl, dm, (ctypes.c_void_p * nl)(*[l.w.data_ptr() for l in layers]),
                                       (ctypes.c_void_p * nl)(*[l.bias.data_ptr() for l in layers]), out.data_ptr(),
-                                      dims[-1], 0, plan.data_ptr(), plan_bytes, 0, N.current_stream())
+                                      dims[-1], 0, plan.data_ptr(), plan_bytes, Wt.scale_flags(layers), N.current_stream())
         assert st == 0
         torch.cuda.synchronize()
         return out
