@@ -92,9 +92,10 @@ __device__ __forceinline__ f32x16 mfma_f16(uint4 a, uint4 b, f32x16 c) {
 // Operand precision of a scale, PR (chosen on the host per scale, utils/weights.py):
 //   3  split bf16: hi/lo planes of activations and weights, three MFMA passes per k-step (~5e-6 of the fp32 oracle)
 //   1  fp16: one plane, one pass (v_cvt_pk_f16_f32 rounds to nearest even, v_mfma_f32_32x32x16_f16, fp32 accumulate);
-//      used for the scales whose every contraction is >= 256 wide (layer4 of 3dssd.yaml), measured 3-5e-4 of the fp32
-//      oracle through the three stacked layers against the 1e-3 bar.  Half the LDS, weight bytes and fragment
-//      registers, a third of the matrix passes, one converter instruction per pair instead of six.
+//      used for the scales whose every contraction is >= 128 wide (layer3 / layer4 of 3dssd.yaml), 4-7e-4 of the fp32
+//      oracle through the three stacked layers against the 1e-3 bar (utils/weights.py has the measurements).  Half
+//      the LDS, weight bytes and fragment registers, a third of the matrix passes, one converter instruction per pair
+//      instead of six.
 constexpr __host__ __device__ int grp_bytes(int PR) { return PR == 3 ? 32 : 16; }   // one 8-channel group of an LDS row
 constexpr __host__ __device__ int wblk(int PR) { return PR == 3 ? 128 : 64; }       // uint4 per (tile, k-step) of weights
 
@@ -1045,7 +1046,7 @@ int roundup(int x, int q) { return (x + q - 1) / q * q; }
 int sa_rowwave_try(int b, int n, int m, int ns, int c, const float *xyz, const float *feat, const float *new_xyz,
                    const int *idx, const int *cnt, int nl, const int *dims, const void *const *wpack,
                    const float *const *bias, float *out, int out_stride, int out_off, const int *plan_hdr,
-                   const int *plan_gran, long max_tiles, hipStream_t stream, int *st);
+                   const int *plan_gran, long max_tiles, int fp16, hipStream_t stream, int *st);
 
 // Upper bound of the plan length: next fit never leaves two consecutive tiles with a combined fill <= 4 granules, so
 // the list is shorter than twice the granules (+ the padding of the last tile).
@@ -1121,10 +1122,10 @@ extern "C" int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float 
         SA_CHECK_LAUNCH();
     }
     const bool fp16 = (flags & 4) != 0;
-    if (!fp16) {
+    {
         int st = SA_OK;
         if (sa_rowwave_try(b, n, m, ns, c, xyz, feat, new_xyz, idx, cnt, nl, dims, wpack, bias, out, out_stride,
-                           out_off, hdr, gran, max_tiles, stream, &st))
+                           out_off, hdr, gran, max_tiles, fp16 ? 1 : 0, stream, &st))
             return st;
     }
     const int abytes = fp16 ? 2 : 4;               // LDS bytes per activation channel (one fp16 plane / hi + lo bf16)

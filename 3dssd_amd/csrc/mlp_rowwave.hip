@@ -23,6 +23,8 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct RwParams {
@@ -46,6 +48,11 @@ __device__ __forceinline__ f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) {
                                                    __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+__device__ __forceinline__ f32x16 mfma_f16(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a),
+                                                  __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
 // x ~= hi + lo, two values per v_cvt_pk_bf16_f32 (round to nearest even); residuals stay scalar so that no
 // aligned register pairs are forced on the allocator
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -63,6 +70,17 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4 &hi, uint4 &lo
     split2(v[2], v[3], hi.y, lo.y);
     split2(v[4], v[5], hi.z, lo.z);
     split2(v[6], v[7], hi.w, lo.w);
+}
+// the fp16 operand form (PR == 1, see mlp.hip "Operand precision"): one plane, v_cvt_pk_f16_f32 (nearest even)
+__device__ __forceinline__ unsigned cvt2_f16(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
+// 8 fp32 -> the operand planes of precision PR (lo is untouched for PR == 1)
+template <int PR>
+__device__ __forceinline__ void to_planes(const float (&v)[8], uint4 &hi, uint4 &lo) {
+    if (PR == 3) split8(v, hi, lo);
+    else hi = make_uint4(cvt2_f16(v[0], v[1]), cvt2_f16(v[2], v[3]), cvt2_f16(v[4], v[5]), cvt2_f16(v[6], v[7]));
 }
 
 #ifdef SA_RW_TIMING
@@ -143,22 +161,39 @@ __device__ __forceinline__ void load_group(const RwParams &P, const RowRef &rr, 
 
 // acc (D^T form: reg r of lane (row, h) = channel (r&3) + 8*(r>>2) + 4h of the tile) -> ReLU -> the two
 // B-operand fragments (k-steps 2*ct and 2*ct+1 of the next layer) of this lane
-template <int KSN>
+template <int KSN, int PR = 3>
 __device__ __forceinline__ void acc_to_frags(const f32x16 &acc, int ct, uint4 (&fh)[KSN], uint4 (&fl)[KSN]) {
 #pragma unroll
     for (int hk = 0; hk < 2; ++hk) {
         if (2 * ct + hk < KSN) {
-            float v[8];
+            if (PR == 3) {
+                float v[8];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float a = sa::fmax_nn(acc[8 * hk + r], 0.0f);
-                const float b = sa::fmax_nn(acc[8 * hk + 4 + r], 0.0f);
-                // upper-half lanes of `a` <-> lower-half lanes of `b`
-                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-                v[r] = __uint_as_float(sw[0]);
-                v[4 + r] = __uint_as_float(sw[1]);
+                for (int r = 0; r < 4; ++r) {
+                    const float a = sa::fmax_nn(acc[8 * hk + r], 0.0f);
+                    const float b = sa::fmax_nn(acc[8 * hk + 4 + r], 0.0f);
+                    // upper-half lanes of `a` <-> lower-half lanes of `b`
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+                    v[r] = __uint_as_float(sw[0]);
+                    v[4 + r] = __uint_as_float(sw[1]);
+                }
+                split8(v, fh[2 * ct + hk], fl[2 * ct + hk]);
+            } else {
+                // fp16: convert first, then swap the PACKED pairs -- half the cross-half moves
+                unsigned pa[2], pb[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    pa[j] = cvt2_f16(sa::fmax_nn(acc[8 * hk + 2 * j], 0.0f), sa::fmax_nn(acc[8 * hk + 2 * j + 1], 0.0f));
+                    pb[j] = cvt2_f16(sa::fmax_nn(acc[8 * hk + 4 + 2 * j], 0.0f), sa::fmax_nn(acc[8 * hk + 4 + 2 * j + 1], 0.0f));
+                }
+                uint4 f;
+                {
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(pa[0], pb[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(pa[1], pb[1], false, false);
+                    f = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                }
+                fh[2 * ct + hk] = f;
             }
-            split8(v, fh[2 * ct + hk], fl[2 * ct + hk]);
         }
     }
 }
@@ -353,80 +388,90 @@ struct RsCtx {
     uint4 *ring;          // 2 slots x PC x 64 uint4
     int w, lane;
     int abase;            // uint4 index of this lane's fragment slot in the current chunk
-    u32x4 nh, nl;         // weight fragment (hi, lo plane) of the NEXT k-step tile, already requested from LDS
+    u32x4 qh[4], ql[4];   // weight fragments (hi, lo plane) of the next LA k-step tiles, already requested from LDS
 };
 
-// The stream of a pass is cut into CPP = 12 chunks of G = TOT/12 k-step tiles (PC = 2G pieces of 1 KiB; wave w
-// moves pieces w, w+NW, ...).  DEPTH staging sets: chunk k travels in set k % DEPTH, its loads are issued DEPTH
-// boundaries before the boundary that stores it into LDS (12 % DEPTH == 0 keeps every index a compile-time
-// constant across passes), i.e. they have DEPTH chunks of matrix work to land.
+// The stream of a pass is cut into CPP chunks of G = TOT/CPP k-step tiles (PC = NP*G pieces of 1 KiB, NP = planes per
+// tile: 2 for split bf16, 1 for fp16; wave w moves pieces w, w+NW, ...).  DEPTH staging sets: chunk k travels in set
+// k % DEPTH, its loads are issued DEPTH boundaries before the boundary that stores it into LDS (CPP % DEPTH == 0 keeps
+// every index a compile-time constant across passes), i.e. they have DEPTH chunks of matrix work to land.
 constexpr int kRsCPP = 12;
 
-// global loads of stream chunk sc (0 .. 11) into staging set `st`.  The three layers of the scale are packed
+// global loads of stream chunk sc (0 .. CPP-1) into staging set `st`.  The three layers of the scale are packed
 // back to back in ONE device buffer (checked on the host): the stream is a plain linear array of pieces.
-template <int G, int NW, int PPW>
+template <int PC, int NW, int PPW>
 __device__ __forceinline__ void rs_issue_chunk(const RwParams &P, RsCtx &X, u32x4 (&st)[PPW], int sc) {
     int wl = X.w;
     asm volatile("" : "+s"(wl));        // opaque: keeps the per-chunk addresses from being hoisted out of the pass loop
-    const unsigned off = (unsigned)((sc * 2 * G + wl) * 64 + X.lane);
+    const unsigned off = (unsigned)((sc * PC + wl) * 64 + X.lane);
 #pragma unroll
     for (int i = 0; i < PPW; ++i)
-        if (NW * i + NW <= 2 * G || wl + NW * i < 2 * G)          // ragged last round: wave-uniform
+        if (NW * i + NW <= PC || wl + NW * i < PC)          // ragged last round: wave-uniform
             st[i] = *(const u32x4 *)(P.w[0] + (off + (unsigned)(NW * i * 64)));
 }
-template <int G, int NW, int PPW>
+template <int PC, int NW, int PPW>
 __device__ __forceinline__ void rs_store_stage(RsCtx &X, const u32x4 (&st)[PPW], int slot) {
 #pragma unroll
     for (int i = 0; i < PPW; ++i)
-        if (NW * i + NW <= 2 * G || X.w + NW * i < 2 * G)
-            *(u32x4 *)(X.ring + ((slot * 2 * G + X.w + NW * i) * 64 + X.lane)) = st[i];
+        if (NW * i + NW <= PC || X.w + NW * i < PC)
+            *(u32x4 *)(X.ring + ((slot * PC + X.w + NW * i) * 64 + X.lane)) = st[i];
 }
 // chunk boundary in front of stream position p (p % G == 0)
-template <int G, int NW, int PPW, int DEPTH>
+template <int G, int NP, int NW, int PPW, int DEPTH, int CPP>
 __device__ __forceinline__ void rs_boundary(const RwParams &P, RsCtx &X, u32x4 (&st)[DEPTH][PPW], int p) {
+    constexpr int PC = NP * G;
     const int cidx = p / G;
     __builtin_amdgcn_sched_barrier(0);      // the chunk's loads must not drift up across earlier boundaries
     __syncthreads();
-    rs_store_stage<G, NW, PPW>(X, st[(cidx + 1) % DEPTH], (cidx + 1) & 1);
-    rs_issue_chunk<G, NW, PPW>(P, X, st[(cidx + 1) % DEPTH], (cidx + 1 + DEPTH) % kRsCPP);
+    rs_store_stage<PC, NW, PPW>(X, st[(cidx + 1) % DEPTH], (cidx + 1) & 1);
+    rs_issue_chunk<PC, NW, PPW>(P, X, st[(cidx + 1) % DEPTH], (cidx + 1 + DEPTH) % CPP);
     __builtin_amdgcn_sched_barrier(0);
-    X.abase = (cidx & 1) * 2 * G * 64 + X.lane;
+    X.abase = (cidx & 1) * PC * 64 + X.lane;
 }
 // one output tile of a layer: k-step tiles base .. base+KS-1 of the stream.  One accumulator chain: two waves
 // share a SIMD in this kernel, their chains interleave on the matrix pipe, and the register budget (256) has no
-// room for a second accumulator.
-template <int KS, int G, int NW, int PPW, int DEPTH, bool WFIRST>
+// room for a second accumulator.  The weight fragments of the next LA k-step tiles are requested from LDS before
+// the current tile's MFMAs are issued: a fragment feeds three passes (96 cycles) in the split-bf16 form, so one
+// tile of lookahead covers the LDS round trip there, but only one 32-cycle pass in the fp16 form -- LA = 4.
+template <int KS, int G, int PR, int NW, int PPW, int DEPTH, int CPP, bool WFIRST>
 __device__ __forceinline__ void rs_tile_mma(const RwParams &P, RsCtx &X, u32x4 (&st)[DEPTH][PPW],
                                             const uint4 (&ih)[KS], const uint4 (&il)[KS], int base,
                                             f32x16 &acc) {
+    constexpr int NP = PR == 3 ? 2 : 1;
+    constexpr int LA = PR == 3 ? 1 : 4;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        const int p = base + ks;
-        u32x4 ch, cl;
-        if (p % G == 0) {
-            rs_boundary<G, NW, PPW, DEPTH>(P, X, st, p);
-            ch = *(const u32x4 *)(X.ring + (X.abase + ((p % G) * 2) * 64));
-            cl = *(const u32x4 *)(X.ring + (X.abase + ((p % G) * 2 + 1) * 64));
-        } else {
-            ch = X.nh;
-            cl = X.nl;
+        const int p = base + ks, pc = p % G;
+        if (pc == 0) {
+            rs_boundary<G, NP, NW, PPW, DEPTH, CPP>(P, X, st, p);
+#pragma unroll
+            for (int j = 0; j < LA; ++j) {
+                if (j < G) {
+                    X.qh[j] = *(const u32x4 *)(X.ring + (X.abase + (j * NP) * 64));
+                    if (PR == 3) X.ql[j] = *(const u32x4 *)(X.ring + (X.abase + (j * NP + 1) * 64));
+                }
+            }
         }
-        // the next k-step tile's fragments are requested before this one's MFMAs are issued (one wave per SIMD:
-        // nobody else hides the LDS round trip); the first tile of a chunk cannot be requested before its barrier
-        if ((p + 1) % G != 0) {
-            X.nh = *(const u32x4 *)(X.ring + (X.abase + (((p + 1) % G) * 2) * 64));
-            X.nl = *(const u32x4 *)(X.ring + (X.abase + (((p + 1) % G) * 2 + 1) * 64));
+        const u32x4 ch = X.qh[pc % LA], cl = X.ql[pc % LA];
+        // (the first LA tiles of a chunk cannot be requested before its barrier)
+        if (pc + LA < G) {
+            X.qh[pc % LA] = *(const u32x4 *)(X.ring + (X.abase + ((pc + LA) * NP) * 64));
+            if (PR == 3) X.ql[pc % LA] = *(const u32x4 *)(X.ring + (X.abase + ((pc + LA) * NP + 1) * 64));
             __builtin_amdgcn_sched_barrier(0);
         }
         const uint4 wh = __builtin_bit_cast(uint4, ch), wl = __builtin_bit_cast(uint4, cl);
-        if (WFIRST) {
-            acc = mfma_bf16(wh, ih[ks], acc);
-            acc = mfma_bf16(wl, ih[ks], acc);
-            acc = mfma_bf16(wh, il[ks], acc);
+        if (PR == 3) {
+            if (WFIRST) {
+                acc = mfma_bf16(wh, ih[ks], acc);
+                acc = mfma_bf16(wl, ih[ks], acc);
+                acc = mfma_bf16(wh, il[ks], acc);
+            } else {
+                acc = mfma_bf16(ih[ks], wh, acc);
+                acc = mfma_bf16(ih[ks], wl, acc);
+                acc = mfma_bf16(il[ks], wh, acc);
+            }
         } else {
-            acc = mfma_bf16(ih[ks], wh, acc);
-            acc = mfma_bf16(ih[ks], wl, acc);
-            acc = mfma_bf16(il[ks], wh, acc);
+            acc = WFIRST ? mfma_f16(wh, ih[ks], acc) : mfma_f16(ih[ks], wh, acc);
         }
     }
 }
@@ -438,13 +483,17 @@ __device__ __forceinline__ void load_bias_tile(const float *bias, int ct, int ha
     }
 }
 
-template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF, int DEPTH>
+// PR: operand precision (3 = split bf16, 1 = fp16, see mlp.hip); CPP: chunks per pass (a divisor of the k-step tiles
+// of the scale); PF: 1 = the next tile's rows are requested right after this tile's last layer (two or more tiles per
+// wave), 0 = at the top of the pass (one tile per wave: nothing to prefetch, 17 x 8 registers less).
+template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF, int DEPTH, int PR, int CPP, int PF>
 __global__ __launch_bounds__(NW * 64, WPE) void mlp_rs_kernel(RwParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KT0 = NT1 * KS0, KT1 = NT2 * KS1, KT2 = NT3 * KS2, TOT = KT0 + KT1 + KT2;
-    static_assert(TOT % kRsCPP == 0 && kRsCPP % DEPTH == 0, "12 chunks per pass, staging depth a divisor of 12");
-    constexpr int G = TOT / kRsCPP;          // k-step tiles per chunk
-    constexpr int PC = 2 * G;                // 1 KiB pieces (one plane of one k-step tile) per chunk
+    static_assert(TOT % CPP == 0 && CPP % DEPTH == 0, "CPP chunks per pass, staging depth a divisor of CPP");
+    constexpr int NP = PR == 3 ? 2 : 1;      // planes (1 KiB pieces) per k-step tile
+    constexpr int G = TOT / CPP;             // k-step tiles per chunk
+    constexpr int PC = NP * G;               // 1 KiB pieces per chunk
     constexpr int PPW = (PC + NW - 1) / NW;  // pieces a wave moves per chunk (last round may be ragged)
     RsCtx X;
     u32x4 stage[DEPTH][PPW];                 // chunk k waits in stage[k % DEPTH]
@@ -471,13 +520,13 @@ __global__ __launch_bounds__(NW * 64, WPE) void mlp_rs_kernel(RwParams P) {
     int tc = gw, tf = gw + nwaves;
 
     // ---- prologue: chunk 0 into slot 0, chunks 1 .. DEPTH staged; first tile's rows and features
-    rs_issue_chunk<G, NW, PPW>(P, X, stage[0], 0);
+    rs_issue_chunk<PC, NW, PPW>(P, X, stage[0], 0);
     RowRef cur = load_row_ref(P, ngran, tc, row);
-    rs_store_stage<G, NW, PPW>(X, stage[0], 0);
+    rs_store_stage<PC, NW, PPW>(X, stage[0], 0);
 #pragma unroll
-    for (int k = 1; k <= DEPTH; ++k) rs_issue_chunk<G, NW, PPW>(P, X, stage[k % DEPTH], k % kRsCPP);
+    for (int k = 1; k <= DEPTH; ++k) rs_issue_chunk<PC, NW, PPW>(P, X, stage[k % DEPTH], k % CPP);
     float raw[KS0][8];
-    {
+    if (PF) {
         const RowTail tl = load_row_tail<TAILF>(P, cur);
 #pragma unroll
         for (int ks = 0; ks < KS0; ++ks) load_group(P, cur, tl, 2 * ks + half, raw[ks]);
@@ -487,9 +536,14 @@ __global__ __launch_bounds__(NW * 64, WPE) void mlp_rs_kernel(RwParams P) {
     RW_TICK(0)
     for (int q = 0; q < npass; ++q) {
         RW_COUNT();
+        if (!PF) {
+            const RowTail tl = load_row_tail<TAILF>(P, cur);
+#pragma unroll
+            for (int ks = 0; ks < KS0; ++ks) load_group(P, cur, tl, 2 * ks + half, raw[ks]);
+        }
         uint4 h0[KS0], l0[KS0];
 #pragma unroll
-        for (int ks = 0; ks < KS0; ++ks) split8(raw[ks], h0[ks], l0[ks]);
+        for (int ks = 0; ks < KS0; ++ks) to_planes<PR>(raw[ks], h0[ks], l0[ks]);
         int ent[4], cn[4];                       // the tile's plan entries / ball counts, wave-uniform
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -504,8 +558,8 @@ __global__ __launch_bounds__(NW * 64, WPE) void mlp_rs_kernel(RwParams P) {
         for (int ct = 0; ct < NT1; ++ct) {
             f32x16 ae;
             load_bias_tile(b0, ct, half, ae);
-            rs_tile_mma<KS0, G, NW, PPW, DEPTH, true>(P, X, stage, h0, l0, ct * KS0, ae);
-            acc_to_frags<KS1>(ae, ct, h1, l1);
+            rs_tile_mma<KS0, G, PR, NW, PPW, DEPTH, CPP, true>(P, X, stage, h0, l0, ct * KS0, ae);
+            acc_to_frags<KS1, PR>(ae, ct, h1, l1);
         }
         RW_TICK(2)
         // ---- hidden layer 1
@@ -514,8 +568,8 @@ __global__ __launch_bounds__(NW * 64, WPE) void mlp_rs_kernel(RwParams P) {
         for (int ct = 0; ct < NT2; ++ct) {
             f32x16 ae;
             load_bias_tile(b1, ct, half, ae);
-            rs_tile_mma<KS1, G, NW, PPW, DEPTH, true>(P, X, stage, h1, l1, KT0 + ct * KS1, ae);
-            acc_to_frags<KS2>(ae, ct, h2, l2);
+            rs_tile_mma<KS1, G, PR, NW, PPW, DEPTH, CPP, true>(P, X, stage, h1, l1, KT0 + ct * KS1, ae);
+            acc_to_frags<KS2, PR>(ae, ct, h2, l2);
         }
         RW_TICK(3)
         // ---- last layer (D form), granule maxima, relu(max + bias) written per ball run (layers_util.py:178-181)
@@ -524,7 +578,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void mlp_rs_kernel(RwParams P) {
             f32x16 ae;
 #pragma unroll
             for (int r = 0; r < 16; ++r) ae[r] = 0.0f;
-            rs_tile_mma<KS2, G, NW, PPW, DEPTH, false>(P, X, stage, h2, l2, KT0 + KT1 + ct * KS2, ae);
+            rs_tile_mma<KS2, G, PR, NW, PPW, DEPTH, CPP, false>(P, X, stage, h2, l2, KT0 + KT1 + ct * KS2, ae);
             float qm[4];
             sa::granule_max(ae, qm);
             const int c = ct * 32 + (lane & 31);
@@ -536,7 +590,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void mlp_rs_kernel(RwParams P) {
         tc += nwaves;
         tf += nwaves;
         cur = nxt;
-        {
+        if (PF) {
             const RowTail tl = load_row_tail<TAILF>(P, cur);
 #pragma unroll
             for (int ks = 0; ks < KS0; ++ks) load_group(P, cur, tl, 2 * ks + half, raw[ks]);
@@ -577,11 +631,11 @@ int launch_rw(const RwParams &P, long max_tiles, int wgs_per_cu, hipStream_t str
     return SA_OK;
 }
 
-template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF, int DEPTH>
+template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF, int DEPTH, int PR, int CPP, int PF>
 int launch_rs(const RwParams &P, long max_tiles, int wgs_per_cu, hipStream_t stream) {
-    constexpr int G = (NT1 * KS0 + NT2 * KS1 + NT3 * KS2) / kRsCPP;
-    constexpr size_t lds = (size_t)2 * 2 * G * 1024 + (size_t)(NT1 + NT2 + NT3) * 128;
-    auto kern = mlp_rs_kernel<KS0, NT1, KS1, NT2, KS2, NT3, NW, WPE, TAILF, DEPTH>;
+    constexpr int G = (NT1 * KS0 + NT2 * KS1 + NT3 * KS2) / CPP;
+    constexpr size_t lds = (size_t)2 * (PR == 3 ? 2 : 1) * G * 1024 + (size_t)(NT1 + NT2 + NT3) * 128;
+    auto kern = mlp_rs_kernel<KS0, NT1, KS1, NT2, KS2, NT3, NW, WPE, TAILF, DEPTH, PR, CPP, PF>;
     if (lds > 48 * 1024) {
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipGetLastError();
@@ -601,7 +655,7 @@ int launch_rs(const RwParams &P, long max_tiles, int wgs_per_cu, hipStream_t str
 int sa_rowwave_try(int b, int n, int m, int ns, int c, const float *xyz, const float *feat, const float *new_xyz,
                    const int *idx, const int *cnt, int nl, const int *dims, const void *const *wpack,
                    const float *const *bias, float *out, int out_stride, int out_off, const int *plan_hdr,
-                   const int *plan_gran, long max_tiles, hipStream_t stream, int *st) {
+                   const int *plan_gran, long max_tiles, int fp16, hipStream_t stream, int *st) {
     static const bool enabled = !(getenv("SA_MLP_ROWWAVE") && atoi(getenv("SA_MLP_ROWWAVE")) == 0);
     if (!enabled || nl != 3) return 0;
     if (!(c == 1 || (c > 0 && (c & 7) == 0))) return 0;      // input layouts the in-register gather handles
@@ -626,7 +680,7 @@ int sa_rowwave_try(int b, int n, int m, int ns, int c, const float *xyz, const f
     P.inv_m = 1.0f / (float)m;
     if (max_tiles > 0x0FFFFFFFl) return 0;
 #define SA_RW(K0, N1, K1, N2, K2, N3_, NW_, WPE_, WGS)                                              \
-    if (KS0 == K0 && NT1 == N1 && KS1 == K1 && NT2 == N2 && KS2 == K2 && NT3 == N3_) {             \
+    if (!fp16 && KS0 == K0 && NT1 == N1 && KS1 == K1 && NT2 == N2 && KS2 == K2 && NT3 == N3_) {             \
         *st = c == 1 ? launch_rw<K0, N1, K1, N2, K2, N3_, NW_, WPE_, 1>(P, max_tiles, WGS, stream)             \
                      : launch_rw<K0, N1, K1, N2, K2, N3_, NW_, WPE_, 0>(P, max_tiles, WGS, stream);            \
         return 1;                                                                                   \
@@ -638,19 +692,31 @@ int sa_rowwave_try(int b, int n, int m, int ns, int c, const float *xyz, const f
 #undef SA_RW
     // the streamed kernel walks the three layers as one linear weight stream: they must be packed back to back
     // (utils/weights.py pack_scale does that); separately allocated layers take the generic kernel
+    const int planes = fp16 ? 1 : 2;         // 1 KiB pieces per (tile, k-step)
     const bool contiguous =
-        (const char *)wpack[1] == (const char *)wpack[0] + (size_t)NT1 * KS0 * 2048 &&
-        (const char *)wpack[2] == (const char *)wpack[1] + (size_t)NT2 * KS1 * 2048;
+        (const char *)wpack[1] == (const char *)wpack[0] + (size_t)NT1 * KS0 * planes * 1024 &&
+        (const char *)wpack[2] == (const char *)wpack[1] + (size_t)NT2 * KS1 * planes * 1024;
     static const bool stream_enabled = !(getenv("SA_MLP_ROWSTREAM") && atoi(getenv("SA_MLP_ROWSTREAM")) == 0);
-#define SA_RS(K0, N1, K1, N2, K2, N3_, NW_, WPE_, WGS, D_)                                          \
-    if (stream_enabled && contiguous && c != 1 && KS0 == K0 && NT1 == N1 && KS1 == K1 && NT2 == N2 && KS2 == K2 && NT3 == N3_) { \
-        *st = launch_rs<K0, N1, K1, N2, K2, N3_, NW_, WPE_, 0, D_>(P, max_tiles, WGS, stream);       \
+#define SA_RS(K0, N1, K1, N2, K2, N3_, NW_, WPE_, WGS, D_, PR_, CPP_, PF_)                              \
+    if (stream_enabled && contiguous && c != 1 && (PR_ == 1) == (fp16 != 0) && KS0 == K0 && NT1 == N1 && KS1 == K1 && NT2 == N2 && KS2 == K2 && NT3 == N3_) { \
+        *st = launch_rs<K0, N1, K1, N2, K2, N3_, NW_, WPE_, 0, D_, PR_, CPP_, PF_>(P, max_tiles, WGS, stream); \
         return 1;                                                                                   \
     }
-    // 8 waves (2 per SIMD, 256 registers each), 1 workgroup per CU; staging depth as the register budget allows
-    SA_RS(9, 4, 8, 4, 8, 8, 8, 2, 1, 2)       // 131 -> 128 -> 128 -> 256   (layer3 scale 0): 132 k-step tiles
-    SA_RS(9, 4, 8, 6, 12, 8, 8, 2, 1, 2)      // 131 -> 128 -> 192 -> 256   (layer3 scale 1): 180
-    SA_RS(9, 4, 8, 8, 16, 8, 8, 2, 1, 1)      // 131 -> 128 -> 256 -> 256   (layer3 scale 2): 228
+    // split bf16: 8 waves (2 per SIMD, 256 registers each), 1 workgroup per CU; staging depth as the register budget
+    // allows; the widest shape runs 4 waves of 512 registers (the 8-wave form spilled 34 registers per lane)
+    SA_RS(9, 4, 8, 4, 8, 8, 8, 2, 1, 2, 3, 12, 1)       // 131 -> 128 -> 128 -> 256   (layer3 scale 0): 132 k-step tiles
+    SA_RS(9, 4, 8, 6, 12, 8, 8, 2, 1, 2, 3, 12, 1)      // 131 -> 128 -> 192 -> 256   (layer3 scale 1): 180
+    SA_RS(9, 4, 8, 8, 16, 8, 4, 1, 1, 2, 3, 12, 1)      // 131 -> 128 -> 256 -> 256   (layer3 scale 2): 228
+    // fp16 (one plane, half the fragment registers: 150-180 VGPRs, no staging-depth compromise).  Layer4 scale 0 runs
+    // here too (4 waves of 512 registers: 0.035 ms against 0.050 for the LDS-activation kernel of mlp.hip); the
+    // 259 -> 256 -> 512 -> 1024 scale was built in this form as well (its 512-wide hidden layer fits a wave's registers
+    // in fp16: 128 for the 32 fragments) and measured SLOWER than group_mlp_wide_kernel (0.125-0.15 ms against 0.106,
+    // whatever the chunk size, staging depth or fragment lookahead): one wave per SIMD has nobody to overlap its
+    // 1416-MFMA chain with, so that scale stays with the wide kernel.
+    SA_RS(9, 4, 8, 4, 8, 8, 8, 2, 1, 2, 1, 12, 1)       // layer3 scale 0
+    SA_RS(9, 4, 8, 6, 12, 8, 8, 2, 1, 2, 1, 12, 1)      // layer3 scale 1
+    SA_RS(9, 4, 8, 8, 16, 8, 8, 2, 1, 2, 1, 12, 1)      // layer3 scale 2
+    SA_RS(17, 8, 16, 8, 16, 16, 4, 1, 1, 2, 1, 26, 0)   // 259 -> 256 -> 256 -> 512   (layer4 scale 0): 520 tiles, 20 per chunk
 #undef SA_RS
     return 0;
 }
