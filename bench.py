@@ -292,6 +292,34 @@ def timed_region(sh, dev, run, steps, warmup, frames_per_step):
     return t_max, frames_total, host_issue_ms, outs
 
 
+def overlap_probe(run, k):
+    """How the steps of the headline run overlap, measured by the application itself (rocprofv3's kernel trace
+    serialises the streams: profiles/r02_trace16_summary.txt shows 1.4 kernels in flight under the profiler).  A
+    second, untimed run of k steps with a HIP event before and after every step on its stream: a step's device-side
+    span is several times the time between completions, i.e. that many steps are in flight."""
+    torch.cuda.synchronize()
+    base = torch.cuda.Event(enable_timing=True)
+    base.record()
+    marks = []
+    run(k, marks)
+    torch.cuda.synchronize()
+    iv = sorted((base.elapsed_time(s), base.elapsed_time(e)) for s, e in marks)
+    ends = sorted(e for _, e in iv)
+    # steady part: from the first completion to the last start
+    t0, t1 = ends[0], max(s for s, _ in iv)
+    if t1 <= t0:
+        t0, t1 = iv[0][0], ends[-1]
+    busy = sum(max(0.0, min(e, t1) - max(s, t0)) for s, e in iv)
+    spans = [e - s for s, e in iv]
+    done = [e for e in ends if t0 <= e <= t1]
+    return {"steps": k, "step_span_ms_mean": round(sum(spans) / len(spans), 3), "step_span_ms_min": round(min(spans), 3),
+            "step_span_ms_max": round(max(spans), 3),
+            "steps_in_flight_mean": round(busy / (t1 - t0), 2),
+            "ms_between_completions": round((t1 - t0) / max(len(done) - 1, 1), 4),
+            "note": "device-side spans from HIP events around every step of a second, untimed run; in flight = sum of "
+                    "spans inside the steady window / its length"}
+
+
 def mlp_row_stats(net, pts):
     """Rows of the grouped tensor per step: nominal (m x nsample, what the reference's conv2d evaluates), distinct
     (sum of clamp(cnt, 1, ns)) and evaluated (8-row granules of the plan), from the plan headers of one eager step."""
@@ -338,22 +366,35 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
                 xl, fl, _ = net(pts)
             graphs.append((g, xl[-1], fl[-1]))
         torch.cuda.synchronize()
+        # setup, like the capture itself: every graph is replayed once (W warm-up steps reach only the first W graphs)
+        for st, (g, _x, _f) in zip(streams, graphs):
+            with torch.cuda.stream(st):
+                g.replay()
+        torch.cuda.synchronize()
 
-    def run(k):
+    def run(k, marks=None):
         outs = []
         for i in range(k):
             j = i % len(streams)
             with torch.cuda.stream(streams[j]):
+                if marks is not None:
+                    s_ev = torch.cuda.Event(enable_timing=True)
+                    s_ev.record()
                 if graphs is not None:
                     graphs[j][0].replay()
                     outs.append((graphs[j][1], graphs[j][2]))
                 else:
                     xl, fl, _ = net(pts)
                     outs.append((xl[-1], fl[-1]))
+                if marks is not None:
+                    e_ev = torch.cuda.Event(enable_timing=True)
+                    e_ev.record()
+                    marks.append((s_ev, e_ev))
         return outs
 
     t_max, frames_total, host_issue_ms, outs = timed_region(sh, dev, run, args.steps, args.warmup, len(frames))
     assert outs[-1][1].shape == (len(frames), 256, 512)
+    overlap = overlap_probe(run, min(args.steps, 96)) if rank == 0 else None
     # single-stream latency of one batch (no overlap), for the record
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -372,7 +413,9 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
         "value": round(frames_total / t_max, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "bf16 (split hi/lo, 3 MFMA passes, fp32 accumulate) for the grouped MLP; fp32 for FPS / ball query",
+        "dtype": "grouped MLP: fp16 x fp16 -> fp32 accumulate (one MFMA pass) on the scales whose contractions are all >= 128 "
+                 "wide (layer3, layer4), split bf16 hi/lo (three passes) on the narrow scales and the aggregation layers; "
+                 "fp32 for FPS / ball query / distance matrix",
         "data": "synthetic KITTI-shape frames (seeded), random-init weights",
         "config": {"workload": "%s: full 3DSSD SA backbone (3dssd.yaml rows 1-6), %d-pt frames, batch=%d per GPU"
                                % (tag, points, args.batch),
@@ -382,6 +425,7 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
         "host_issue_ms_per_step": round(host_issue_ms, 3),
         "hip_graphs": use_graphs,
         "mlp_rows_per_step": rows,
+        "overlap": overlap,
     }
     if stages:
         dom = max(stages, key=lambda s: s["avg_ms"] * s["calls_per_step"])
@@ -406,7 +450,8 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
             "evaluated_tflops": round(rows["gflop_evaluated"] / mlp_ms, 3) if mlp_ms else 0.0,
             "note": "achieved = the reference's m x nsample rows (SURVEY 8d, 30.9 GFLOP/frame) / single-stream kernel "
                     "time incl. the row-plan kernels; evaluated_tflops counts only the rows the kernels run (distinct "
-                    "rows of each ball, 8-row granules); the split-bf16 form issues 3x as many MFMA flops as either",
+                    "rows of each ball, 8-row granules); issued MFMA flops = evaluated x 3 on the split-bf16 scales, x 1 on "
+                    "the fp16 scales",
             "pmc": _pmc_mlp_util()}
         line["roofline_ball_query"] = {
             "bound": "hbm", "achieved": round(bq_mb / bq_ms, 2) if bq_ms else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
