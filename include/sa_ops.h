@@ -109,12 +109,14 @@ int sa_query_ball_point_grid(int b, int n, int m, int nbands, const float *rmin,
 /* One scale of pointnet_sa_module_msg fused: mask, group, concat [features, rel-xyz], nl x
  * (conv1x1 + folded BN + ReLU), max over nsample, empty-ball mask (layers_util.py:157-181).
  * dims[0] = c+3, dims[l+1] = output channels of layer l; wpack[l]/bias[l] device pointers in the
- * layouts documented in 3dssd_amd/csrc/mlp.hip; out[(b*m+j)*out_stride + out_off + ch]. */
+ * layouts documented in 3dssd_amd/csrc/mlp.hip; out[(b*m+j)*out_stride + out_off + ch].
  * Only the DISTINCT rows of a ball are evaluated: the ball query pads a ball of cnt < nsample points with copies of
  * its first hit (tf_grouping_g.cu:245-248), those rows give identical outputs and the max ignores them -- same
  * result bit for bit, a fraction of the work on KITTI-like clouds (3dssd_amd/csrc/mlp_plan.h).  ws: caller-owned
  * device scratch of sa_group_mlp_max_ws_bytes(b, m, ns) bytes (the per-call row plan).  flags bit 0: evaluate all
- * nsample rows of every ball instead (A/B measurements). */
+ * nsample rows of every ball instead (A/B measurements); bit 1: the plan in ws was built by sa_group_mlp_plan;
+ * bit 2: wpack[] holds single-plane fp16 fragments and the scale runs one fp16 MFMA pass per k-step (fp32
+ * accumulate) instead of the three split-bf16 passes -- chosen per scale by the host (utils/weights.py). */
 unsigned long sa_group_mlp_max_ws_bytes(int b, int m, int ns);
 /* The row plans of all scales of a layer in ONE launch: cnt[i] = pts_cnt of scale i, ws[i] = that scale's scratch,
  * out_off[i] / nout[i] = where scale i's channels go in out.  The layer's sa_group_mlp_max calls then pass
