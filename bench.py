@@ -461,7 +461,7 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
                                            "the grid ball query moves 19 MB per launch and is latency-bound, not "
                                            "bandwidth-bound"}
         line["stages"] = stages
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only (the contract)
         line["cpu_baseline"] = cpu_baseline(arch, params, min(args.batch, 8), points)
     return line
 
@@ -495,7 +495,7 @@ def workload_ffps_isolated(args, sh, rank, world, dev):
     if stages:
         line["roofline"] = roofline_of(max(stages, key=lambda s: s["avg_ms"]), len(frames))
         line["stages"] = stages
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:
         from oracle import sa_oracle as O
         O.lib()
         nb = min(len(frames), os.cpu_count() or 1, 32)
