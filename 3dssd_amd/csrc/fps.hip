@@ -46,15 +46,37 @@ __device__ __forceinline__ float4 cross_wave_pick(const float (*s_val)[kWaves],
     return r;
 }
 
+// Optional inputs/outputs of the *_ex2 entry points: a frame stride for `inp` (so that a range slice xyz[:, s:e] of a
+// larger tensor is sampled in place, no copy launch) and the picked points themselves (the gather_point that
+// layers_util.py:116-119 runs right after the sampler, fused into the sampler's epilogue: one launch less per layer).
+struct FpsSide {
+    long in_bstride;     // elements between consecutive frames of inp (0: dense, n*c / n*n)
+    float *ctr;          // [b, ., 3] centres out, or null
+    long ctr_bstride;    // floats between frames of ctr
+    const float *xyz;    // coordinates the centres are read from (distance-matrix kernel); null: inp itself
+    long xyz_bstride;
+};
+// after the pick loop: o[0..m) hold idx_off + local index; every thread copies some of the picked rows
+__device__ __forceinline__ void write_centres(const FpsSide &S, const float *src, const int *o, int m, int idx_off,
+                                              int b, int t, int nthreads) {
+    if (!S.ctr) return;
+    __syncthreads();                                 // thread 0's index stores are visible to the workgroup
+    float *c = S.ctr + (size_t)b * S.ctr_bstride;
+    for (int i = t; i < m; i += nthreads) {
+        const int k = o[i] - idx_off;
+        c[i * 3 + 0] = src[k * 3 + 0]; c[i * 3 + 1] = src[k * 3 + 1]; c[i * 3 + 2] = src[k * 3 + 2];
+    }
+}
+
 // ---- D-FPS, c == 3, n <= 1024*PPT, everything register resident ------------------------------
 template <int PPT>
 __global__ __launch_bounds__(kBlock) void fps3_reg_kernel(int n, int m, const float *__restrict__ inp,
                                                           int *__restrict__ out, int out_stride,
-                                                          int idx_off) {
+                                                          int idx_off, FpsSide S) {
     __shared__ float s_val[2][kWaves];
     __shared__ float4 s_pt[2][kWaves];
     const int b = blockIdx.x;
-    const float *p = inp + (size_t)b * n * 3;
+    const float *p = inp + (size_t)b * (S.in_bstride ? S.in_bstride : (long)n * 3);
     int *o = out + (size_t)b * out_stride;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
 
@@ -102,6 +124,7 @@ __global__ __launch_bounds__(kBlock) void fps3_reg_kernel(int n, int m, const fl
         ox = wp.x; oy = wp.y; oz = wp.z;
         if (t == 0) o[it] = __float_as_int(wp.w) + idx_off;
     }
+    write_centres(S, p, o, m, idx_off, b, t, kBlock);
 }
 
 // ---- FPS on a precomputed [n,n] distance matrix (F-FPS), n <= 1024*PPT ------------------------
@@ -109,7 +132,7 @@ template <int PPT>
 __global__ __launch_bounds__(kBlock) void fpsdist_reg_kernel(int n, int m,
                                                              const float *__restrict__ dist,
                                                              int *__restrict__ out, int out_stride,
-                                                             int idx_off) {
+                                                             int idx_off, FpsSide S) {
     __shared__ float s_val[2][kWaves];
     __shared__ float4 s_pt[2][kWaves];
     const int b = blockIdx.x;
@@ -154,6 +177,7 @@ __global__ __launch_bounds__(kBlock) void fpsdist_reg_kernel(int n, int m,
         old = __builtin_amdgcn_readfirstlane(__float_as_int(wp.w));
         if (t == 0) o[it] = old + idx_off;
     }
+    if (S.xyz) write_centres(S, S.xyz + (size_t)b * S.xyz_bstride, o, m, idx_off, b, t, kBlock);
 }
 
 // ---- generic fallback: any c, any n; running min-distance in global `temp` like the reference --
@@ -390,28 +414,36 @@ int ppt_for(int n) {
 
 // Internal launchers with an output row stride / index offset so that an SA layer can write the
 // F-FPS and D-FPS halves straight into one [b, npoint_total] index tensor (layers_util.py:96-108).
-extern "C" int sa_fps_bucket_ex(int b, int n, int m, const float *inp, int *out, int out_stride, int idx_off,
-                                hipStream_t stream);
+extern "C" int sa_fps_bucket_ex2(int b, int n, int m, const float *inp, long in_bstride, int *out, int out_stride,
+                                 int idx_off, float *ctr, long ctr_bstride, hipStream_t stream);
 
 extern "C" int sa_fps_coop_ex(int b, int n, int c, int m, const float *inp, float *temp, int *out, int out_stride,
                               int idx_off, hipStream_t stream);
 
-extern "C" int sa_fps_ex(int b, int n, int c, int m, const float *inp, float *temp, int *out,
-                         int out_stride, int idx_off, hipStream_t stream) {
+// in_bstride: elements between frames of inp (0 = dense n*c); ctr / ctr_bstride: when ctr is non-null the picked rows
+// (c == 3) are also written to ctr + frame * ctr_bstride + 3 * i -- the gather_point of layers_util.py:116-119.
+// Both extras need the register-resident c == 3 kernels (n <= 16384): SA_ERR_UNSUPPORTED otherwise, the caller then
+// slices / gathers with separate launches.
+extern "C" int sa_fps_ex2(int b, int n, int c, int m, const float *inp, long in_bstride, float *temp, int *out,
+                          int out_stride, int idx_off, float *ctr, long ctr_bstride, hipStream_t stream) {
     if (b <= 0 || n <= 0 || c <= 0 || m <= 0 || !inp || !out || out_stride < m) return SA_ERR_INVALID;
+    const bool extras = (in_bstride != 0 && in_bstride != (long)n * c) || ctr != nullptr;
     // Layer-1 shape: the wave-bucket culled kernel (fps_bucket.hip), bit-identical output, ~1.4x faster than the
     // plain kernel at 16384 -> 4096.  SA_FPS_BUCKET_MIN_N = smallest n it is used for (0 = never).
     static const int bucket_min_n = getenv("SA_FPS_BUCKET_MIN_N") ? atoi(getenv("SA_FPS_BUCKET_MIN_N")) : 8192;
     if (c == 3 && bucket_min_n > 0 && n >= bucket_min_n && n <= 16384 && m >= 64)
-        return sa_fps_bucket_ex(b, n, m, inp, out, out_stride, idx_off, stream);
+        return sa_fps_bucket_ex2(b, n, m, inp, in_bstride, out, out_stride, idx_off, ctr, ctr_bstride, stream);
     const int ppt = ppt_for(n);
     if (c == 3 && ppt <= 16) {
+        FpsSide S{};
+        S.in_bstride = in_bstride; S.ctr = ctr; S.ctr_bstride = ctr_bstride;
         switch (ppt) {
-#define SA_FPS3(P) case P: hipLaunchKernelGGL(fps3_reg_kernel<P>, dim3(b), dim3(kBlock), 0, stream, n, m, inp, out, out_stride, idx_off); break;
+#define SA_FPS3(P) case P: hipLaunchKernelGGL(fps3_reg_kernel<P>, dim3(b), dim3(kBlock), 0, stream, n, m, inp, out, out_stride, idx_off, S); break;
             SA_FPS3(1) SA_FPS3(2) SA_FPS3(4) SA_FPS3(8) SA_FPS3(16)
 #undef SA_FPS3
         }
     } else {
+        if (extras) return SA_ERR_UNSUPPORTED;
         if (!temp) return SA_ERR_INVALID;
         // frames too large for one CU's registers/LDS: several cooperating workgroups per frame (fps_coop.hip)
         const int rc = sa_fps_coop_ex(b, n, c, m, inp, temp, out, out_stride, idx_off, stream);
@@ -424,23 +456,44 @@ extern "C" int sa_fps_ex(int b, int n, int c, int m, const float *inp, float *te
     return SA_OK;
 }
 
-extern "C" int sa_fps_with_distance_ex(int b, int n, int m, const float *dist, float *temp, int *out,
-                                       int out_stride, int idx_off, hipStream_t stream) {
-    if (b <= 0 || n <= 0 || m <= 0 || !dist || !out || out_stride < m) return SA_ERR_INVALID;
+extern "C" int sa_fps_ex(int b, int n, int c, int m, const float *inp, float *temp, int *out,
+                         int out_stride, int idx_off, hipStream_t stream) {
+    return sa_fps_ex2(b, n, c, m, inp, 0, temp, out, out_stride, idx_off, nullptr, 0, stream);
+}
+
+extern "C" int sa_fps_bucket_ex(int b, int n, int m, const float *inp, int *out, int out_stride, int idx_off,
+                                hipStream_t stream) {
+    return sa_fps_bucket_ex2(b, n, m, inp, 0, out, out_stride, idx_off, nullptr, 0, stream);
+}
+
+// xyz / xyz_bstride / ctr / ctr_bstride: when ctr is non-null, rows xyz[frame][pick] (3 floats, frames xyz_bstride
+// floats apart) are written to ctr + frame * ctr_bstride + 3 * i (register-resident kernel only, n <= 16384).
+extern "C" int sa_fps_with_distance_ex2(int b, int n, int m, const float *dist, float *temp, int *out,
+                                        int out_stride, int idx_off, const float *xyz, long xyz_bstride, float *ctr,
+                                        long ctr_bstride, hipStream_t stream) {
+    if (b <= 0 || n <= 0 || m <= 0 || !dist || !out || out_stride < m || (ctr && !xyz)) return SA_ERR_INVALID;
     const int ppt = ppt_for(n);
     if (ppt <= 16) {
+        FpsSide S{};
+        S.ctr = ctr; S.ctr_bstride = ctr_bstride; S.xyz = ctr ? xyz : nullptr; S.xyz_bstride = xyz_bstride;
         switch (ppt) {
-#define SA_FPSD(P) case P: hipLaunchKernelGGL(fpsdist_reg_kernel<P>, dim3(b), dim3(kBlock), 0, stream, n, m, dist, out, out_stride, idx_off); break;
+#define SA_FPSD(P) case P: hipLaunchKernelGGL(fpsdist_reg_kernel<P>, dim3(b), dim3(kBlock), 0, stream, n, m, dist, out, out_stride, idx_off, S); break;
             SA_FPSD(1) SA_FPSD(2) SA_FPSD(4) SA_FPSD(8) SA_FPSD(16)
 #undef SA_FPSD
         }
     } else {
+        if (ctr) return SA_ERR_UNSUPPORTED;
         if (!temp) return SA_ERR_INVALID;
         hipLaunchKernelGGL(fps_generic_kernel<1>, dim3(b), dim3(kBlock), 0, stream, n, 0, m, dist, temp,
                            out, out_stride, idx_off);
     }
     SA_CHECK_LAUNCH();
     return SA_OK;
+}
+
+extern "C" int sa_fps_with_distance_ex(int b, int n, int m, const float *dist, float *temp, int *out,
+                                       int out_stride, int idx_off, hipStream_t stream) {
+    return sa_fps_with_distance_ex2(b, n, m, dist, temp, out, out_stride, idx_off, nullptr, 0, nullptr, 0, stream);
 }
 
 // Force the generic (global-temp) kernels: used by tests to cover the n > 16384 path at small n.

@@ -68,15 +68,15 @@ struct Table {
 };
 
 __global__ __launch_bounds__(kT) void fps3_wave_bucket_kernel(int n, int m, const float *__restrict__ inp,
-                                                             int *__restrict__ out, int out_stride,
-                                                             int idx_off) {
+                                                             long in_bstride, int *__restrict__ out, int out_stride,
+                                                             int idx_off, float *__restrict__ ctr, long ctr_bstride) {
     __shared__ unsigned s_sorted[kCap];          // (morton << 14) | original index, ascending; 64 KiB;
 
     __shared__ float s_red[4][kW];
     __shared__ float s_box[6][kNB];
     __shared__ Table s_tbl;
     const int bidx = blockIdx.x;
-    const float *p = inp + (size_t)bidx * n * 3;
+    const float *p = inp + (size_t)bidx * (in_bstride ? in_bstride : (long)n * 3);
     int *o = out + (size_t)bidx * out_stride;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -269,6 +269,14 @@ __global__ __launch_bounds__(kT) void fps3_wave_bucket_kernel(int n, int m, cons
         if (tid == 0) o[it] = (int)tie_key_index((unsigned)__builtin_amdgcn_readlane((int)key, bl)) + idx_off;
         FP_T(4)
     }
+    if (ctr) {                                       // the picked points themselves (gather_point fused, layers_util.py:116-119)
+        __syncthreads();
+        float *cq = ctr + (size_t)bidx * ctr_bstride;
+        for (int i = tid; i < m; i += kT) {
+            const int k = o[i] - idx_off;
+            cq[i * 3 + 0] = p[k * 3 + 0]; cq[i * 3 + 1] = p[k * 3 + 1]; cq[i * 3 + 2] = p[k * 3 + 2];
+        }
+    }
 #ifdef SA_FPSB_PROF
     if (bidx == 0 && lane == 0) {
         if (w == 0) { for (int i = 0; i < 5; ++i) g_fpsb_prof[i] = pacc[i]; g_fpsb_prof[5] = pact; }
@@ -280,12 +288,12 @@ __global__ __launch_bounds__(kT) void fps3_wave_bucket_kernel(int n, int m, cons
 
 }  // namespace
 
-// D-FPS on coordinates with wave-bucket culling; same contract as sa_fps_ex with c == 3, n <= 16384.
-extern "C" int sa_fps_bucket_ex(int b, int n, int m, const float *inp, int *out, int out_stride, int idx_off,
-                                hipStream_t stream) {
+// D-FPS on coordinates with wave-bucket culling; same contract as sa_fps_ex2 with c == 3, n <= 16384.
+extern "C" int sa_fps_bucket_ex2(int b, int n, int m, const float *inp, long in_bstride, int *out, int out_stride,
+                                 int idx_off, float *ctr, long ctr_bstride, hipStream_t stream) {
     if (b <= 0 || n <= 0 || n > kCap || m <= 0 || !inp || !out || out_stride < m) return SA_ERR_INVALID;
-    hipLaunchKernelGGL(fps3_wave_bucket_kernel, dim3(b), dim3(kT), 0, stream, n, m, inp, out, out_stride,
-                       idx_off);
+    hipLaunchKernelGGL(fps3_wave_bucket_kernel, dim3(b), dim3(kT), 0, stream, n, m, inp, in_bstride, out, out_stride,
+                       idx_off, ctr, ctr_bstride);
     SA_CHECK_LAUNCH();
     return SA_OK;
 }

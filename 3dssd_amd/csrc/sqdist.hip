@@ -26,6 +26,8 @@ constexpr int kLd = 68;   // padded leading dimension of a k-major stage row
 struct RowSrc {
     const float *p0; int c0;   // first piece  [rows, c0]
     const float *p1; int c1;   // second piece [rows, c1] (may be null, c1 = 0)
+    int rs0 = 0, rs1 = 0;      // rows between consecutive frames of each piece (0: dense, the frame's own row count);
+                               // honoured by the pack kernel only: a range slice of a larger tensor is read in place
 };
 
 __device__ __forceinline__ float load_ch(const RowSrc &s, long row, int ch) {
@@ -498,9 +500,10 @@ __global__ __launch_bounds__(2 * kMT) void sqdist_pack_kernel(int n, int np, int
 #pragma unroll
             for (int u = 0; u < 32; ++u) {
                 const int row = t * kMT + r0 + u;
-                const long grow = (long)b * n + (row < n ? row : n - 1);
-                const float x0 = A.p0[grow * A.c0 + k0];
-                const float x1 = A.c1 > 0 ? A.p1[grow * A.c1 + k1] : 0.0f;
+                const int rr = row < n ? row : n - 1;
+                const long grow0 = (long)b * (A.rs0 ? A.rs0 : n) + rr, grow1 = (long)b * (A.rs1 ? A.rs1 : n) + rr;
+                const float x0 = A.p0[grow0 * A.c0 + k0];
+                const float x1 = A.c1 > 0 ? A.p1[grow1 * A.c1 + k1] : 0.0f;
                 x[u] = row < n ? (first ? x0 : x1) : 0.0f;
             }
 #pragma unroll
@@ -683,24 +686,37 @@ extern "C" size_t sa_calc_square_dist_ws_bytes(int b, int n, int m, int c, int s
 
 // sa_calc_square_dist_split with caller-owned scratch of sa_calc_square_dist_ws_bytes(b, n, m, c0 + c1, a == bb)
 // bytes: the packed form (one pre-pass per operand, then plain-copy staging).  Same result, bit for bit.
-extern "C" int sa_calc_square_dist_split_ws(int b, int n, int m, int c0, int c1, const float *a0, const float *a1,
-                                            const float *b0, const float *b1, float *out, void *workspace,
-                                            hipStream_t stream) {
+// The symmetric F-FPS case on a range slice: a0 / a1 are frames rs0 / rs1 ROWS apart (0 = n: dense).  Only the
+// packed form reads strided sources; when it cannot run, SA_ERR_UNSUPPORTED (the caller copies the slice).
+extern "C" int sa_calc_square_dist_self_ws(int b, int n, int c0, int c1, const float *a0, int rs0, const float *a1,
+                                           int rs1, float *out, void *workspace, hipStream_t stream);
+
+static int sqdist_split_ws_impl(int b, int n, int m, int c0, int c1, const float *a0, const float *a1,
+                                const float *b0, const float *b1, float *out, void *workspace, int rs0, int rs1,
+                                hipStream_t stream) {
     if (b <= 0 || n <= 0 || m <= 0 || c0 <= 0 || c1 < 0 || !a0 || !b0 || !out) return SA_ERR_INVALID;
     if (c1 > 0 && (!a1 || !b1)) return SA_ERR_INVALID;
+    const bool strided = (rs0 != 0 && rs0 != n) || (rs1 != 0 && rs1 != n);
     static const bool packed_on = !(getenv("SA_SQDIST_PACKED") && atoi(getenv("SA_SQDIST_PACKED")) == 0);
     const long big = (long)kMT * (m > n ? m : n) + kMT;
-    if (!workspace || !packed_on || big >= (1l << 31) || ((uintptr_t)workspace % 16) != 0 || b > 65535)
+    if (!workspace || !packed_on || big >= (1l << 31) || ((uintptr_t)workspace % 16) != 0 || b > 65535) {
+        if (strided) return SA_ERR_UNSUPPORTED;
         return sa_calc_square_dist_split(b, n, m, c0, c1, a0, a1, b0, b1, out, stream);
+    }
     const bool sym = n == m && a0 == b0 && a1 == b1;
     const int c = c0 + c1, S = (c + kKS2 - 1) / kKS2;
     const int npa = (n + kMT - 1) / kMT * kMT, npb = (m + kMT - 1) / kMT * kMT;
     float *packA = (float *)workspace, *normA = packA + (size_t)b * S * (npa / kMT) * kPackTile;
     float *packB = packA, *normB = normA;
     RowSrc A{a0, c0, a1, c1}, Bm{b0, c0, b1, c1};
+    A.rs0 = rs0; A.rs1 = rs1;
+    if (sym) { Bm.rs0 = rs0; Bm.rs1 = rs1; }
     const int ldc = c | 1;
     const size_t pack_lds = (size_t)kMT * ldc * sizeof(float);
-    if (pack_lds > 150 * 1024) return sa_calc_square_dist_split(b, n, m, c0, c1, a0, a1, b0, b1, out, stream);
+    if (pack_lds > 150 * 1024) {
+        if (strided) return SA_ERR_UNSUPPORTED;
+        return sa_calc_square_dist_split(b, n, m, c0, c1, a0, a1, b0, b1, out, stream);
+    }
     if (pack_lds > 48 * 1024) {
         (void)hipFuncSetAttribute((const void *)sqdist_pack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pack_lds);
         (void)hipGetLastError();
@@ -726,6 +742,16 @@ extern "C" int sa_calc_square_dist_split_ws(int b, int n, int m, int c0, int c1,
     }
     SA_CHECK_LAUNCH();
     return SA_OK;
+}
+
+extern "C" int sa_calc_square_dist_split_ws(int b, int n, int m, int c0, int c1, const float *a0, const float *a1,
+                                            const float *b0, const float *b1, float *out, void *workspace,
+                                            hipStream_t stream) {
+    return sqdist_split_ws_impl(b, n, m, c0, c1, a0, a1, b0, b1, out, workspace, 0, 0, stream);
+}
+extern "C" int sa_calc_square_dist_self_ws(int b, int n, int c0, int c1, const float *a0, int rs0, const float *a1,
+                                           int rs1, float *out, void *workspace, hipStream_t stream) {
+    return sqdist_split_ws_impl(b, n, n, c0, c1, a0, a1, a0, a1, out, workspace, rs0, rs1, stream);
 }
 
 // model_util.calc_square_dist(a, b, norm=False): a [bs,n,c], bb [bs,m,c] -> [bs,n,m].

@@ -23,6 +23,10 @@ SIGNATURES = {
     "sa_calc_square_dist": [_c_int] * 4 + [_vp, _vp, _vp, _vp],
     "sa_fps_ex": [_c_int] * 4 + [_vp, _vp, _vp, _c_int, _c_int, _vp],
     "sa_fps_with_distance_ex": [_c_int] * 3 + [_vp, _vp, _vp, _c_int, _c_int, _vp],
+    "sa_fps_ex2": [_c_int] * 4 + [_vp, _c_long, _vp, _vp, _c_int, _c_int, _vp, _c_long, _vp],
+    "sa_fps_bucket_ex2": [_c_int] * 3 + [_vp, _c_long, _vp, _c_int, _c_int, _vp, _c_long, _vp],
+    "sa_fps_with_distance_ex2": [_c_int] * 3 + [_vp, _vp, _vp, _c_int, _c_int, _vp, _c_long, _vp, _c_long, _vp],
+    "sa_calc_square_dist_self_ws": [_c_int] * 4 + [_vp, _c_int, _vp, _c_int, _vp, _vp, _vp],
     "sa_fps_bucket_ex": [_c_int] * 3 + [_vp, _vp, _c_int, _c_int, _vp],
     "sa_fps_generic": [_c_int] * 4 + [_vp, _vp, _vp, _c_int, _vp],
     "sa_calc_square_dist_split": [_c_int] * 5 + [_vp, _vp, _vp, _vp, _vp, _vp],

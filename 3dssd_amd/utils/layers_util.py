@@ -73,30 +73,55 @@ def vote_layer(xyz, points, mlp_list, is_training, bn_decay, bn, scope, variable
     return out, points, ctr_offsets
 
 
-def _ffps_into(npoint, tmp_xyz, tmp_points, out, col, idx_off):
-    """F-FPS: calc_square_dist(concat([xyz, feat])) + farthest_point_sample_with_distance
-    (layers_util.py:94-96,102-104), written into out[:, col:col+npoint] with idx_off added."""
-    b, n, _ = tmp_xyz.shape
-    c1 = tmp_points.shape[2]
-    dist = torch.empty((b, n, n), dtype=torch.float32, device=tmp_xyz.device)
+_UNSUPPORTED = -3
+
+
+def _ffps_into(npoint, xyz, points, start, end, out, col, ctr):
+    """F-FPS on rows [start, end) of every frame: calc_square_dist(concat([xyz, feat])) +
+    farthest_point_sample_with_distance (layers_util.py:94-96,102-104), written into out[:, col:col+npoint] with
+    `start` added.  The range is read in place (no slice copy) and, when ctr = (tensor [b, total, 3]) is given, the
+    picked points go straight into ctr[:, col:col+npoint] (the gather_point of :116-119).  Returns True when the
+    centres were written."""
+    b, n_all, _ = xyz.shape
+    n = end - start
+    c1 = points.shape[2]
+    dev = xyz.device
+    dist = torch.empty((b, n, n), dtype=torch.float32, device=dev)
     lib = N.lib()
+    xp = xyz.data_ptr() + 4 * 3 * start
+    pp = points.data_ptr() + 4 * c1 * start
     # packed form: the operand is laid out once in the matrix kernel's LDS image, tiles are staged by plain copies
-    ws = torch.empty((lib.sa_calc_square_dist_ws_bytes(b, n, n, 3 + c1, 1) + 3) // 4, dtype=torch.float32,
-                     device=tmp_xyz.device)
-    st = 0 if "sqdist" in _ABLATE else lib.sa_calc_square_dist_split_ws(
-        b, n, n, 3, c1, tmp_xyz.data_ptr(), tmp_points.data_ptr(), tmp_xyz.data_ptr(), tmp_points.data_ptr(),
-        dist.data_ptr(), ws.data_ptr(), N.current_stream())
-    N.check(st, "calc_square_dist")
-    temp = torch.empty((b, n), dtype=torch.float32, device=dist.device) if n > 16384 else None
+    ws = torch.empty((lib.sa_calc_square_dist_ws_bytes(b, n, n, 3 + c1, 1) + 3) // 4, dtype=torch.float32, device=dev)
+    keep = None
+    if "sqdist" not in _ABLATE:
+        st = lib.sa_calc_square_dist_self_ws(b, n, 3, c1, xp, n_all, pp, n_all, dist.data_ptr(), ws.data_ptr(),
+                                             N.current_stream())
+        if st == _UNSUPPORTED:                      # strided sources need the packed form: copy the slice instead
+            keep = (xyz[:, start:end].contiguous(), points[:, start:end].contiguous())
+            st = lib.sa_calc_square_dist_split_ws(b, n, n, 3, c1, keep[0].data_ptr(), keep[1].data_ptr(),
+                                                  keep[0].data_ptr(), keep[1].data_ptr(), dist.data_ptr(),
+                                                  ws.data_ptr(), N.current_stream())
+        N.check(st, "calc_square_dist")
+    temp = torch.empty((b, n), dtype=torch.float32, device=dev) if n > 16384 else None
+    done = [False]
 
     def chain():
         if "fpsdist" in _ABLATE:
             return
-        st = lib.sa_fps_with_distance_ex(b, n, npoint, dist.data_ptr(),
-                                         temp.data_ptr() if temp is not None else None,
-                                         out.data_ptr() + 4 * col, out.shape[1], idx_off, N.current_stream())
+        tp = temp.data_ptr() if temp is not None else None
+        if ctr is not None:
+            st = lib.sa_fps_with_distance_ex2(b, n, npoint, dist.data_ptr(), tp, out.data_ptr() + 4 * col, out.shape[1],
+                                              start, xp, 3 * n_all, ctr.data_ptr() + 4 * 3 * col, 3 * ctr.shape[1],
+                                              N.current_stream())
+            if st != _UNSUPPORTED:
+                N.check(st, "farthest_point_sample_with_distance")
+                done[0] = True
+                return
+        st = lib.sa_fps_with_distance_ex(b, n, npoint, dist.data_ptr(), tp, out.data_ptr() + 4 * col, out.shape[1],
+                                         start, N.current_stream())
         N.check(st, "farthest_point_sample_with_distance")
     _run_chain(chain)
+    return done[0]
 
 
 def _run_chain(fn):
@@ -137,17 +162,35 @@ def _side_stream(main, which=0):
     return _SIDE_STREAMS[key]
 
 
-def _dfps_into(npoint, tmp_xyz, out, col, idx_off):
-    b, n, c = tmp_xyz.shape
-    temp = torch.empty((b, n), dtype=torch.float32, device=tmp_xyz.device) if (c != 3 or n > 16384) else None
+def _dfps_into(npoint, xyz, start, end, out, col, ctr):
+    """D-FPS on rows [start, end) of every frame (layers_util.py:97,106), read in place; indices (+ start) into
+    out[:, col:col+npoint], the picked points into ctr[:, col:col+npoint] when given.  Returns True when the centres
+    were written."""
+    b, n_all, c = xyz.shape
+    n = end - start
+    dev = xyz.device
+    done = [False]
 
     def chain():
         if ("dfps:%d" % n) in _ABLATE:
             return
-        st = N.lib().sa_fps_ex(b, n, c, npoint, tmp_xyz.data_ptr(), temp.data_ptr() if temp is not None else None,
-                               out.data_ptr() + 4 * col, out.shape[1], idx_off, N.current_stream())
+        lib = N.lib()
+        xp = xyz.data_ptr() + 4 * c * start
+        st = lib.sa_fps_ex2(b, n, c, npoint, xp, c * n_all, None, out.data_ptr() + 4 * col, out.shape[1], start,
+                            ctr.data_ptr() + 4 * 3 * col if ctr is not None else None,
+                            3 * ctr.shape[1] if ctr is not None else 0, N.current_stream())
+        if st != _UNSUPPORTED:
+            N.check(st, "farthest_point_sample")
+            done[0] = ctr is not None
+            return
+        # frames that do not fit the register-resident kernels: dense copy of the range, scratch, separate gather
+        src = xyz if (start == 0 and end == n_all) else xyz[:, start:end].contiguous()
+        temp = torch.empty((b, n), dtype=torch.float32, device=dev)
+        st = lib.sa_fps_ex(b, n, c, npoint, src.data_ptr(), temp.data_ptr(), out.data_ptr() + 4 * col, out.shape[1],
+                           start, N.current_stream())
         N.check(st, "farthest_point_sample")
     _run_chain(chain)
+    return done[0]
 
 
 def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_training, bn_decay, bn,
@@ -198,42 +241,47 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
     has_d = any(k in ("FS", "D-FPS") for k, _s, _e, _c in plan)
     main = torch.cuda.current_stream()
     side = _side_stream(main) if (has_f and has_d and DFPS_SIDE_STREAM in (1, 2)) else None
-    # Pass 1 (main stream): the range slices every sampler reads.  Then ONE fork: the D-FPS halves go to the side
-    # stream BEFORE the F-FPS chains (distance matrix + matrix FPS) are enqueued on the main stream, so the two
-    # serial chains of a layer really run side by side (each keeps one CU per frame busy).
+    # The samplers read their range of xyz / points in place (frame stride = the whole tensor's) and write the picked
+    # points themselves: no slice copies, no separate gather_point launch (:116-119) -- each launch of a step costs
+    # 25-50 us of its span when 16 steps are in flight (tools/dispatch_chain.py).
+    ctr_src = T.f32_cuda(vote_ctr, "vote_ctr") if vote_ctr is not None else xyz
+    fuse_ctr = (vote_ctr is None and former_n == 0 and not only_identity and xyz.shape[2] == 3)
+    new_xyz = torch.empty((bs, total, 3), dtype=torch.float32, device=dev) if fuse_ctr else None
+    centres_ok = fuse_ctr
     work = []
     for kind, start, end, cnt in plan_iter:
         if kind == "identity":
             fps_idx[:, col:col + cnt] = torch.arange(start, start + cnt, dtype=torch.int32, device=dev)[None]
+            if fuse_ctr:
+                new_xyz[:, col:col + cnt] = xyz[:, start:start + cnt]
         else:
-            whole = (start == 0 and end == n_all)
-            tmp_xyz = xyz if whole else xyz[:, start:end].contiguous()
-            tmp_points = None
-            if kind in ("FS", "F-FPS"):
-                tmp_points = points if whole else points[:, start:end].contiguous()
-            work.append((kind, start, cnt, col, tmp_xyz, tmp_points))
+            work.append((kind, start, end, cnt, col))
         col += cnt
-    if DFPS_SIDE_STREAM in (2, 3):
-        for kind, start, cnt, c0, tmp_xyz, tmp_points in work:
+
+    def ffps_all():
+        ok = True
+        for kind, start, end, cnt, c0 in work:
             if kind in ("FS", "F-FPS"):
-                _ffps_into(cnt // 2 if kind == "FS" else cnt, tmp_xyz, tmp_points, fps_idx, c0, start)
+                ok = _ffps_into(cnt // 2 if kind == "FS" else cnt, xyz, points, start, end, fps_idx, c0, new_xyz) and ok
+        return ok
+
+    if DFPS_SIDE_STREAM in (2, 3):
+        centres_ok = ffps_all() and centres_ok
     if side is not None:
         ev = torch.cuda.Event()
         ev.record(main)
         side.wait_event(ev)
-    for kind, start, cnt, c0, tmp_xyz, tmp_points in work:                  # D-FPS parts (:97,106)
+    for kind, start, end, cnt, c0 in work:                                  # D-FPS parts (:97,106)
         if kind in ("FS", "D-FPS"):
             d_n = cnt // 2 if kind == "FS" else cnt
             d_col = c0 + d_n if kind == "FS" else c0                        # 'FS': [F-FPS idx || D-FPS idx] (:96-98)
             if side is not None:
                 with torch.cuda.stream(side):
-                    _dfps_into(d_n, tmp_xyz, fps_idx, d_col, start)
+                    centres_ok = _dfps_into(d_n, xyz, start, end, fps_idx, d_col, new_xyz) and centres_ok
             else:
-                _dfps_into(d_n, tmp_xyz, fps_idx, d_col, start)
-    for kind, start, cnt, c0, tmp_xyz, tmp_points in work:                  # F-FPS parts (:94-96,102-104)
-        if kind in ("FS", "F-FPS") and DFPS_SIDE_STREAM not in (2, 3):
-            npt = cnt // 2 if kind == "FS" else cnt
-            _ffps_into(npt, tmp_xyz, tmp_points, fps_idx, c0, start)
+                centres_ok = _dfps_into(d_n, xyz, start, end, fps_idx, d_col, new_xyz) and centres_ok
+    if DFPS_SIDE_STREAM not in (2, 3):                                      # F-FPS parts (:94-96,102-104)
+        centres_ok = ffps_all() and centres_ok
     if side is not None:
         ev = torch.cuda.Event()
         ev.record(side)
@@ -241,8 +289,9 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
     if former_fps_idx is not None:                                          # :112-113
         fps_idx[:, col:] = T.i32_cuda(former_fps_idx, "former_fps_idx")
 
-    ctr_src = T.f32_cuda(vote_ctr, "vote_ctr") if vote_ctr is not None else xyz
-    if only_identity and plan[0][1] == 0 and plan[0][3] == ctr_src.shape[1]:
+    if centres_ok:
+        pass                                                                # written by the samplers
+    elif only_identity and plan[0][1] == 0 and plan[0][3] == ctr_src.shape[1]:
         new_xyz = ctr_src                                                   # gather with the identity: the tensor itself
     else:
         new_xyz = gather_point(ctr_src, fps_idx)                            # :116-119

@@ -68,12 +68,15 @@ class TimingProxy:
 def _algorithmic(name, a):
     """(flops, bytes, label) of one C-ABI call from its scalar arguments (SURVEY.md 8d conventions:
     inputs read once, outputs written once)."""
-    if name in ("sa_fps_ex", "sa_farthest_point_sample"):
+    if name in ("sa_fps_ex", "sa_fps_ex2", "sa_farthest_point_sample"):
         b, n, c, m = a[0:4]
         return (3 * c + 2) * b * (m - 1) * n, b * (n * c * 4 + m * 4), "fps n=%d->%d c=%d" % (n, m, c)
-    if name == "sa_fps_with_distance_ex":
+    if name in ("sa_fps_with_distance_ex", "sa_fps_with_distance_ex2"):
         b, n, m = a[0:3]
         return 2 * b * (m - 1) * n, b * ((m - 1) * n * 4 + m * 4), "fps_with_distance n=%d->%d" % (n, m)
+    if name == "sa_calc_square_dist_self_ws":
+        b, n, c0, c1 = a[0:4]
+        return 2 * b * n * n * (c0 + c1), b * (n * n * 4 + 2 * n * (c0 + c1) * 4), "calc_square_dist n=%d c=%d" % (n, c0 + c1)
     if name in ("sa_calc_square_dist_split", "sa_calc_square_dist_split_ws"):
         b, n, m, c0, c1 = a[0:5]
         return 2 * b * n * m * (c0 + c1), b * (n * m * 4 + (n + m) * (c0 + c1) * 4), "calc_square_dist n=%d c=%d" % (n, c0 + c1)
@@ -154,7 +157,7 @@ def _pmc_traffic(stage):
         return None
     label = stage["label"]
     name = None
-    if stage["kernel"] == "sa_fps_ex" and " c=3" in label:
+    if stage["kernel"] in ("sa_fps_ex", "sa_fps_ex2") and " c=3" in label:
         n = int(label.split("n=")[1].split("->")[0])
         ppt = 1
         while ppt * 1024 < n:
@@ -162,7 +165,7 @@ def _pmc_traffic(stage):
         name = "fps3_reg_kernel<%d>" % ppt
         if 8192 <= n <= 16384 and int(os.environ.get("SA_FPS_BUCKET_MIN_N", "8192")) > 0:
             name = "fps3_wave_bucket_kernel"          # the culled kernel takes the layer-1 shape (fps.hip dispatch)
-    elif stage["kernel"] == "sa_fps_with_distance_ex":
+    elif stage["kernel"] in ("sa_fps_with_distance_ex", "sa_fps_with_distance_ex2"):
         n = int(label.split("n=")[1].split("->")[0])
         ppt = 1
         while ppt * 1024 < n:
@@ -195,7 +198,7 @@ def _pmc_mlp_util():
 
 def roofline_of(stage, frames):
     k = stage["kernel"]
-    if k in ("sa_group_mlp_max", "sa_dense", "sa_calc_square_dist_split", "sa_calc_square_dist_split_ws"):
+    if k in ("sa_group_mlp_max", "sa_dense", "sa_calc_square_dist_split", "sa_calc_square_dist_split_ws", "sa_calc_square_dist_self_ws"):
         peak = MFMA_BF16_PEAK_TF if not k.startswith("sa_calc_square_dist") else VALU_F32_PEAK_TF
         a = stage.get("tflops", 0.0)
         return dict(kernel=stage["label"], bound="mfma", achieved=a, peak=peak, unit="TFLOP/s",

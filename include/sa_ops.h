@@ -76,6 +76,19 @@ int sa_fps_with_distance_ex(int b, int n, int m, const float *dist, float *temp,
  * for large frames (3dssd_amd/csrc/fps_bucket.hip). */
 int sa_fps_bucket_ex(int b, int n, int m, const float *inp, int *out, int out_stride, int idx_off,
                      sa_stream_t stream);
+/* The samplers with two fused neighbours of theirs in pointnet_sa_module_msg (layers_util.py:84-119), each one launch
+ * less per layer: in_bstride = elements between consecutive frames of inp (0 = dense), so a range slice xyz[:, s:e] of
+ * a larger tensor is sampled in place (tf.slice, layers_util.py:85-86); ctr != NULL additionally receives the picked
+ * points, frame f pick i at ctr + f * ctr_bstride + 3 * i (the gather_point of layers_util.py:116-119; the matrix
+ * sampler reads them from xyz, frames xyz_bstride floats apart).  Register-resident kernels only (c == 3 and
+ * n <= 16384 / n <= 16384): SA_ERR_UNSUPPORTED otherwise. */
+int sa_fps_ex2(int b, int n, int c, int m, const float *inp, long in_bstride, float *temp, int *out, int out_stride,
+               int idx_off, float *ctr, long ctr_bstride, sa_stream_t stream);
+int sa_fps_bucket_ex2(int b, int n, int m, const float *inp, long in_bstride, int *out, int out_stride, int idx_off,
+                      float *ctr, long ctr_bstride, sa_stream_t stream);
+int sa_fps_with_distance_ex2(int b, int n, int m, const float *dist, float *temp, int *out, int out_stride,
+                             int idx_off, const float *xyz, long xyz_bstride, float *ctr, long ctr_bstride,
+                             sa_stream_t stream);
 /* Forces the global-scratch kernels (mode 0: points [b,n,c], mode 1: matrix [b,n,n]); test hook. */
 int sa_fps_generic(int b, int n, int c, int m, const float *inp, float *temp, int *out, int mode,
                    sa_stream_t stream);
@@ -91,6 +104,10 @@ int sa_calc_square_dist_split(int b, int n, int m, int c0, int c1, const float *
 unsigned long sa_calc_square_dist_ws_bytes(int b, int n, int m, int c, int symmetric);
 int sa_calc_square_dist_split_ws(int b, int n, int m, int c0, int c1, const float *a0, const float *a1,
                                  const float *b0, const float *b1, float *out, void *workspace, sa_stream_t stream);
+/* The symmetric F-FPS case (a == b) on a range slice read in place: frames of a0 / a1 are rs0 / rs1 ROWS apart
+ * (0 = n).  Packed form only: SA_ERR_UNSUPPORTED when it cannot run (no workspace, very wide rows). */
+int sa_calc_square_dist_self_ws(int b, int n, int c0, int c1, const float *a0, int rs0, const float *a1, int rs1,
+                                float *out, void *workspace, sa_stream_t stream);
 
 /* All radius bands of one SA layer in one pass (layers_util.py:134-147).  rmin/rmax/ns: host arrays of
  * nbands entries; idx/cnt: host arrays of nbands device pointers.  dilated=0 ignores rmin. */

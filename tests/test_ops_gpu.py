@@ -38,6 +38,59 @@ def test_fps_matches_oracle(gpu, oracle, b, n, m, dup):
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("n_all,start,end,m", [(1024, 0, 512, 256), (1024, 512, 1024, 256), (5000, 100, 4196, 300),
+                                               (16384, 0, 16384, 512), (20000, 3000, 19384, 200)])
+def test_fps_in_place_range_with_fused_centres(gpu, oracle, n_all, start, end, m):
+    # sa_fps_ex2: a range slice xyz[:, start:end] of a larger tensor sampled in place (frame stride), the picked points
+    # written by the sampler itself, into a column window of a wider centre tensor -- == slice copy + sampler + gather
+    N = pkg("utils._native")
+    rng = np.random.default_rng(n_all + start + m)
+    b, n = 2, end - start
+    p = _cloud(rng, b, n_all, dup=n_all // 10)
+    t = _t(p, gpu)
+    out = torch.full((b, m + 7), -5, dtype=torch.int32, device=gpu)
+    ctr = torch.full((b, m + 9, 3), -7.0, dtype=torch.float32, device=gpu)
+    st = N.lib().sa_fps_ex2(b, n, 3, m, t.data_ptr() + 12 * start, 3 * n_all, None, out.data_ptr() + 4 * 3, m + 7, start,
+                            ctr.data_ptr() + 12 * 4, 3 * (m + 9), N.current_stream())
+    assert st == 0
+    torch.cuda.synchronize()
+    ref = oracle.farthest_point_sample(m, np.ascontiguousarray(p[:, start:end]))
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:, 3:3 + m], ref + start) and (got[:, :3] == -5).all() and (got[:, 3 + m:] == -5).all()
+    c = ctr.cpu().numpy()
+    assert np.array_equal(c[:, 4:4 + m], np.take_along_axis(p[:, start:end], ref[..., None].astype(np.int64), 1))
+    assert (c[:, :4] == -7).all() and (c[:, 4 + m:] == -7).all()
+
+
+def test_ffps_in_place_range_with_fused_centres(gpu, oracle):
+    # sa_calc_square_dist_self_ws on a range slice read in place + sa_fps_with_distance_ex2 writing the picked points
+    N = pkg("utils._native")
+    rng = np.random.default_rng(99)
+    b, n_all, start, end, c1, m = 2, 1024, 0, 512, 128, 256
+    n = end - start
+    xyz = _cloud(rng, b, n_all)
+    feat = rng.normal(0, 1, (b, n_all, c1)).astype(np.float32)
+    tx, tf = _t(xyz, gpu), _t(feat, gpu)
+    lib = N.lib()
+    dist = torch.empty((b, n, n), dtype=torch.float32, device=gpu)
+    ws = torch.empty((lib.sa_calc_square_dist_ws_bytes(b, n, n, 3 + c1, 1) + 3) // 4, dtype=torch.float32, device=gpu)
+    st = lib.sa_calc_square_dist_self_ws(b, n, 3, c1, tx.data_ptr() + 12 * start, n_all, tf.data_ptr() + 4 * c1 * start,
+                                         n_all, dist.data_ptr(), ws.data_ptr(), N.current_stream())
+    assert st == 0
+    f = np.concatenate([xyz[:, start:end], feat[:, start:end]], -1)
+    ref_d = oracle.calc_square_dist(f, f)
+    assert np.array_equal(dist.cpu().numpy(), ref_d)
+    out = torch.empty((b, m), dtype=torch.int32, device=gpu)
+    ctr = torch.empty((b, m, 3), dtype=torch.float32, device=gpu)
+    st = lib.sa_fps_with_distance_ex2(b, n, m, dist.data_ptr(), None, out.data_ptr(), m, start, tx.data_ptr() + 12 * start,
+                                      3 * n_all, ctr.data_ptr(), 3 * m, N.current_stream())
+    assert st == 0
+    torch.cuda.synchronize()
+    ref = oracle.farthest_point_sample_with_distance(m, ref_d)
+    assert np.array_equal(out.cpu().numpy(), ref + start)
+    assert np.array_equal(ctr.cpu().numpy(), np.take_along_axis(xyz[:, start:end], ref[..., None].astype(np.int64), 1))
+
+
 def test_fps_all_points_identical(gpu, oracle):
     # every distance is 0: ties everywhere, the (k mod 1024, k) rule decides every pick
     S = pkg("utils.tf_ops.sampling.tf_sampling")
