@@ -5,6 +5,7 @@ import torch
 
 from .builder.layer_builder import LayerBuilder
 from .utils import layers_util
+from .utils import _native as N
 from .utils.weights import VariableStore
 
 
@@ -20,8 +21,12 @@ class SABackbone:
     def forward(self, point_cloud):
         """point_cloud [B,n,3+C] fp32 on the GPU -> (xyz_list, feature_list, fps_idx_list); the backbone
         output is the last entry of xyz_list / feature_list."""
-        l0_xyz = point_cloud[:, :, 0:3].contiguous()
-        l0_points = point_cloud[:, :, 3:].contiguous()
+        # the two tf.slice of single_stage_detector.py:117-118 in one launch
+        point_cloud = point_cloud.contiguous()
+        bs, n, ch = point_cloud.shape
+        l0_xyz = torch.empty((bs, n, 3), dtype=torch.float32, device=point_cloud.device)
+        l0_points = torch.empty((bs, n, ch - 3), dtype=torch.float32, device=point_cloud.device)
+        N.copy_blocks([(point_cloud[:, :, 0:3], l0_xyz, bs, n, 3), (point_cloud[:, :, 3:], l0_points, bs, n, ch - 3)])
         xyz_list, feature_list, fps_idx_list = [l0_xyz], [l0_points], [None]
         out = {}
         for layer in self.layers:

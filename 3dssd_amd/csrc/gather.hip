@@ -52,6 +52,51 @@ int launch_gather(int b, int n, int c, long rows_per_batch, const float *src, co
 
 }  // namespace
 
+// ---- up to four strided block copies in ONE launch (tf.slice of layers_util.py:85-86 and
+//      single_stage_detector.py:117-118: the [B,n,3+C] input into xyz / features, a prefix range of xyz and points)
+namespace {
+constexpr int kMaxCopyJobs = 4;
+struct CopyJob {
+    const float *src;
+    float *dst;
+    int frames, rows, cols;              // dst[f, r, 0:cols] = src[f, r, 0:cols]
+    long src_fs, src_rs, dst_fs, dst_rs; // frame / row strides in floats
+};
+struct CopyJobs { CopyJob j[kMaxCopyJobs]; };
+__global__ __launch_bounds__(256) void copy_blocks_kernel(CopyJobs J) {
+    const CopyJob job = J.j[blockIdx.y];
+    const long per_frame = (long)job.rows * job.cols, total = per_frame * job.frames;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long f = i / per_frame, q = i - f * per_frame;
+        const long r = q / job.cols;
+        const int c = (int)(q - r * job.cols);
+        job.dst[f * job.dst_fs + r * job.dst_rs + c] = job.src[f * job.src_fs + r * job.src_rs + c];
+    }
+}
+}  // namespace
+
+// jobs: host array of njobs (<= 4) records of 9 longs {src, dst, frames, rows, cols, src_frame_stride,
+// src_row_stride, dst_frame_stride, dst_row_stride} (pointers as integers, strides in floats).
+extern "C" int sa_copy_blocks(int njobs, const long *jobs, hipStream_t stream) {
+    if (njobs < 1 || njobs > kMaxCopyJobs || !jobs) return SA_ERR_INVALID;
+    CopyJobs J{};
+    long most = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const long *q = jobs + 9 * i;
+        if (!q[0] || !q[1] || q[2] <= 0 || q[3] <= 0 || q[4] <= 0) return SA_ERR_INVALID;
+        J.j[i].src = (const float *)q[0]; J.j[i].dst = (float *)q[1];
+        J.j[i].frames = (int)q[2]; J.j[i].rows = (int)q[3]; J.j[i].cols = (int)q[4];
+        J.j[i].src_fs = q[5]; J.j[i].src_rs = q[6]; J.j[i].dst_fs = q[7]; J.j[i].dst_rs = q[8];
+        const long t = q[2] * q[3] * q[4];
+        if (t > most) most = t;
+    }
+    long blocks = (most + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(copy_blocks_kernel, dim3((unsigned)blocks, njobs), dim3(256), 0, stream, J);
+    SA_CHECK_LAUNCH();
+    return SA_OK;
+}
+
 // lib/utils/tf_ops/sampling/tf_sampling.cpp:235  gatherpointLauncher(b,n,m,c,inp,idx,out)
 extern "C" int sa_gather_point(int b, int n, int m, int c, const float *inp, const int *idx, float *out,
                                hipStream_t stream) {

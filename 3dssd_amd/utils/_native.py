@@ -23,6 +23,7 @@ SIGNATURES = {
     "sa_calc_square_dist": [_c_int] * 4 + [_vp, _vp, _vp, _vp],
     "sa_fps_ex": [_c_int] * 4 + [_vp, _vp, _vp, _c_int, _c_int, _vp],
     "sa_fps_with_distance_ex": [_c_int] * 3 + [_vp, _vp, _vp, _c_int, _c_int, _vp],
+    "sa_copy_blocks": [_c_int, _vp, _vp],
     "sa_fps_ex2": [_c_int] * 4 + [_vp, _c_long, _vp, _vp, _c_int, _c_int, _vp, _c_long, _vp],
     "sa_fps_bucket_ex2": [_c_int] * 3 + [_vp, _c_long, _vp, _c_int, _c_int, _vp, _c_long, _vp],
     "sa_fps_with_distance_ex2": [_c_int] * 3 + [_vp, _vp, _vp, _c_int, _c_int, _vp, _c_long, _vp, _c_long, _vp],
@@ -107,6 +108,17 @@ def check(status, what):
 def current_stream():
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+def copy_blocks(jobs):
+    """One launch for up to four strided block copies; jobs = [(src, dst, frames, rows, cols), ...] with src / dst
+    3-D fp32 views [frames, rows, >= cols] whose last dimension is dense (any frame / row strides)."""
+    flat = []
+    for src, dst, frames, rows, cols in jobs:
+        assert src.stride(2) == 1 and dst.stride(2) == 1
+        flat += [src.data_ptr(), dst.data_ptr(), frames, rows, cols, src.stride(0), src.stride(1), dst.stride(0), dst.stride(1)]
+    arr = (ctypes.c_long * len(flat))(*flat)
+    check(lib().sa_copy_blocks(len(jobs), arr, current_stream()), "copy_blocks")
 
 
 def mlp_plan_ws(b, m, ns, device):

@@ -289,10 +289,21 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
     if former_fps_idx is not None:                                          # :112-113
         fps_idx[:, col:] = T.i32_cuda(former_fps_idx, "former_fps_idx")
 
+    sliced_points = None
     if centres_ok:
         pass                                                                # written by the samplers
     elif only_identity and plan[0][1] == 0 and plan[0][3] == ctr_src.shape[1]:
         new_xyz = ctr_src                                                   # gather with the identity: the tensor itself
+    elif only_identity and ctr_src.shape[2] == 3:
+        # identity sampling of a range: the gathers of :116-119 (and :186-187 when the layer has no radius scales) are
+        # block copies -- one launch for both
+        s0, cnt0 = plan[0][1], plan[0][3]
+        new_xyz = torch.empty((bs, cnt0, 3), dtype=torch.float32, device=dev)
+        jobs = [(ctr_src[:, s0:s0 + cnt0], new_xyz, bs, cnt0, 3)]
+        if len(radius_list) == 0:
+            sliced_points = torch.empty((bs, cnt0, points.shape[2]), dtype=torch.float32, device=dev)
+            jobs.append((points[:, s0:s0 + cnt0], sliced_points, bs, cnt0, points.shape[2]))
+        N.copy_blocks(jobs)
     else:
         new_xyz = gather_point(ctr_src, fps_idx)                            # :116-119
     m = new_xyz.shape[1]
@@ -367,5 +378,5 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
             T.require(agg.N == aggregation_channel, "aggregation_channel does not match the ensemble weights")
             new_points_concat = _dense(new_points_concat, agg, relu=True)
     else:
-        new_points_concat = gather_point(points, fps_idx)                   # :186-187
+        new_points_concat = sliced_points if sliced_points is not None else gather_point(points, fps_idx)   # :186-187
     return new_xyz, new_points_concat, fps_idx

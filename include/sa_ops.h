@@ -89,6 +89,11 @@ int sa_fps_bucket_ex2(int b, int n, int m, const float *inp, long in_bstride, in
 int sa_fps_with_distance_ex2(int b, int n, int m, const float *dist, float *temp, int *out, int out_stride,
                              int idx_off, const float *xyz, long xyz_bstride, float *ctr, long ctr_bstride,
                              sa_stream_t stream);
+/* Up to four strided block copies in one launch (the tf.slice calls of single_stage_detector.py:117-118 and
+ * layers_util.py:85-86): jobs = host array of njobs records of 9 longs {src, dst, frames, rows, cols,
+ * src_frame_stride, src_row_stride, dst_frame_stride, dst_row_stride}, pointers as integers, strides in floats;
+ * dst[f, r, 0:cols] = src[f, r, 0:cols]. */
+int sa_copy_blocks(int njobs, const long *jobs, sa_stream_t stream);
 /* Forces the global-scratch kernels (mode 0: points [b,n,c], mode 1: matrix [b,n,n]); test hook. */
 int sa_fps_generic(int b, int n, int c, int m, const float *inp, float *temp, int *out, int mode,
                    sa_stream_t stream);
