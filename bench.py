@@ -433,7 +433,7 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
     if stages:
         dom = max(stages, key=lambda s: s["avg_ms"] * s["calls_per_step"])
         mlp = [s for s in stages if s["kernel"] == "sa_group_mlp_max"]
-        mlp_ms = sum(s["avg_ms"] * s["calls_per_step"] for s in mlp)
+        mlp_ms = sum(s["avg_ms"] * s["calls_per_step"] for s in stages if s["kernel"] in ("sa_group_mlp_max", "sa_group_mlp_plan"))
         mlp_fl = sum(s["gflop"] * s["calls_per_step"] for s in mlp)
         bq = [s for s in stages if s["kernel"] in ("sa_query_ball_point_multi", "sa_query_ball_point_grid")]
         bq_ms = sum(s["avg_ms"] * s["calls_per_step"] for s in bq)
