@@ -1214,6 +1214,54 @@ extern "C" int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float 
     return SA_OK;
 }
 
+int sa_rowwave_try_layer(int b, int n, int m, const int *ns, int c, const float *xyz, const float *feat,
+                         const float *new_xyz, const int *const *idx, const int *const *cnt, const int *dims,
+                         const void *const *wpack, const float *const *bias, float *out, int out_stride,
+                         const int *out_off, const int *const *plan_hdr, const int *const *plan_gran,
+                         const long *max_tiles, const int *fp16, hipStream_t stream, int *st);
+
+// All scales of one SA layer (layers_util.py:134-181): scale i has nsample ns[i], index / count tensors idx[i] /
+// cnt[i], layer widths dims[i*(nl+1) ..], weights wpack[i*nl ..] / bias[i*nl ..], output slice out_off[i], plan
+// scratch ws[i] and flags[i] (as sa_group_mlp_max).  The three-scale layers of 3dssd.yaml whose plans were built by
+// sa_group_mlp_plan run as ONE launch (mlp_rowwave.hip, mlp_multi_kernel); anything else is the per-scale loop.
+extern "C" int sa_group_mlp_max_layer(int nscale, int b, int n, int m, const int *ns, int c, const float *xyz,
+                                      const float *feat, const float *new_xyz, const int *const *idx,
+                                      const int *const *cnt, int nl, const int *dims, const void *const *wpack,
+                                      const float *const *bias, float *out, int out_stride, const int *out_off,
+                                      void *const *ws, const size_t *ws_bytes, const int *flags, hipStream_t stream) {
+    if (nscale < 1 || !ns || !idx || !cnt || !dims || !wpack || !bias || !out_off || !ws || !ws_bytes || !flags)
+        return SA_ERR_INVALID;
+    if (nscale == 3 && nl == 3 && b > 0 && m > 0 && c >= 0 && xyz && new_xyz && out) {
+        bool ok = true;
+        const int *hdr[3], *gran[3];
+        long max_tiles[3];
+        int fp16[3];
+        for (int i = 0; i < 3 && ok; ++i) {
+            ok = (flags[i] & 2) && !(flags[i] & 1) && ns[i] > 0 && idx[i] && cnt[i] && ws[i] &&
+                 ws_bytes[i] >= sa_group_mlp_max_ws_bytes(b, m, ns[i]) && dims[4 * i] == c + 3 && (c == 0 || feat);
+            for (int l = 0; l < 3 && ok; ++l) ok = dims[4 * i + l + 1] > 0 && wpack[3 * i + l] && bias[3 * i + l];
+            if (!ok) break;
+            hdr[i] = (const int *)ws[i];
+            gran[i] = hdr[i] + sa::kPlanHeaderInts;
+            max_tiles[i] = (sa_plan_max_granules((long)b * m, ns[i]) + 3) / 4;
+            fp16[i] = (flags[i] & 4) ? 1 : 0;
+        }
+        if (ok) {
+            int st = SA_OK;
+            if (sa_rowwave_try_layer(b, n, m, ns, c, xyz, feat, new_xyz, idx, cnt, dims, wpack, bias, out, out_stride,
+                                     out_off, hdr, gran, max_tiles, fp16, stream, &st))
+                return st;
+        }
+    }
+    for (int i = 0; i < nscale; ++i) {
+        const int st = sa_group_mlp_max(b, n, m, ns[i], c, xyz, feat, new_xyz, idx[i], cnt[i], nl, dims + (nl + 1) * i,
+                                        wpack + nl * i, bias + nl * i, out, out_stride, out_off[i], ws[i], ws_bytes[i],
+                                        flags[i], stream);
+        if (st != SA_OK) return st;
+    }
+    return SA_OK;
+}
+
 // y[rows,N] = act(x[rows,K] W + b): tf_util.conv1d 1x1 with folded BN (tf_util.py:51-124).
 extern "C" int sa_dense(long rows, int K, int N, const float *x, const void *wpack, const float *bias,
                         int relu, float *y, hipStream_t stream) {

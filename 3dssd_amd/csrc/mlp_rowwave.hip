@@ -239,7 +239,7 @@ __device__ __forceinline__ void hidden_layer(const uint4 *W, const float *bias, 
 // KS0: k-steps of the gathered input; (NT1, KS1), (NT2, KS2): output tiles of hidden layer 1 / 2 and the
 // k-steps the next layer reads of them; NT3: output tiles of the last layer.  NW waves per workgroup.
 template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF>
-__global__ __launch_bounds__(NW * 64, WPE) void mlp_rw_kernel(RwParams P) {
+__device__ __forceinline__ void rw_body(const RwParams &P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int nW0 = NT1 * KS0 * 128, nW1 = NT2 * KS1 * 128, nW2 = NT3 * KS2 * 128;   // uint4 counts
     uint4 *W0 = (uint4 *)smem, *W1 = W0 + nW0, *W2 = W1 + nW1;
@@ -369,6 +369,10 @@ __global__ __launch_bounds__(NW * 64, WPE) void mlp_rw_kernel(RwParams P) {
     }
     RW_FLUSH(gw)
 }
+template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF>
+__global__ __launch_bounds__(NW * 64, WPE) void mlp_rw_kernel(RwParams P) {
+    rw_body<KS0, NT1, KS1, NT2, KS2, NT3, NW, WPE, TAILF>(P);
+}
 
 // =====================================================================================================
 // Streamed-weight variant for the mid-width scales (layer3 of 3dssd.yaml: 131 -> 128 -> 128..256 -> 256) whose
@@ -487,7 +491,7 @@ __device__ __forceinline__ void load_bias_tile(const float *bias, int ct, int ha
 // of the scale); PF: 1 = the next tile's rows are requested right after this tile's last layer (two or more tiles per
 // wave), 0 = at the top of the pass (one tile per wave: nothing to prefetch, 17 x 8 registers less).
 template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF, int DEPTH, int PR, int CPP, int PF>
-__global__ __launch_bounds__(NW * 64, WPE) void mlp_rs_kernel(RwParams P) {
+__device__ __forceinline__ void rs_body(const RwParams &P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KT0 = NT1 * KS0, KT1 = NT2 * KS1, KT2 = NT3 * KS2, TOT = KT0 + KT1 + KT2;
     static_assert(TOT % CPP == 0 && CPP % DEPTH == 0, "CPP chunks per pass, staging depth a divisor of CPP");
@@ -600,6 +604,32 @@ __global__ __launch_bounds__(NW * 64, WPE) void mlp_rs_kernel(RwParams P) {
     }
     RW_FLUSH(gw)
 }
+template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF, int DEPTH, int PR, int CPP, int PF>
+__global__ __launch_bounds__(NW * 64, WPE) void mlp_rs_kernel(RwParams P) {
+    rs_body<KS0, NT1, KS1, NT2, KS2, NT3, NW, WPE, TAILF, DEPTH, PR, CPP, PF>(P);
+}
+
+// ---- all scales of an SA layer in ONE launch: blockIdx.y picks the scale (its own parameters, its own shape).  The
+//      scales of a layer are independent (same inputs, disjoint output slices), a launch costs ~2 us of throughput and
+//      these kernels run one or two tiles per wave, so three launches of 14-40 us become one of the longest's length.
+struct RwMulti { RwParams p[3]; };
+template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF>
+struct RwBody {
+    static constexpr size_t lds = (size_t)(NT1 * KS0 + NT2 * KS1 + NT3 * KS2) * 2048 + (size_t)(NT1 + NT2 + NT3) * 128;
+    static __device__ __forceinline__ void run(const RwParams &P) { rw_body<KS0, NT1, KS1, NT2, KS2, NT3, NW, WPE, TAILF>(P); }
+};
+template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int DEPTH, int PR, int CPP, int PF>
+struct RsBody {
+    static constexpr size_t lds = (size_t)2 * (PR == 3 ? 2 : 1) * ((NT1 * KS0 + NT2 * KS1 + NT3 * KS2) / CPP) * 1024 +
+                                  (size_t)(NT1 + NT2 + NT3) * 128;
+    static __device__ __forceinline__ void run(const RwParams &P) { rs_body<KS0, NT1, KS1, NT2, KS2, NT3, NW, WPE, 0, DEPTH, PR, CPP, PF>(P); }
+};
+template <class B0, class B1, class B2, int NW, int WPE>
+__global__ __launch_bounds__(NW * 64, WPE) void mlp_multi_kernel(RwMulti M) {
+    if (blockIdx.y == 0) B0::run(M.p[0]);
+    else if (blockIdx.y == 1) B1::run(M.p[1]);
+    else B2::run(M.p[2]);
+}
 
 int roundup(int x, int q) { return (x + q - 1) / q * q; }
 
@@ -648,27 +678,53 @@ int launch_rs(const RwParams &P, long max_tiles, int wgs_per_cu, hipStream_t str
     return SA_OK;
 }
 
+template <class B0, class B1, class B2, int NW, int WPE>
+int launch_multi(const RwParams (&P)[3], const long (&max_tiles)[3], int wgs_per_cu, hipStream_t stream) {
+    constexpr size_t l01 = B0::lds > B1::lds ? B0::lds : B1::lds, lds = l01 > B2::lds ? l01 : B2::lds;
+    auto kern = mlp_multi_kernel<B0, B1, B2, NW, WPE>;
+    if (lds > 48 * 1024) {
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipGetLastError();
+    }
+    long mt = max_tiles[0] > max_tiles[1] ? max_tiles[0] : max_tiles[1];
+    if (max_tiles[2] > mt) mt = max_tiles[2];
+    long grid = (mt + NW - 1) / NW;             // the densest plan of the widest scale; workgroups without a tile leave at once
+    const long cap = (long)num_cus() * wgs_per_cu;
+    if (grid > cap) grid = cap;
+    RwMulti M;
+    for (int i = 0; i < 3; ++i) M.p[i] = P[i];
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid, 3), dim3(NW * 64), lds, stream, M);
+    SA_CHECK_LAUNCH();
+    return SA_OK;
+}
+
+struct ScaleSig { int KS0, NT1, KS1, NT2, KS2, NT3; };
+bool sig_is(const ScaleSig &s, int a, int b, int c, int d, int e, int f) {
+    return s.KS0 == a && s.NT1 == b && s.KS1 == c && s.NT2 == d && s.KS2 == e && s.NT3 == f;
+}
+
 }  // namespace
 
 // Returns 1 when the shape has a row-wave instantiation and the launch was issued (status in *st), 0 when the
 // caller should take the generic kernel.
-int sa_rowwave_try(int b, int n, int m, int ns, int c, const float *xyz, const float *feat, const float *new_xyz,
-                   const int *idx, const int *cnt, int nl, const int *dims, const void *const *wpack,
-                   const float *const *bias, float *out, int out_stride, int out_off, const int *plan_hdr,
-                   const int *plan_gran, long max_tiles, int fp16, hipStream_t stream, int *st) {
+// parameters + padded shape of one scale; false when the row-wave kernels cannot take it
+static bool rowwave_scale(int b, int n, int m, int ns, int c, const float *xyz, const float *feat, const float *new_xyz,
+                          const int *idx, const int *cnt, int nl, const int *dims, const void *const *wpack,
+                          const float *const *bias, float *out, int out_stride, int out_off, const int *plan_hdr,
+                          const int *plan_gran, long max_tiles, RwParams &P, ScaleSig &S) {
     static const bool enabled = !(getenv("SA_MLP_ROWWAVE") && atoi(getenv("SA_MLP_ROWWAVE")) == 0);
-    if (!enabled || nl != 3) return 0;
-    if (!(c == 1 || (c > 0 && (c & 7) == 0))) return 0;      // input layouts the in-register gather handles
+    if (!enabled || nl != 3) return false;
+    if (!(c == 1 || (c > 0 && (c & 7) == 0))) return false;  // input layouts the in-register gather handles
     // 32-bit element offsets everywhere (and a float-exact ball / m)
     const long nb_ = (long)b * m;
     if (nb_ >= (1l << 24) || (long)b * n * (c > 3 ? c : 3) >= (1l << 31) || nb_ * ns >= (1l << 31) ||
         nb_ * out_stride + out_off + dims[3] >= (1l << 31))
-        return 0;
-    const int KS0 = roundup(dims[0], 16) / 16;
-    const int NT1 = roundup(dims[1], 32) / 32, KS1 = roundup(dims[1], 16) / 16;
-    const int NT2 = roundup(dims[2], 32) / 32, KS2 = roundup(dims[2], 16) / 16;
-    const int NT3 = roundup(dims[3], 32) / 32;
-    RwParams P{};
+        return false;
+    S.KS0 = roundup(dims[0], 16) / 16;
+    S.NT1 = roundup(dims[1], 32) / 32; S.KS1 = roundup(dims[1], 16) / 16;
+    S.NT2 = roundup(dims[2], 32) / 32; S.KS2 = roundup(dims[2], 16) / 16;
+    S.NT3 = roundup(dims[3], 32) / 32;
+    P = RwParams{};
     P.xyz = xyz; P.feat = feat; P.new_xyz = new_xyz; P.idx = idx; P.cnt = cnt; P.out = out;
     for (int l = 0; l < 3; ++l) { P.w[l] = (const uint4 *)wpack[l]; P.bias[l] = bias[l]; }
     P.n = n; P.m = m; P.ns = ns; P.C = c; P.nballs = (long)b * m;
@@ -678,7 +734,68 @@ int sa_rowwave_try(int b, int n, int m, int ns, int c, const float *xyz, const f
     P.m_shift = -1;
     for (int sft = 0; sft < 31; ++sft) if (m == (1 << sft)) P.m_shift = sft;
     P.inv_m = 1.0f / (float)m;
-    if (max_tiles > 0x0FFFFFFFl) return 0;
+    return max_tiles <= 0x0FFFFFFFl;
+}
+static bool rowwave_contiguous(const ScaleSig &S, const void *const *wpack, int fp16) {
+    const int planes = fp16 ? 1 : 2;         // 1 KiB pieces per (tile, k-step)
+    return (const char *)wpack[1] == (const char *)wpack[0] + (size_t)S.NT1 * S.KS0 * planes * 1024 &&
+           (const char *)wpack[2] == (const char *)wpack[1] + (size_t)S.NT2 * S.KS1 * planes * 1024;
+}
+
+// The three scales of a layer in one launch (mlp_multi_kernel) for the layer shapes of 3dssd.yaml; 0 when the layer
+// is not one of them (the caller then launches scale by scale).
+int sa_rowwave_try_layer(int b, int n, int m, const int *ns, int c, const float *xyz, const float *feat,
+                         const float *new_xyz, const int *const *idx, const int *const *cnt, const int *dims,
+                         const void *const *wpack, const float *const *bias, float *out, int out_stride,
+                         const int *out_off, const int *const *plan_hdr, const int *const *plan_gran,
+                         const long *max_tiles, const int *fp16, hipStream_t stream, int *st) {
+    static const bool on = !(getenv("SA_MLP_MULTI") && atoi(getenv("SA_MLP_MULTI")) == 0);
+    static const bool stream_enabled = !(getenv("SA_MLP_ROWSTREAM") && atoi(getenv("SA_MLP_ROWSTREAM")) == 0);
+    if (!on) return 0;
+    RwParams P[3];
+    ScaleSig S[3];
+    long mt[3];
+    for (int i = 0; i < 3; ++i) {
+        if (!rowwave_scale(b, n, m, ns[i], c, xyz, feat, new_xyz, idx[i], cnt[i], 3, dims + 4 * i, wpack + 3 * i,
+                           bias + 3 * i, out, out_stride, out_off[i], plan_hdr[i], plan_gran[i], max_tiles[i], P[i], S[i]))
+            return 0;
+        mt[i] = max_tiles[i];
+    }
+    const bool all16 = fp16[0] && fp16[1] && fp16[2], none16 = !fp16[0] && !fp16[1] && !fp16[2];
+    if (none16 && c == 1 && sig_is(S[0], 1, 1, 1, 1, 1, 1) && sig_is(S[1], 1, 1, 1, 1, 1, 1) && sig_is(S[2], 1, 1, 2, 1, 2, 2)) {
+        typedef RwBody<1, 1, 1, 1, 1, 1, 4, 4, 1> A;                    // layer1: 4 -> 16 -> 16 -> 32 (x2), 4 -> 32 -> 32 -> 64
+        typedef RwBody<1, 1, 2, 1, 2, 2, 4, 4, 1> Bq;
+        *st = launch_multi<A, A, Bq, 4, 4>(P, mt, 4, stream);
+        return 1;
+    }
+    if (none16 && c != 1 && sig_is(S[0], 5, 2, 4, 2, 4, 4) && sig_is(S[1], 5, 2, 4, 2, 4, 4) && sig_is(S[2], 5, 2, 4, 3, 6, 4)) {
+        typedef RwBody<5, 2, 4, 2, 4, 4, 8, 2, 0> A;                    // layer2: 67 -> 64 -> 64 -> 128 (x2), 67 -> 64 -> 96 -> 128
+        typedef RwBody<5, 2, 4, 3, 6, 4, 8, 2, 0> Bq;
+        *st = launch_multi<A, A, Bq, 8, 2>(P, mt, 1, stream);
+        return 1;
+    }
+    if (all16 && stream_enabled && c != 1 && sig_is(S[0], 9, 4, 8, 4, 8, 8) && sig_is(S[1], 9, 4, 8, 6, 12, 8) &&
+        sig_is(S[2], 9, 4, 8, 8, 16, 8) && rowwave_contiguous(S[0], wpack, 1) && rowwave_contiguous(S[1], wpack + 3, 1) &&
+        rowwave_contiguous(S[2], wpack + 6, 1)) {
+        typedef RsBody<9, 4, 8, 4, 8, 8, 8, 2, 2, 1, 12, 1> A;          // layer3, fp16
+        typedef RsBody<9, 4, 8, 6, 12, 8, 8, 2, 2, 1, 12, 1> Bq;
+        typedef RsBody<9, 4, 8, 8, 16, 8, 8, 2, 2, 1, 12, 1> Cq;
+        *st = launch_multi<A, Bq, Cq, 8, 2>(P, mt, 1, stream);
+        return 1;
+    }
+    return 0;
+}
+
+int sa_rowwave_try(int b, int n, int m, int ns, int c, const float *xyz, const float *feat, const float *new_xyz,
+                   const int *idx, const int *cnt, int nl, const int *dims, const void *const *wpack,
+                   const float *const *bias, float *out, int out_stride, int out_off, const int *plan_hdr,
+                   const int *plan_gran, long max_tiles, int fp16, hipStream_t stream, int *st) {
+    RwParams P;
+    ScaleSig S;
+    if (!rowwave_scale(b, n, m, ns, c, xyz, feat, new_xyz, idx, cnt, nl, dims, wpack, bias, out, out_stride, out_off,
+                       plan_hdr, plan_gran, max_tiles, P, S))
+        return 0;
+    const int KS0 = S.KS0, NT1 = S.NT1, KS1 = S.KS1, NT2 = S.NT2, KS2 = S.KS2, NT3 = S.NT3;
 #define SA_RW(K0, N1, K1, N2, K2, N3_, NW_, WPE_, WGS)                                              \
     if (!fp16 && KS0 == K0 && NT1 == N1 && KS1 == K1 && NT2 == N2 && KS2 == K2 && NT3 == N3_) {             \
         *st = c == 1 ? launch_rw<K0, N1, K1, N2, K2, N3_, NW_, WPE_, 1>(P, max_tiles, WGS, stream)             \
@@ -692,10 +809,7 @@ int sa_rowwave_try(int b, int n, int m, int ns, int c, const float *xyz, const f
 #undef SA_RW
     // the streamed kernel walks the three layers as one linear weight stream: they must be packed back to back
     // (utils/weights.py pack_scale does that); separately allocated layers take the generic kernel
-    const int planes = fp16 ? 1 : 2;         // 1 KiB pieces per (tile, k-step)
-    const bool contiguous =
-        (const char *)wpack[1] == (const char *)wpack[0] + (size_t)NT1 * KS0 * planes * 1024 &&
-        (const char *)wpack[2] == (const char *)wpack[1] + (size_t)NT2 * KS1 * planes * 1024;
+    const bool contiguous = rowwave_contiguous(S, wpack, fp16);
     static const bool stream_enabled = !(getenv("SA_MLP_ROWSTREAM") && atoi(getenv("SA_MLP_ROWSTREAM")) == 0);
 #define SA_RS(K0, N1, K1, N2, K2, N3_, NW_, WPE_, WGS, D_, PR_, CPP_, PF_)                              \
     if (stream_enabled && contiguous && c != 1 && (PR_ == 1) == (fp16 != 0) && KS0 == K0 && NT1 == N1 && KS1 == K1 && NT2 == N2 && KS2 == K2 && NT3 == N3_) { \

@@ -353,26 +353,45 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
                                        new_points_concat.data_ptr(), ctot, (ctypes.c_int * nscale)(*offs),
                                        (ctypes.c_int * nscale)(*[ls[-1].N for ls in layers]), MLP_PLAN_FLAGS, stream)
             N.check(st, "group_mlp_plan")
-        off = 0
-        for i in range(nscale):
-            ls = layers[i]
-            nl = len(ls)
-            dims = (ctypes.c_int * (nl + 1))(*([c_feat + 3] + [l.N for l in ls]))
-            wp = (ctypes.c_void_p * nl)(*[l.w.data_ptr() for l in ls])
-            bp = (ctypes.c_void_p * nl)(*[l.bias.data_ptr() for l in ls])
-            plan, plan_bytes = plans[i]
-            if ("mlp:%s" % scope) in _ABLATE or ("mlp:%s:%d" % (scope, i)) in _ABLATE:
-                off += ls[-1].N
-                continue
-            st = lib.sa_group_mlp_max(bs, n_all, m, int(nsample_list[i]), c_feat, xyz.data_ptr(),
-                                      points.data_ptr(), new_xyz.data_ptr(), idx_list[i].data_ptr(),
-                                      cnt_list[i].data_ptr(), nl, dims, wp, bp,
-                                      new_points_concat.data_ptr(), ctot, off, plan.data_ptr(), plan_bytes,
-                                      MLP_PLAN_FLAGS | (2 if have_plans else 0) | W.scale_flags(ls), stream)
-            N.check(st, "group_mlp_max")
-            if PLAN_LOG is not None:                                        # bench.py: rows evaluated per scale
-                PLAN_LOG.append((bs, m, int(nsample_list[i]), sum(dims[j] * dims[j + 1] for j in range(nl)), plan))
-            off += ls[-1].N
+        # ---- the grouped MLPs of all scales: ONE C-ABI call per layer (one launch for the three-scale layers of the
+        #      reference configuration: the scales are independent, every launch costs ~2 us of throughput)
+        nls = {len(ls) for ls in layers}
+        ablated = [("mlp:%s" % scope) in _ABLATE or ("mlp:%s:%d" % (scope, i)) in _ABLATE for i in range(nscale)]
+        live = [i for i in range(nscale) if not ablated[i]]
+        if len(nls) == 1 and live:
+            nl = nls.pop()
+            k = len(live)
+            dims_a = (ctypes.c_int * (k * (nl + 1)))(*[v for i in live for v in ([c_feat + 3] + [l.N for l in layers[i]])])
+            wp = (ctypes.c_void_p * (k * nl))(*[l.w.data_ptr() for i in live for l in layers[i]])
+            bp = (ctypes.c_void_p * (k * nl))(*[l.bias.data_ptr() for i in live for l in layers[i]])
+            st = lib.sa_group_mlp_max_layer(
+                k, bs, n_all, m, (ctypes.c_int * k)(*[int(nsample_list[i]) for i in live]), c_feat, xyz.data_ptr(),
+                points.data_ptr(), new_xyz.data_ptr(), (ctypes.c_void_p * k)(*[idx_list[i].data_ptr() for i in live]),
+                (ctypes.c_void_p * k)(*[cnt_list[i].data_ptr() for i in live]), nl, dims_a, wp, bp,
+                new_points_concat.data_ptr(), ctot, (ctypes.c_int * k)(*[offs[i] for i in live]),
+                (ctypes.c_void_p * k)(*[plans[i][0].data_ptr() for i in live]),
+                (ctypes.c_ulong * k)(*[plans[i][1] for i in live]),
+                (ctypes.c_int * k)(*[MLP_PLAN_FLAGS | (2 if have_plans else 0) | W.scale_flags(layers[i]) for i in live]),
+                stream)
+            N.check(st, "group_mlp_max_layer")
+        else:                                                               # scales of different depth: one by one
+            for i in live:
+                ls = layers[i]
+                nl = len(ls)
+                dims = (ctypes.c_int * (nl + 1))(*([c_feat + 3] + [l.N for l in ls]))
+                wp = (ctypes.c_void_p * nl)(*[l.w.data_ptr() for l in ls])
+                bp = (ctypes.c_void_p * nl)(*[l.bias.data_ptr() for l in ls])
+                st = lib.sa_group_mlp_max(bs, n_all, m, int(nsample_list[i]), c_feat, xyz.data_ptr(),
+                                          points.data_ptr(), new_xyz.data_ptr(), idx_list[i].data_ptr(),
+                                          cnt_list[i].data_ptr(), nl, dims, wp, bp,
+                                          new_points_concat.data_ptr(), ctot, offs[i], plans[i][0].data_ptr(), plans[i][1],
+                                          MLP_PLAN_FLAGS | (2 if have_plans else 0) | W.scale_flags(ls), stream)
+                N.check(st, "group_mlp_max")
+        if PLAN_LOG is not None:                                            # bench.py: rows evaluated per scale
+            for i in live:
+                nl = len(layers[i])
+                d_ = [c_feat + 3] + [l.N for l in layers[i]]
+                PLAN_LOG.append((bs, m, int(nsample_list[i]), sum(d_[j] * d_[j + 1] for j in range(nl)), plans[i][0]))
         if AGGREGATION_SA_FEATURE:                                          # :184-185
             agg = vs.layer(scope + "/ensemble", bn)
             T.require(agg.N == aggregation_channel, "aggregation_channel does not match the ensemble weights")

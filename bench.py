@@ -91,6 +91,20 @@ def _algorithmic(name, a):
         macs = sum(dims[i] * dims[i + 1] for i in range(nl))
         by = b * (n * (c + 3) * 4 + m * 12 + m * ns * 4 + m * 4 + m * dims[-1] * 4)
         return 2 * b * m * ns * macs, by, "group_mlp_max m=%d ns=%d %s" % (m, ns, "-".join(map(str, dims)))
+    if name == "sa_group_mlp_max_layer":
+        k, b, n, m = a[0:4]
+        c, nl = a[5], a[11]
+        ns = [a[4][i] for i in range(k)]
+        fl = by = 0
+        shapes = []
+        for i in range(k):
+            dims = [a[12][i * (nl + 1) + j] for j in range(nl + 1)]
+            macs = sum(dims[j] * dims[j + 1] for j in range(nl))
+            fl += 2 * b * m * ns[i] * macs
+            by += b * (m * ns[i] * 4 + m * 4 + m * dims[-1] * 4)
+            shapes.append("%d:%s" % (ns[i], "-".join(map(str, dims))))
+        by += b * (n * (c + 3) * 4 + m * 12)
+        return fl, by, "group_mlp_max_layer m=%d %s" % (m, " ".join(shapes))
     if name == "sa_dense":
         rows, K, N = a[0:3]
         return 2 * rows * K * N, rows * (K + N) * 4 + K * N * 4, "dense %dx%d->%d" % (rows, K, N)
@@ -198,7 +212,7 @@ def _pmc_mlp_util():
 
 def roofline_of(stage, frames):
     k = stage["kernel"]
-    if k in ("sa_group_mlp_max", "sa_dense", "sa_calc_square_dist_split", "sa_calc_square_dist_split_ws", "sa_calc_square_dist_self_ws"):
+    if k in ("sa_group_mlp_max", "sa_group_mlp_max_layer", "sa_dense", "sa_calc_square_dist_split", "sa_calc_square_dist_split_ws", "sa_calc_square_dist_self_ws"):
         peak = MFMA_BF16_PEAK_TF if not k.startswith("sa_calc_square_dist") else VALU_F32_PEAK_TF
         a = stage.get("tflops", 0.0)
         return dict(kernel=stage["label"], bound="mfma", achieved=a, peak=peak, unit="TFLOP/s",
@@ -432,13 +446,15 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
     }
     if stages:
         dom = max(stages, key=lambda s: s["avg_ms"] * s["calls_per_step"])
-        mlp = [s for s in stages if s["kernel"] == "sa_group_mlp_max"]
-        mlp_ms = sum(s["avg_ms"] * s["calls_per_step"] for s in stages if s["kernel"] in ("sa_group_mlp_max", "sa_group_mlp_plan"))
+        mlp = [s for s in stages if s["kernel"] in ("sa_group_mlp_max", "sa_group_mlp_max_layer")]
+        mlp_ms = sum(s["avg_ms"] * s["calls_per_step"] for s in stages
+                     if s["kernel"] in ("sa_group_mlp_max", "sa_group_mlp_max_layer", "sa_group_mlp_plan"))
         mlp_fl = sum(s["gflop"] * s["calls_per_step"] for s in mlp)
         bq = [s for s in stages if s["kernel"] in ("sa_query_ball_point_multi", "sa_query_ball_point_grid")]
         bq_ms = sum(s["avg_ms"] * s["calls_per_step"] for s in bq)
         bq_mb = sum(s["mbytes"] * s["calls_per_step"] for s in bq)
-        gflop_step = sum(s["gflop"] * s["calls_per_step"] for s in stages if s["kernel"] in ("sa_group_mlp_max", "sa_dense"))
+        gflop_step = sum(s["gflop"] * s["calls_per_step"] for s in stages
+                         if s["kernel"] in ("sa_group_mlp_max", "sa_group_mlp_max_layer", "sa_dense"))
         mb_step = sum(s["mbytes"] * s["calls_per_step"] for s in stages)
         line["roofline"] = roofline_of(dom, len(frames))
         line["whole_step"] = {

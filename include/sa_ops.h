@@ -150,6 +150,16 @@ int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float *xyz, const
                      const void *const *wpack, const float *const *bias, float *out, int out_stride,
                      int out_off, void *ws, unsigned long ws_bytes, int flags, sa_stream_t stream);
 
+/* All scales of one SA layer in one call: scale i has nsample ns[i], idx[i] / cnt[i], layer widths
+ * dims[i*(nl+1) .. (i+1)*(nl+1)), weights wpack[i*nl ..] / bias[i*nl ..], output slice out_off[i], plan scratch ws[i]
+ * (ws_bytes[i]) and flags[i] as in sa_group_mlp_max.  Three-scale layers of the reference configuration whose plans
+ * come from sa_group_mlp_plan are ONE launch (the scales are independent); anything else is the per-scale loop. */
+int sa_group_mlp_max_layer(int nscale, int b, int n, int m, const int *ns, int c, const float *xyz, const float *feat,
+                           const float *new_xyz, const int *const *idx, const int *const *cnt, int nl, const int *dims,
+                           const void *const *wpack, const float *const *bias, float *out, int out_stride,
+                           const int *out_off, void *const *ws, const unsigned long *ws_bytes, const int *flags,
+                           sa_stream_t stream);
+
 /* y[rows,N] = act(x[rows,K] W + b): tf_util.conv1d 1x1 + folded BN (tf_util.py:51-124). */
 int sa_dense(long rows, int K, int N, const float *x, const void *wpack, const float *bias, int relu,
              float *y, sa_stream_t stream);
