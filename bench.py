@@ -200,7 +200,7 @@ def _pmc_mlp_util():
     busy = cap = 0.0
     per_kernel = {}
     for k, e in d.items():
-        if ("mlp_r" in k or "group_mlp" in k) and "mfma_util" in e:
+        if ("mlp_r" in k or "mlp_multi" in k or "group_mlp" in k) and "mfma_util" in e:
             busy += e["mfma_busy_cycles_per_launch"]
             cap += e["gui_active_cycles_per_launch"] / 8.0 * 1024.0
             per_kernel[k] = e["mfma_util"]
@@ -412,11 +412,17 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
     t_max, frames_total, host_issue_ms, outs = timed_region(sh, dev, run, args.steps, args.warmup, len(frames))
     assert outs[-1][1].shape == (len(frames), 256, 512)
     overlap = overlap_probe(run, min(args.steps, 96)) if rank == 0 else None
-    # single-stream latency of one batch (no overlap), for the record
+    # latency of one batch alone on the device (no overlap), for the record: one graph replayed by itself (eager
+    # launches are partly host-bound -- ~0.6 ms of Python per step -- and measured 5.1-9.5 ms depending on the host)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     for _ in range(3):
-        net(pts)
+        if graphs is not None:
+            with torch.cuda.stream(streams[0]):
+                graphs[0][0].replay()
+            streams[0].synchronize()
+        else:
+            net(pts)
     torch.cuda.synchronize()
     latency_ms = (time.perf_counter() - t1) / 3 * 1e3
     if rank != 0:
