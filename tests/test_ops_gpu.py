@@ -481,6 +481,73 @@ def test_group_mlp_max_operand_precisions(gpu, oracle, c, ns, dims, m):
         assert np.array_equal(got, _run_group_mlp(gpu, xyz, feat, new_xyz, pidx, cnt, ws, bs, flags=1, precision=precision))
 
 
+@pytest.mark.parametrize("c,nss,dimss", [
+    (1, [32, 32, 64], [[16, 16, 32], [16, 16, 32], [32, 32, 64]]),                     # layer1: LDS-resident weights, split bf16
+    (64, [32, 32, 64], [[64, 64, 128], [64, 64, 128], [64, 96, 128]]),                 # layer2
+    (128, [32, 32, 32], [[128, 128, 256], [128, 192, 256], [128, 256, 256]]),          # layer3: streamed, fp16
+    (256, [16, 32], [[256, 256, 512], [256, 512, 1024]]),                              # layer4: two scales -> the per-scale loop
+])
+def test_group_mlp_max_layer_equals_scale_by_scale(gpu, oracle, c, nss, dimss):
+    # sa_group_mlp_max_layer (the three scales of a layer in ONE launch where the shapes are the reference configuration's)
+    # == sa_group_mlp_plan + one sa_group_mlp_max per scale, bit for bit, and within the bar of the oracle
+    import ctypes
+    N, Wt = pkg("utils._native"), pkg("utils.weights")
+    rng = np.random.default_rng(c + len(nss))
+    b, n, m = 8, 700, 96
+    k = len(nss)
+    xyz = _cloud(rng, b, n, scale=4.0)
+    feat = rng.normal(0, 1, (b, n, c)).astype(np.float32)
+    new_xyz = xyz[:, rng.integers(0, n, m)] + rng.normal(0, 0.1, (b, m, 3)).astype(np.float32)
+    tx, tf, tn = _t(xyz, gpu), _t(feat, gpu), _t(new_xyz, gpu)
+    idxs, cnts, layers, refs = [], [], [], []
+    for ns, dims in zip(nss, dimss):
+        idx = rng.integers(0, n, (b, m, ns)).astype(np.int32)
+        cnt = rng.integers(0, ns + 1, (b, m)).astype(np.int32)
+        idx = _pad_like_ball_query(idx, cnt)
+        ws, bs = _rand_layers(rng, [c + 3] + dims)
+        idxs.append(_t(idx, gpu)); cnts.append(_t(cnt, gpu)); layers.append(Wt.pack_scale(ws, bs, gpu))
+        refs.append(oracle.group_mlp_max(xyz, feat, new_xyz, idx, cnt, ws, bs))
+    ctot = sum(d[-1] for d in dimss)
+    offs = [sum(d[-1] for d in dimss[:i]) for i in range(k)]
+    lib = N.lib()
+
+    def run(fused):
+        out = torch.full((b, m, ctot), -3.0, dtype=torch.float32, device=gpu)
+        plans = [N.mlp_plan_ws(b, m, ns, gpu) for ns in nss]
+        nsa = (ctypes.c_int * k)(*nss)
+        st = lib.sa_group_mlp_plan(b, m, k, nsa, (ctypes.c_void_p * k)(*[t.data_ptr() for t in cnts]),
+                                   (ctypes.c_void_p * k)(*[p[0].data_ptr() for p in plans]), out.data_ptr(), ctot,
+                                   (ctypes.c_int * k)(*offs), (ctypes.c_int * k)(*[d[-1] for d in dimss]), 0, N.current_stream())
+        assert st == 0
+        flags = [2 | Wt.scale_flags(ls) for ls in layers]
+        if fused:
+            st = lib.sa_group_mlp_max_layer(
+                k, b, n, m, nsa, c, tx.data_ptr(), tf.data_ptr(), tn.data_ptr(),
+                (ctypes.c_void_p * k)(*[t.data_ptr() for t in idxs]), (ctypes.c_void_p * k)(*[t.data_ptr() for t in cnts]), 3,
+                (ctypes.c_int * (4 * k))(*[v for d in dimss for v in [c + 3] + d]),
+                (ctypes.c_void_p * (3 * k))(*[l.w.data_ptr() for ls in layers for l in ls]),
+                (ctypes.c_void_p * (3 * k))(*[l.bias.data_ptr() for ls in layers for l in ls]), out.data_ptr(), ctot,
+                (ctypes.c_int * k)(*offs), (ctypes.c_void_p * k)(*[p[0].data_ptr() for p in plans]),
+                (ctypes.c_ulong * k)(*[p[1] for p in plans]), (ctypes.c_int * k)(*flags), N.current_stream())
+            assert st == 0
+        else:
+            for i in range(k):
+                st = lib.sa_group_mlp_max(b, n, m, nss[i], c, tx.data_ptr(), tf.data_ptr(), tn.data_ptr(), idxs[i].data_ptr(),
+                                          cnts[i].data_ptr(), 3, (ctypes.c_int * 4)(*([c + 3] + dimss[i])),
+                                          (ctypes.c_void_p * 3)(*[l.w.data_ptr() for l in layers[i]]),
+                                          (ctypes.c_void_p * 3)(*[l.bias.data_ptr() for l in layers[i]]), out.data_ptr(), ctot,
+                                          offs[i], plans[i][0].data_ptr(), plans[i][1], flags[i], N.current_stream())
+                assert st == 0
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
+
+    a, bb = run(True), run(False)
+    assert np.array_equal(a, bb)
+    for i in range(k):
+        got = a[:, :, offs[i]:offs[i] + dimss[i][-1]]
+        assert np.abs(got - refs[i]).max() / np.abs(refs[i]).max() < MLP_TOL
+
+
 def test_group_mlp_max_separately_allocated_layers(gpu, oracle):
     # layer-3 shape with the three layers in three device buffers: no streamed path, same result
     rng = np.random.default_rng(77)
