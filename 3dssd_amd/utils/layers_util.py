@@ -193,16 +193,9 @@ def _dfps_into(npoint, xyz, start, end, out, col, ctr):
     return done[0]
 
 
-def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_training, bn_decay, bn,
-                           fps_sample_range_list, fps_method_list, npoint_list, former_fps_idx,
-                           use_attention, scope, dilated_group, vote_ctr=None, aggregation_channel=None,
-                           debugging=False, epsilon=1e-5, variables=None):
-    """layers_util.py:59-189.  xyz (B,n,3), points (B,n,C) -> new_xyz (B,m,3), new_points (B,m,C'),
-    fps_idx (B,m) int32."""
-    T.require(not use_attention, "use_attention (query_ball_point_withidx) is outside the 3DSSD SA path")
-    vs = variables or W.default_variables()
-    xyz = T.f32_cuda(xyz, "xyz")
-    points = T.f32_cuda(points, "points")
+def sample_layer(xyz, points, fps_sample_range_list, fps_method_list, npoint_list, former_fps_idx, vote_ctr, radius_list):
+    """The sampling half of pointnet_sa_module_msg (layers_util.py:84-119): range slicing, D-FPS / F-FPS / FS / identity
+    per range, index offsets, the centres.  Returns (fps_idx [B,m] int32, new_xyz [B,m,3], sliced_points or None)."""
     bs, n_all, _ = xyz.shape
     dev = xyz.device
 
@@ -306,6 +299,25 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
         N.copy_blocks(jobs)
     else:
         new_xyz = gather_point(ctr_src, fps_idx)                            # :116-119
+    return fps_idx, new_xyz, sliced_points
+
+
+def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_training, bn_decay, bn,
+                           fps_sample_range_list, fps_method_list, npoint_list, former_fps_idx,
+                           use_attention, scope, dilated_group, vote_ctr=None, aggregation_channel=None,
+                           debugging=False, epsilon=1e-5, variables=None):
+    """layers_util.py:59-189.  xyz (B,n,3), points (B,n,C) -> new_xyz (B,m,3), new_points (B,m,C'),
+    fps_idx (B,m) int32."""
+    T.require(not use_attention, "use_attention (query_ball_point_withidx) is outside the 3DSSD SA path")
+    vs = variables or W.default_variables()
+    xyz = T.f32_cuda(xyz, "xyz")
+    points = T.f32_cuda(points, "points")
+    bs, n_all, _ = xyz.shape
+    dev = xyz.device
+
+    # ---- sampling (layers_util.py:84-119)
+    fps_idx, new_xyz, sliced_points = sample_layer(xyz, points, fps_sample_range_list, fps_method_list, npoint_list,
+                                                   former_fps_idx, vote_ctr, radius_list)
     m = new_xyz.shape[1]
     lib = N.lib()
     stream = N.current_stream()
