@@ -85,11 +85,12 @@ def test_kitti_backbone_teacher_forced(gpu, oracle, batch, n, dup):
         assert _rel(fl[li + 1], rf) < TOL, "features of row %d (%s): %g" % (li, row[12], _rel(fl[li + 1], rf))
 
 
-def test_kitti_backbone_free_running(gpu, oracle):
+@pytest.mark.parametrize("first_frame", [7, 41, 300, 1234])
+def test_kitti_backbone_free_running(gpu, oracle, first_frame):
     cfgs, syn = pkg("configs"), pkg("synthetic")
     arch = cfgs.KITTI_3DSSD_ARCH
     params = syn.random_backbone_params(arch)
-    pts = syn.kitti_like_batch(2, first_frame=7)
+    pts = syn.kitti_like_batch(2, first_frame=first_frame)
     xl, fl, il = _run_gpu(arch, params, pts, gpu)
     rxl, rfl, ril = oracle.sa_backbone(pts, arch, params, cfgs.KITTI_MAX_TRANSLATE_RANGE)
     # layer 1 (list index 1) is pure geometry: always bit-exact in the indices
@@ -97,9 +98,39 @@ def test_kitti_backbone_free_running(gpu, oracle):
     assert _rel(fl[1], rfl[1]) < TOL
     for li in range(2, len(rxl)):
         if ril[li] is not None and not np.array_equal(il[li], ril[li]):
-            # an F-FPS pick flipped on a ~1e-5 feature difference: everything downstream is a different
-            # (equally valid) point set; the teacher-forced test covers those layers
-            pytest.skip("free-running F-FPS diverged at list index %d (chaotic, expected occasionally)" % li)
+            # The pipeline is chaotic in its index outputs: an F-FPS pick that flips on a ~1e-5 feature difference
+            # re-orders everything downstream (the teacher-forced test covers those layers).  That is the ONLY
+            # divergence accepted here, and it is checked, not skipped: the first differing pick must be an F-FPS pick
+            # (a D-FPS pick is pure geometry on bit-identical centres) and a near tie under the ORACLE's own distances.
+            row = arch[li - 1]
+            frames, cols = np.nonzero(il[li] != ril[li])
+            col = int(cols.min())
+            frame = int(frames[cols == col][0])
+            xyz_in, feat_in = rxl[row[0][0]], rfl[row[1][0]]
+            last = out_col = 0
+            hit = None
+            for rng_, method, npoint in zip(row[6], row[7], row[8]):
+                end = xyz_in.shape[1] if rng_ == -1 else last + rng_
+                if npoint == 0:
+                    last += rng_
+                    continue
+                parts = [("F", npoint), ("D", npoint)] if method == "FS" else [("F" if method == "F-FPS" else "D", npoint)]
+                for kind, cnt in parts:
+                    if out_col <= col < out_col + cnt:
+                        hit = (kind, last, end, out_col)
+                    out_col += cnt
+                last += rng_
+            assert hit is not None and hit[0] == "F", "free-running indices differ at a D-FPS / identity pick: %r" % (hit,)
+            _kind, s0, e0, c0 = hit
+            fcat = np.concatenate([xyz_in[frame:frame + 1, s0:e0], feat_in[frame:frame + 1, s0:e0]], -1)
+            D = oracle.calc_square_dist(fcat, fcat)[0]
+            prev = ril[li][frame, c0:col] - s0                       # the picks both sides agree on
+            td = D[prev].min(0) if len(prev) else np.full(D.shape[0], 1e38, np.float32)
+            a, b_ = int(ril[li][frame, col] - s0), int(il[li][frame, col] - s0)
+            assert td[b_] >= td[a] * (1 - 2e-3) - 1e-6, "list index %d: the GPU's pick is not a near tie (%g vs %g)" % (li, td[b_], td[a])
+            print("free-running F-FPS flipped a near tie at list index %d, frame %d, pick %d (%.7g vs %.7g); downstream layers "
+                  "are covered by the teacher-forced test" % (li, frame, col - c0, td[b_], td[a]))
+            return
         assert _rel(fl[li], rfl[li]) < TOL, "list index %d: %g" % (li, _rel(fl[li], rfl[li]))
     assert _rel(xl[-1], rxl[-1]) < TOL
 
