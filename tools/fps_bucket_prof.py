@@ -12,12 +12,12 @@ m = 4096
 out = torch.empty((1, m), dtype=torch.int32, device=dev)
 h = (ctypes.c_ulonglong * 16)()
 lib.sa_debug_fpsb_prof.argtypes = [ctypes.c_void_p, ctypes.c_int]
-lib.sa_fps_bucket_ex.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 2 + [ctypes.c_int] * 2 + [ctypes.c_void_p]
+lib.sa_fps_bucket_ex2.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p] + [ctypes.c_int] * 2 + [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p]
 for rep in range(2):
     lib.sa_debug_fpsb_prof(None, 1)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    lib.sa_fps_bucket_ex(1, 16384, m, pts.data_ptr(), out.data_ptr(), m, 0, None)
+    lib.sa_fps_bucket_ex2(1, 16384, m, pts.data_ptr(), 0, out.data_ptr(), m, 0, None, 0, None)
     e.record(); torch.cuda.synchronize()
     lib.sa_debug_fpsb_prof(h, 0)
     v = list(h)
