@@ -203,3 +203,24 @@ def test_prob_sample_matches_oracle(gpu, oracle, b, n, m):
     out = torch.empty((b, m), dtype=torch.int32, device=gpu)
     assert N.lib().sa_prob_sample(b, n, m, tw.data_ptr(), tr.data_ptr(), temp.data_ptr(), out.data_ptr(), N.current_stream()) == 0
     assert np.array_equal(temp.cpu().numpy(), oracle.prob_sample(w, r, return_cumsum=True)[1])
+
+
+@pytest.mark.gpu
+def test_copy_blocks_matches_slicing(gpu):
+    # sa_copy_blocks: up to four strided block copies in one launch == torch slicing + contiguous()
+    N = pkg("utils._native")
+    rng = np.random.default_rng(5)
+    pc = _t(rng.normal(0, 1, (3, 700, 4)).astype(np.float32), gpu)
+    big = _t(rng.normal(0, 1, (3, 512, 37)).astype(np.float32), gpu)
+    xyz = torch.full((3, 700, 3), -1.0, device=gpu)
+    feat = torch.full((3, 700, 1), -1.0, device=gpu)
+    pre = torch.full((3, 200, 37), -1.0, device=gpu)
+    tail = torch.full((3, 100, 5), -1.0, device=gpu)
+    N.copy_blocks([(pc[:, :, 0:3], xyz, 3, 700, 3), (pc[:, :, 3:], feat, 3, 700, 1),
+                   (big[:, 56:256], pre, 3, 200, 37), (big[:, 412:, 30:35], tail, 3, 100, 5)])
+    torch.cuda.synchronize()
+    assert torch.equal(xyz, pc[:, :, 0:3]) and torch.equal(feat, pc[:, :, 3:])
+    assert torch.equal(pre, big[:, 56:256]) and torch.equal(tail, big[:, 412:, 30:35])
+    with pytest.raises(ValueError):
+        import ctypes
+        N.check(N.lib().sa_copy_blocks(5, (ctypes.c_long * 45)(), N.current_stream()), "copy_blocks")
