@@ -70,9 +70,8 @@ __device__ __forceinline__ void write_centres(const FpsSide &S, const float *src
 
 // ---- D-FPS, c == 3, n <= 1024*PPT, everything register resident ------------------------------
 template <int PPT>
-__global__ __launch_bounds__(kBlock) void fps3_reg_kernel(int n, int m, const float *__restrict__ inp,
-                                                          int *__restrict__ out, int out_stride,
-                                                          int idx_off, FpsSide S) {
+__device__ __forceinline__ void fps3_reg_body(int n, int m, const float *__restrict__ inp, int *__restrict__ out,
+                                              int out_stride, int idx_off, const FpsSide &S) {
     __shared__ float s_val[2][kWaves];
     __shared__ float4 s_pt[2][kWaves];
     const int b = blockIdx.x;
@@ -126,13 +125,17 @@ __global__ __launch_bounds__(kBlock) void fps3_reg_kernel(int n, int m, const fl
     }
     write_centres(S, p, o, m, idx_off, b, t, kBlock);
 }
+template <int PPT>
+__global__ __launch_bounds__(kBlock) void fps3_reg_kernel(int n, int m, const float *__restrict__ inp,
+                                                          int *__restrict__ out, int out_stride,
+                                                          int idx_off, FpsSide S) {
+    fps3_reg_body<PPT>(n, m, inp, out, out_stride, idx_off, S);
+}
 
 // ---- FPS on a precomputed [n,n] distance matrix (F-FPS), n <= 1024*PPT ------------------------
 template <int PPT>
-__global__ __launch_bounds__(kBlock) void fpsdist_reg_kernel(int n, int m,
-                                                             const float *__restrict__ dist,
-                                                             int *__restrict__ out, int out_stride,
-                                                             int idx_off, FpsSide S) {
+__device__ __forceinline__ void fpsdist_reg_body(int n, int m, const float *__restrict__ dist, int *__restrict__ out,
+                                                 int out_stride, int idx_off, const FpsSide &S) {
     __shared__ float s_val[2][kWaves];
     __shared__ float4 s_pt[2][kWaves];
     const int b = blockIdx.x;
@@ -178,6 +181,29 @@ __global__ __launch_bounds__(kBlock) void fpsdist_reg_kernel(int n, int m,
         if (t == 0) o[it] = old + idx_off;
     }
     if (S.xyz) write_centres(S, S.xyz + (size_t)b * S.xyz_bstride, o, m, idx_off, b, t, kBlock);
+}
+template <int PPT>
+__global__ __launch_bounds__(kBlock) void fpsdist_reg_kernel(int n, int m,
+                                                             const float *__restrict__ dist,
+                                                             int *__restrict__ out, int out_stride,
+                                                             int idx_off, FpsSide S) {
+    fpsdist_reg_body<PPT>(n, m, dist, out, out_stride, idx_off, S);
+}
+
+// The two samplers of an 'FS' layer (layers_util.py:93-98) -- or of a layer whose two ranges use F-FPS and D-FPS
+// (:101-106) -- in ONE launch: blockIdx.y == 0 runs the matrix sampler, blockIdx.y == 1 the coordinate sampler.  They are
+// independent serial chains on b workgroups each; side by side the launch lasts as long as the longer one (0.54 ms at
+// layer2 instead of 0.54 + 0.29), without a second stream.
+struct FpsDualArgs {
+    int n, m, out_stride, idx_off;
+    const float *src;       // distance matrix / coordinates
+    int *out;
+    FpsSide S;
+};
+template <int PPTF, int PPTD>
+__global__ __launch_bounds__(kBlock) void fps_dual_kernel(FpsDualArgs F, FpsDualArgs D) {
+    if (blockIdx.y == 0) fpsdist_reg_body<PPTF>(F.n, F.m, F.src, F.out, F.out_stride, F.idx_off, F.S);
+    else fps3_reg_body<PPTD>(D.n, D.m, D.src, D.out, D.out_stride, D.idx_off, D.S);
 }
 
 // ---- generic fallback: any c, any n; running min-distance in global `temp` like the reference --
@@ -494,6 +520,32 @@ extern "C" int sa_fps_with_distance_ex2(int b, int n, int m, const float *dist, 
 extern "C" int sa_fps_with_distance_ex(int b, int n, int m, const float *dist, float *temp, int *out,
                                        int out_stride, int idx_off, hipStream_t stream) {
     return sa_fps_with_distance_ex2(b, n, m, dist, temp, out, out_stride, idx_off, nullptr, 0, nullptr, 0, stream);
+}
+
+// F-FPS on dist [b, nf, nf] (mf picks, centres from xyz) and D-FPS on inp [b, nd, 3] (md picks) in one launch
+// (fps_dual_kernel).  Register-resident kernels with the same points-per-thread class only: SA_ERR_UNSUPPORTED
+// otherwise (the caller launches the two samplers one after the other).
+extern "C" int sa_fps_dual_ex(int b, int nf, int mf, const float *dist, int *out_f, int out_stride_f, int idx_off_f,
+                              const float *xyz_f, long xyz_bstride_f, float *ctr_f, long ctr_bstride_f, int nd, int md,
+                              const float *inp, long in_bstride, int *out_d, int out_stride_d, int idx_off_d,
+                              float *ctr_d, long ctr_bstride_d, hipStream_t stream) {
+    if (b <= 0 || nf <= 0 || mf <= 0 || nd <= 0 || md <= 0 || !dist || !inp || !out_f || !out_d || out_stride_f < mf ||
+        out_stride_d < md || (ctr_f && !xyz_f))
+        return SA_ERR_INVALID;
+    const int pf = ppt_for(nf), pd = ppt_for(nd);
+    if (pf != pd || pf > 4 || b > 65535) return SA_ERR_UNSUPPORTED;
+    FpsDualArgs F{}, D{};
+    F.n = nf; F.m = mf; F.out_stride = out_stride_f; F.idx_off = idx_off_f; F.src = dist; F.out = out_f;
+    F.S.ctr = ctr_f; F.S.ctr_bstride = ctr_bstride_f; F.S.xyz = ctr_f ? xyz_f : nullptr; F.S.xyz_bstride = xyz_bstride_f;
+    D.n = nd; D.m = md; D.out_stride = out_stride_d; D.idx_off = idx_off_d; D.src = inp; D.out = out_d;
+    D.S.in_bstride = in_bstride; D.S.ctr = ctr_d; D.S.ctr_bstride = ctr_bstride_d;
+    switch (pf) {
+        case 1: hipLaunchKernelGGL((fps_dual_kernel<1, 1>), dim3(b, 2), dim3(kBlock), 0, stream, F, D); break;
+        case 2: hipLaunchKernelGGL((fps_dual_kernel<2, 2>), dim3(b, 2), dim3(kBlock), 0, stream, F, D); break;
+        default: hipLaunchKernelGGL((fps_dual_kernel<4, 4>), dim3(b, 2), dim3(kBlock), 0, stream, F, D); break;
+    }
+    SA_CHECK_LAUNCH();
+    return SA_OK;
 }
 
 // Force the generic (global-temp) kernels: used by tests to cover the n > 16384 path at small n.

@@ -24,6 +24,8 @@ SIGNATURES = {
     "sa_fps_ex": [_c_int] * 4 + [_vp, _vp, _vp, _c_int, _c_int, _vp],
     "sa_fps_with_distance_ex": [_c_int] * 3 + [_vp, _vp, _vp, _c_int, _c_int, _vp],
     "sa_copy_blocks": [_c_int, _vp, _vp],
+    "sa_fps_dual_ex": [_c_int] * 3 + [_vp, _vp, _c_int, _c_int, _vp, _c_long, _vp, _c_long, _c_int, _c_int, _vp, _c_long, _vp,
+                       _c_int, _c_int, _vp, _c_long, _vp],
     "sa_group_mlp_max_layer": [_c_int] * 4 + [_vp, _c_int, _vp, _vp, _vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _vp,
                                _vp, _vp, _vp],
     "sa_fps_ex2": [_c_int] * 4 + [_vp, _c_long, _vp, _vp, _c_int, _c_int, _vp, _c_long, _vp],

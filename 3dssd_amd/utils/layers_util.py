@@ -28,14 +28,20 @@ AGGREGATION_SA_FEATURE = True
 # frames with at least this many points go through the grid ball query (csrc/ballquery_grid.hip)
 # sa_group_mlp_max flags: 0 = evaluate only the distinct rows of every ball (default), 1 = all nsample rows (A/B)
 # Where the D-FPS half of an 'FS' layer (and of a two-range layer) runs, SA_DFPS_SIDE_STREAM:
-#   2 (default)  on a helper stream, forked AFTER the F-FPS chain was enqueued and joined right behind it.  The two
+#   2            on a helper stream, forked AFTER the F-FPS chain was enqueued and joined right behind it.  The two
 #                halves still run back to back, but in a captured graph the D-FPS node sits on its own branch; with 16
 #                graphs in flight this form measured 8.3k frames/s against 6.5k with everything on one stream (0, 3).
 #   1            forked BEFORE the F-FPS chain: the two serial chains overlap, one batch's latency drops from 5.25 to
 #                4.9 ms, but the throughput with 16 graphs in flight HALVES (4.2k frames/s: parallel branches of many
 #                graphs compete for the hardware queues).  The right choice for single-frame latency.
 #   0 / 3        no helper stream (D-FPS first / F-FPS first);   4: every FPS kernel on the helper stream (= 2).
-DFPS_SIDE_STREAM = int(__import__("os").environ.get("SA_DFPS_SIDE_STREAM", "2"))
+#   5 / 6        the matrix sampler and the coordinate sampler of a layer in ONE launch (sa_fps_dual_ex), on the issuing
+#                stream / on the helper stream between a fork and a join event.  6 is the DEFAULT: the two chains really
+#                run side by side (layer2: 0.54 ms instead of 0.54 + 0.29; one batch 4.6 ms instead of 5.0) without a
+#                second concurrent queue, throughput as mode 2 (10.4 k frames/s), +5 % in a 20-step run; the same launch
+#                on the issuing stream (5) gives 7.9 k -- a captured graph WITHOUT a helper-stream branch loses a quarter
+#                of the 16-stream throughput (also seen with modes 0 / 3), for reasons inside the graph executor.
+DFPS_SIDE_STREAM = int(__import__("os").environ.get("SA_DFPS_SIDE_STREAM", "6"))
 # timing experiments only (tools/ablate.sh): comma-separated kernel classes whose launches are SKIPPED (results are
 # then garbage): mlp:<scope>, dense, sqdist, fpsdist, dfps:<n>, bq, plan
 _ABLATE = set(filter(None, __import__("os").environ.get("SA_ABLATE", "").split(",")))
@@ -76,7 +82,7 @@ def vote_layer(xyz, points, mlp_list, is_training, bn_decay, bn, scope, variable
 _UNSUPPORTED = -3
 
 
-def _ffps_into(npoint, xyz, points, start, end, out, col, ctr):
+def _ffps_into(npoint, xyz, points, start, end, out, col, ctr, matrix_only=False):
     """F-FPS on rows [start, end) of every frame: calc_square_dist(concat([xyz, feat])) +
     farthest_point_sample_with_distance (layers_util.py:94-96,102-104), written into out[:, col:col+npoint] with
     `start` added.  The range is read in place (no slice copy) and, when ctr = (tensor [b, total, 3]) is given, the
@@ -102,6 +108,8 @@ def _ffps_into(npoint, xyz, points, start, end, out, col, ctr):
                                                   keep[0].data_ptr(), keep[1].data_ptr(), dist.data_ptr(),
                                                   ws.data_ptr(), N.current_stream())
         N.check(st, "calc_square_dist")
+    if matrix_only:
+        return dist
     temp = torch.empty((b, n), dtype=torch.float32, device=dev) if n > 16384 else None
     done = [False]
 
@@ -258,6 +266,52 @@ def sample_layer(xyz, points, fps_sample_range_list, fps_method_list, npoint_lis
                 ok = _ffps_into(cnt // 2 if kind == "FS" else cnt, xyz, points, start, end, fps_idx, c0, new_xyz) and ok
         return ok
 
+    # ---- one matrix sampler + one coordinate sampler (an 'FS' range, or an F-FPS range and a D-FPS range): ONE launch
+    #      for both (sa_fps_dual_ex, modes 5 / 6); anything else takes the per-sampler path below
+    dual_done = f_handled = False
+    if DFPS_SIDE_STREAM in (5, 6) and "fpsdist" not in _ABLATE:
+        fparts = [(s0, e0, (c // 2 if k == "FS" else c), c0) for k, s0, e0, c, c0 in work if k in ("FS", "F-FPS")]
+        dparts = [(s0, e0, (c // 2 if k == "FS" else c), (c0 + c // 2 if k == "FS" else c0)) for k, s0, e0, c, c0 in work
+                  if k in ("FS", "D-FPS")]
+        if len(fparts) == 1 and len(dparts) == 1 and xyz.shape[2] == 3:
+            (fs, fe, fm, fc), (ds, de, dm, dc) = fparts[0], dparts[0]
+            dist = _ffps_into(fm, xyz, points, fs, fe, fps_idx, fc, new_xyz, matrix_only=True)
+            lib = N.lib()
+            cptr = (lambda col_: new_xyz.data_ptr() + 12 * col_) if new_xyz is not None else (lambda col_: None)
+            cstr = 3 * new_xyz.shape[1] if new_xyz is not None else 0
+
+            def dual():
+                return lib.sa_fps_dual_ex(bs, fe - fs, fm, dist.data_ptr(), fps_idx.data_ptr() + 4 * fc, fps_idx.shape[1], fs,
+                                          xyz.data_ptr() + 12 * fs, 3 * n_all, cptr(fc), cstr, de - ds, dm,
+                                          xyz.data_ptr() + 12 * ds, 3 * n_all, fps_idx.data_ptr() + 4 * dc, fps_idx.shape[1],
+                                          ds, cptr(dc), cstr, N.current_stream())
+            if DFPS_SIDE_STREAM == 6:                       # on the helper stream between a fork and a join event
+                hs = _side_stream(main)
+                ev = torch.cuda.Event()
+                ev.record(main)
+                hs.wait_event(ev)
+                with torch.cuda.stream(hs):
+                    st = dual()
+                ev2 = torch.cuda.Event()
+                ev2.record(hs)
+                main.wait_event(ev2)
+            else:
+                st = dual()
+            f_handled = True
+            if st != _UNSUPPORTED:
+                N.check(st, "fps_dual")
+                dual_done = True
+                centres_ok = centres_ok and new_xyz is not None
+                work = []
+            else:                                           # sizes the dual kernel does not take: sampler by sampler
+                st = lib.sa_fps_with_distance_ex(bs, fe - fs, fm, dist.data_ptr(), None, fps_idx.data_ptr() + 4 * fc,
+                                                 fps_idx.shape[1], fs, N.current_stream())
+                N.check(st, "farthest_point_sample_with_distance")
+                centres_ok = False
+                work = [wk for wk in work if wk[0] == "D-FPS"] + [("D-FPS", s0, e0, c // 2, c0 + c // 2)
+                                                                   for k, s0, e0, c, c0 in work if k == "FS"]
+    if dual_done:
+        side = None
     if DFPS_SIDE_STREAM in (2, 3):
         centres_ok = ffps_all() and centres_ok
     if side is not None:
@@ -273,7 +327,7 @@ def sample_layer(xyz, points, fps_sample_range_list, fps_method_list, npoint_lis
                     centres_ok = _dfps_into(d_n, xyz, start, end, fps_idx, d_col, new_xyz) and centres_ok
             else:
                 centres_ok = _dfps_into(d_n, xyz, start, end, fps_idx, d_col, new_xyz) and centres_ok
-    if DFPS_SIDE_STREAM not in (2, 3):                                      # F-FPS parts (:94-96,102-104)
+    if DFPS_SIDE_STREAM not in (2, 3) and not f_handled:                    # F-FPS parts (:94-96,102-104)
         centres_ok = ffps_all() and centres_ok
     if side is not None:
         ev = torch.cuda.Event()

@@ -89,6 +89,14 @@ int sa_fps_bucket_ex2(int b, int n, int m, const float *inp, long in_bstride, in
 int sa_fps_with_distance_ex2(int b, int n, int m, const float *dist, float *temp, int *out, int out_stride,
                              int idx_off, const float *xyz, long xyz_bstride, float *ctr, long ctr_bstride,
                              sa_stream_t stream);
+/* The matrix sampler (F-FPS on dist [b,nf,nf], mf picks, centres read from xyz_f) and the coordinate sampler (D-FPS on
+ * inp [b,nd,3], md picks) of one SA layer in ONE launch: two independent serial chains side by side, the launch lasts
+ * as long as the longer (layers_util.py:93-106).  Arguments as in the two _ex2 entry points.  SA_ERR_UNSUPPORTED unless
+ * both fit the register-resident kernels of the same points-per-thread class (n <= 4096). */
+int sa_fps_dual_ex(int b, int nf, int mf, const float *dist, int *out_f, int out_stride_f, int idx_off_f,
+                   const float *xyz_f, long xyz_bstride_f, float *ctr_f, long ctr_bstride_f, int nd, int md,
+                   const float *inp, long in_bstride, int *out_d, int out_stride_d, int idx_off_d, float *ctr_d,
+                   long ctr_bstride_d, sa_stream_t stream);
 /* Up to four strided block copies in one launch (the tf.slice calls of single_stage_detector.py:117-118 and
  * layers_util.py:85-86): jobs = host array of njobs records of 9 longs {src, dst, frames, rows, cols,
  * src_frame_stride, src_row_stride, dst_frame_stride, dst_row_stride}, pointers as integers, strides in floats;

@@ -91,6 +91,35 @@ def test_ffps_in_place_range_with_fused_centres(gpu, oracle):
     assert np.array_equal(ctr.cpu().numpy(), np.take_along_axis(xyz[:, start:end], ref[..., None].astype(np.int64), 1))
 
 
+@pytest.mark.parametrize("nf,nd,mf,md", [(512, 512, 256, 256), (4096, 4096, 512, 512), (2000, 1500, 300, 200)])
+def test_fps_dual_launch_equals_the_two_samplers(gpu, oracle, nf, nd, mf, md):
+    # sa_fps_dual_ex: the matrix sampler (range [0, nf)) and the coordinate sampler (range [n_all - nd, n_all)) of one layer
+    # in ONE launch, indices + centres of both into one tensor each == oracle F-FPS and D-FPS on the two ranges
+    N = pkg("utils._native")
+    rng = np.random.default_rng(nf + nd + mf)
+    b, c1 = 3, 24
+    n_all = max(nf, nd) + 77
+    xyz = _cloud(rng, b, n_all, dup=50)
+    feat = rng.normal(0, 1, (b, n_all, c1)).astype(np.float32)
+    tx = _t(xyz, gpu)
+    f = np.concatenate([xyz[:, :nf], feat[:, :nf]], -1)
+    ref_d = oracle.calc_square_dist(f, f)
+    dist = _t(ref_d, gpu)
+    ds = n_all - nd
+    idx = torch.full((b, mf + md), -1, dtype=torch.int32, device=gpu)
+    ctr = torch.full((b, mf + md, 3), -9.0, dtype=torch.float32, device=gpu)
+    st = N.lib().sa_fps_dual_ex(b, nf, mf, dist.data_ptr(), idx.data_ptr(), mf + md, 0, tx.data_ptr(), 3 * n_all, ctr.data_ptr(),
+                                3 * (mf + md), nd, md, tx.data_ptr() + 12 * ds, 3 * n_all, idx.data_ptr() + 4 * mf, mf + md, ds,
+                                ctr.data_ptr() + 12 * mf, 3 * (mf + md), N.current_stream())
+    assert st == 0
+    torch.cuda.synchronize()
+    rf = oracle.farthest_point_sample_with_distance(mf, ref_d)
+    rd = oracle.farthest_point_sample(md, np.ascontiguousarray(xyz[:, ds:])) + ds
+    ref = np.concatenate([rf, rd], 1)
+    assert np.array_equal(idx.cpu().numpy(), ref)
+    assert np.array_equal(ctr.cpu().numpy(), np.take_along_axis(xyz, ref[..., None].astype(np.int64), 1))
+
+
 def test_fps_all_points_identical(gpu, oracle):
     # every distance is 0: ties everywhere, the (k mod 1024, k) rule decides every pick
     S = pkg("utils.tf_ops.sampling.tf_sampling")
