@@ -229,3 +229,26 @@ def test_graph_replay_on_concurrent_streams_equals_eager(gpu, frames):
         torch.cuda.synchronize()
         for g, ox, of in graphs:
             assert torch.equal(ox, ref_xyz) and torch.equal(of, ref_feat), "round %d" % rnd
+
+
+def test_non_finite_inputs_do_not_hang_or_leave_the_index_range(gpu):
+    # The library is built -fno-honor-nans and documents non-finite inputs as unsupported: picks involving
+    # a NaN / Inf point are unspecified (the reference's comparisons simply never select them, tf_sampling_g.cu:151-157).
+    # What IS guaranteed and checked here: the kernels terminate, every index stays inside the frame, finite frames of the
+    # same batch are unaffected.
+    S, G = pkg("utils.tf_ops.sampling.tf_sampling"), pkg("utils.tf_ops.grouping.tf_grouping")
+    rng = np.random.default_rng(11)
+    for n, m in ((3000, 200), (16384, 512)):
+        p = rng.uniform(-10, 10, (2, n, 3)).astype(np.float32)
+        clean = p.copy()
+        p[0, 17] = np.nan
+        p[0, 99, 1] = np.inf
+        t = torch.from_numpy(p).to(gpu)
+        idx = S.farthest_point_sample(m, t).cpu().numpy()
+        assert idx.min() >= 0 and idx.max() < n
+        ref = S.farthest_point_sample(m, torch.from_numpy(clean).to(gpu)).cpu().numpy()
+        assert np.array_equal(idx[1], ref[1])                    # the finite frame of the batch is untouched
+        ctr = S.gather_point(t, torch.from_numpy(ref).to(gpu))
+        gi, gc = G.query_ball_point(1.0, 16, t, ctr)
+        gi, gc = gi.cpu().numpy(), gc.cpu().numpy()
+        assert gi.min() >= 0 and gi.max() < n and gc.min() >= 0 and gc.max() <= 16
