@@ -29,7 +29,7 @@ constexpr int kMaxBands = 4;
 #ifndef SA_BQ_PREFETCH
 #define SA_BQ_PREFETCH 1
 #endif
-constexpr int kQW = SA_BQ_QW;        // queries per wave
+constexpr int kQWmax = SA_BQ_QW;     // queries per wave of the throughput form (a small-problem form uses 2, see the launcher)
 constexpr int kWavesPerWG = 4;
 constexpr int kCH = SA_BQ_CH;        // 64-point steps held in registers per chunk
 constexpr int kRow = 64;      // max nsample of the fused kernel
@@ -45,6 +45,7 @@ struct Bands {
     int dilated;            // 1: d2 == 0 is always a hit (tf_grouping_g.cu:337)
 };
 
+template <int kQW>
 __global__ __launch_bounds__(kWavesPerWG * 64) void ball_query_kernel(
     int n, int m, const float *__restrict__ xyz1, const float *__restrict__ xyz2, Bands B) {
     __shared__ int s_rows[kWavesPerWG][kQW][kMaxBands][kRow];
@@ -263,9 +264,16 @@ extern "C" int sa_query_ball_point_multi(int b, int n, int m, int nbands, const 
             B.cnt[i] = on ? cnt[i] : nullptr;
             if (on && B.thi[i] > B.thi_max) B.thi_max = B.thi[i];
         }
-        const int qpw = kQW * kWavesPerWG;
+        // Queries per wave: 8 amortise a register chunk of points over many queries (the throughput form); the layers
+        // that take this kernel in the backbone are small (512 / 256 centres per frame: 64 waves per frame at 8), where
+        // the launch is one dependent scan per wave -- 2 queries per wave give 4x the waves and a quarter of the scan
+        // (layer3 0.068 -> 0.025 ms, layer4 0.032 -> 0.013 ms).
+        static const int cus = [] { int d = 0; hipDeviceProp_t pr; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
+        const bool small = (long)b * ((m + kQWmax - 1) / kQWmax) < 16l * cus;
+        const int qpw = (small ? 2 : kQWmax) * kWavesPerWG;
         dim3 grid((m + qpw - 1) / qpw, b);
-        hipLaunchKernelGGL(ball_query_kernel, grid, dim3(kWavesPerWG * 64), 0, stream, n, m, xyz1, xyz2, B);
+        if (small) hipLaunchKernelGGL(ball_query_kernel<2>, grid, dim3(kWavesPerWG * 64), 0, stream, n, m, xyz1, xyz2, B);
+        else hipLaunchKernelGGL(ball_query_kernel<kQWmax>, grid, dim3(kWavesPerWG * 64), 0, stream, n, m, xyz1, xyz2, B);
         SA_CHECK_LAUNCH();
     } else {
         for (int i = 0; i < nbands; ++i) {
