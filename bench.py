@@ -74,6 +74,10 @@ def _algorithmic(name, a):
     if name in ("sa_fps_with_distance_ex", "sa_fps_with_distance_ex2"):
         b, n, m = a[0:3]
         return 2 * b * (m - 1) * n, b * ((m - 1) * n * 4 + m * 4), "fps_with_distance n=%d->%d" % (n, m)
+    if name == "sa_fps_dual_ex":                     # matrix sampler || coordinate sampler, one launch
+        b, nf, mf, nd, md = a[0], a[1], a[2], a[11], a[12]
+        return (2 * b * (mf - 1) * nf + 11 * b * (md - 1) * nd,
+                b * ((mf - 1) * nf * 4 + mf * 4 + nd * 12 + md * 4), "fps_dual F n=%d->%d | D n=%d->%d" % (nf, mf, nd, md))
     if name == "sa_calc_square_dist_self_ws":
         b, n, c0, c1 = a[0:4]
         return 2 * b * n * n * (c0 + c1), b * (n * n * 4 + 2 * n * (c0 + c1) * 4), "calc_square_dist n=%d c=%d" % (n, c0 + c1)
