@@ -157,6 +157,65 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void ball_query_kernel(
     }
 }
 
+// Small frames (n <= 2048: layer3 / layer4 of the backbone, 1 024 / 512 points): ONE query per wave with the whole frame
+// in registers (NS steps of 64 points per lane), four times the waves of the chunked form above and no serial part
+// beyond the query itself.  The distances of a query are evaluated once, branch-free; a band is then NS ballots, a
+// running scalar count and one predicated store per step straight into the output row (hit h of the scan lands at slot
+// rank(h) = hits before it, the same "first nsample in index order" as the serial scan; slots >= cnt repeat the first
+// hit, tf_grouping_g.cu:245-248).  No LDS, no cross-lane traffic except the ballots.
+template <int NS>
+__global__ __launch_bounds__(kWavesPerWG * 64) void ball_query_small_kernel(
+    int n, int m, const float *__restrict__ xyz1, const float *__restrict__ xyz2, Bands B) {
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * kWavesPerWG + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (q >= m) return;
+    const float *P = xyz1 + (size_t)b * n * 3;
+    float x1[NS], y1[NS], z1[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int k = s * 64 + lane;
+        const int kk = k < n ? k : n - 1;
+        x1[s] = P[kk * 3 + 0]; y1[s] = P[kk * 3 + 1]; z1[s] = P[kk * 3 + 2];
+    }
+    const size_t qi = (size_t)b * m + q;
+    const float x2 = xyz2[qi * 3 + 0], y2 = xyz2[qi * 3 + 1], z2 = xyz2[qi * 3 + 2];
+    float d2[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const float dx = x2 - x1[s], dy = y2 - y1[s], dz = z2 - z1[s];
+        d2[s] = __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));
+        if (s * 64 + lane >= n) d2[s] = __builtin_inff();            // never a hit: not 0, not below any threshold
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int i = 0; i < B.nbands; ++i) {
+        // one predicate for both forms: dilated  d2 == 0 || (tlo <= d2 < thi)  ==  d2 < thi && (d2 >= tlo || d2 == 0)
+        // because thi > 0 always (rmax > 0); plain  d2 < thi  is the same with tlo = -inf
+        const float tlo = B.dilated ? B.tlo[i] : -__builtin_inff(), thi = B.thi[i];
+        const int nsi = B.ns[i];
+        int *row = B.idx[i] + qi * nsi;
+        int c = 0, first = 0;
+#pragma unroll
+        for (int g = 0; g < NS / 4; ++g) {
+            if (c < nsi) {                                               // tf_grouping_g.cu:237-239 (uniform)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int s = g * 4 + u;
+                    const bool hit = (d2[s] < thi) & ((d2[s] >= tlo) | (d2[s] == 0.0f));
+                    const unsigned long long hm = __ballot(hit);
+                    const int pos = c + (int)__popcll(hm & below);
+                    if (hit && pos < nsi) row[pos] = s * 64 + lane;
+                    first = (c == 0 && hm != 0ull) ? s * 64 + (int)__builtin_ctzll(hm) : first;
+                    c += (int)__popcll(hm);
+                }
+            }
+        }
+        c = c < nsi ? c : nsi;
+        if (lane >= c && lane < nsi) row[lane] = first;               // first == 0 for an empty ball (oracle decision D)
+        if (lane == 0) B.cnt[i][qi] = c;
+    }
+}
+
 // Fallback for nsample > 64: the reference's own shape, one thread per query, serial scan.
 __global__ void ball_query_serial_kernel(int b, int n, int m, float tlo, float thi, int dilated,
                                          int nsample, const float *__restrict__ xyz1,
@@ -268,6 +327,15 @@ extern "C" int sa_query_ball_point_multi(int b, int n, int m, int nbands, const 
         // that take this kernel in the backbone are small (512 / 256 centres per frame: 64 waves per frame at 8), where
         // the launch is one dependent scan per wave -- 2 queries per wave give 4x the waves and a quarter of the scan
         // (layer3 0.068 -> 0.025 ms, layer4 0.032 -> 0.013 ms).
+        static const bool small_form = !(getenv("SA_BQ_SMALL") && atoi(getenv("SA_BQ_SMALL")) == 0);
+        if (small_form && n <= 2048) {                       // one query per wave, the frame in registers
+            dim3 grid((m + kWavesPerWG - 1) / kWavesPerWG, b);
+            if (n <= 512) hipLaunchKernelGGL(ball_query_small_kernel<8>, grid, dim3(kWavesPerWG * 64), 0, stream, n, m, xyz1, xyz2, B);
+            else if (n <= 1024) hipLaunchKernelGGL(ball_query_small_kernel<16>, grid, dim3(kWavesPerWG * 64), 0, stream, n, m, xyz1, xyz2, B);
+            else hipLaunchKernelGGL(ball_query_small_kernel<32>, grid, dim3(kWavesPerWG * 64), 0, stream, n, m, xyz1, xyz2, B);
+            SA_CHECK_LAUNCH();
+            return SA_OK;
+        }
         static const int cus = [] { int d = 0; hipDeviceProp_t pr; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
         const bool small = (long)b * ((m + kQWmax - 1) / kQWmax) < 16l * cus;
         const int qpw = (small ? 2 : kQWmax) * kWavesPerWG;

@@ -766,110 +766,127 @@ __device__ __forceinline__ void dense_stage_load(const DenseParams &P, float (&s
 // One workgroup: 32 rows x (kDW*TG output tiles starting at tile blockIdx.y*kDW*TG).  Splitting the output
 // channels over blockIdx.y keeps >= 256 workgroups in flight for the short, wide aggregation layers
 // (2048 rows x 1536 -> 512 is only 64 row tiles).
+// dense_tile_accumulate: acc[tt] = bias + x[r0 .. r0+31, :] W for the wave's TG output tiles (D^T form: a lane holds row
+// r0 + (lane & 31), channels 8q + 4 * (lane >> 5) + e of the tile).  Ends with a barrier: `buf` is free on return.
 template <int TG>
-__device__ __forceinline__ void dense_body(const DenseParams &P, unsigned char *buf, int lane, int w,
-                                           int tid) {
+__device__ __forceinline__ void dense_tile_accumulate(const DenseParams &P, unsigned char *buf, long r0, int gb, int lane,
+                                                      int tid, f32x16 (&acc)[TG]) {
     const int half = lane >> 5, col = lane & 31;
     const LayerDesc &L = P.L;
     const int Kp = L.KS * 16;
-    const int gb = (blockIdx.y * kDW + w) * TG;
-    for (long r0 = (long)blockIdx.x * kRows; r0 < P.rows; r0 += (long)gridDim.x * kRows) {
-        f32x16 acc[TG];
 #pragma unroll
-        for (int tt = 0; tt < TG; ++tt) {
-            const int ct = min(gb + tt, L.NT - 1);
+    for (int tt = 0; tt < TG; ++tt) {
+        const int ct = min(gb + tt, L.NT - 1);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 bv = *(const float4 *)(L.bias + ct * 32 + 8 * q + 4 * half);
-                acc[tt][4 * q + 0] = bv.x; acc[tt][4 * q + 1] = bv.y;
-                acc[tt][4 * q + 2] = bv.z; acc[tt][4 * q + 3] = bv.w;
+        for (int q = 0; q < 4; ++q) {
+            const float4 bv = *(const float4 *)(L.bias + ct * 32 + 8 * q + 4 * half);
+            acc[tt][4 * q + 0] = bv.x; acc[tt][4 * q + 1] = bv.y;
+            acc[tt][4 * q + 2] = bv.z; acc[tt][4 * q + 3] = bv.w;
+        }
+    }
+    // The fp32 rows of chunk k0 + KC are requested (into registers) before the matrix work of chunk k0 starts, so
+    // their HBM/L2 latency overlaps it; one LDS buffer is enough (it is rewritten after the closing barrier).
+    float sv[kDStageIt][8];
+    dense_stage_load(P, sv, r0, 0, Kp, tid);
+    for (int k0 = 0; k0 < Kp; k0 += P.KC) {
+        const int kc = min(P.KC, Kp - k0);
+        const int G = kc / 8;
+#pragma unroll
+        for (int i = 0; i < kDStageIt; ++i) {
+            const int it = tid + i * kDThreads;
+            if (it < kRows * G) {
+                const int row = it / G, g = it - row * G;
+                uint4 hi, lo;
+                split8(sv[i], hi, lo);
+                unsigned char *dst = buf + row * P.stride + g * 32;
+                *(uint4 *)dst = hi;
+                *(uint4 *)(dst + 16) = lo;
             }
         }
-        // The fp32 rows of chunk k0 + KC are requested (into registers) before the matrix work of chunk k0 starts, so
-        // their HBM/L2 latency overlaps it; one LDS buffer is enough (it is rewritten after the closing barrier).
-        float sv[kDStageIt][8];
-        dense_stage_load(P, sv, r0, 0, Kp, tid);
-        for (int k0 = 0; k0 < Kp; k0 += P.KC) {
-            const int kc = min(P.KC, Kp - k0);
-            const int G = kc / 8;
+        __syncthreads();
+        if (k0 + P.KC < Kp) dense_stage_load(P, sv, r0, k0 + P.KC, Kp, tid);
+        if (gb < L.NT) {
+            // k-steps batched behind a scheduling barrier like mma_k_loop: one L2 round trip per KB k-steps
+            const unsigned char *arow = buf + col * P.stride + half * 32;
+            const int ks0 = k0 / 16, nks = kc / 16;
+            constexpr int KB = TG >= 4 ? 1 : (TG == 2 ? 2 : 4);
+            const uint4 *wb[TG];
 #pragma unroll
-            for (int i = 0; i < kDStageIt; ++i) {
-                const int it = tid + i * kDThreads;
-                if (it < kRows * G) {
-                    const int row = it / G, g = it - row * G;
-                    uint4 hi, lo;
-                    split8(sv[i], hi, lo);
-                    unsigned char *dst = buf + row * P.stride + g * 32;
-                    *(uint4 *)dst = hi;
-                    *(uint4 *)(dst + 16) = lo;
+            for (int tt = 0; tt < TG; ++tt)
+                wb[tt] = L.w + ((size_t)(min(gb + tt, L.NT - 1) * L.KS + ks0)) * 128 + lane;
+            for (int ksb = 0; ksb < nks; ksb += KB) {
+                uint4 wh[KB][TG], wl[KB][TG], ah[KB], al[KB];
+#pragma unroll
+                for (int d = 0; d < KB; ++d) {
+                    const int ks = ksb + d < nks ? ksb + d : nks - 1;
+#pragma unroll
+                    for (int tt = 0; tt < TG; ++tt) { wh[d][tt] = wb[tt][ks * 128]; wl[d][tt] = wb[tt][ks * 128 + 64]; }
+                    ah[d] = *(const uint4 *)(arow + ks * 64);
+                    al[d] = *(const uint4 *)(arow + ks * 64 + 16);
                 }
-            }
-            __syncthreads();
-            if (k0 + P.KC < Kp) dense_stage_load(P, sv, r0, k0 + P.KC, Kp, tid);
-            if (gb < L.NT) {
-                // k-steps batched behind a scheduling barrier like mma_k_loop: one L2 round trip per KB k-steps
-                const unsigned char *arow = buf + col * P.stride + half * 32;
-                const int ks0 = k0 / 16, nks = kc / 16;
-                constexpr int KB = TG >= 4 ? 1 : (TG == 2 ? 2 : 4);
-                const uint4 *wb[TG];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int tt = 0; tt < TG; ++tt)
-                    wb[tt] = L.w + ((size_t)(min(gb + tt, L.NT - 1) * L.KS + ks0)) * 128 + lane;
-                for (int ksb = 0; ksb < nks; ksb += KB) {
-                    uint4 wh[KB][TG], wl[KB][TG], ah[KB], al[KB];
+                for (int d = 0; d < KB; ++d) {
+                    if (ksb + d < nks) {
 #pragma unroll
-                    for (int d = 0; d < KB; ++d) {
-                        const int ks = ksb + d < nks ? ksb + d : nks - 1;
-#pragma unroll
-                        for (int tt = 0; tt < TG; ++tt) { wh[d][tt] = wb[tt][ks * 128]; wl[d][tt] = wb[tt][ks * 128 + 64]; }
-                        ah[d] = *(const uint4 *)(arow + ks * 64);
-                        al[d] = *(const uint4 *)(arow + ks * 64 + 16);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int d = 0; d < KB; ++d) {
-                        if (ksb + d < nks) {
-#pragma unroll
-                            for (int tt = 0; tt < TG; ++tt) {
-                                if (gb + tt < L.NT) {
-                                    acc[tt] = mfma_bf16(wh[d][tt], ah[d], acc[tt]);
-                                    acc[tt] = mfma_bf16(wl[d][tt], ah[d], acc[tt]);
-                                    acc[tt] = mfma_bf16(wh[d][tt], al[d], acc[tt]);
-                                }
+                        for (int tt = 0; tt < TG; ++tt) {
+                            if (gb + tt < L.NT) {
+                                acc[tt] = mfma_bf16(wh[d][tt], ah[d], acc[tt]);
+                                acc[tt] = mfma_bf16(wl[d][tt], ah[d], acc[tt]);
+                                acc[tt] = mfma_bf16(wh[d][tt], al[d], acc[tt]);
                             }
                         }
                     }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __syncthreads();
         }
-        const long r = r0 + col;
-        if (r < P.rows) {
+        __syncthreads();
+    }
+}
+
+// (ReLU and) write the wave's TG tiles of rows r0 .. r0+31; leaves the activated values in acc
+template <int TG>
+__device__ __forceinline__ void dense_tile_store(const DenseParams &P, long r0, int gb, int lane, f32x16 (&acc)[TG]) {
+    const int half = lane >> 5, col = lane & 31;
+    const LayerDesc &L = P.L;
+    const long r = r0 + col;
 #pragma unroll
-            for (int tt = 0; tt < TG; ++tt) {
-                if (gb + tt < L.NT) {
+    for (int tt = 0; tt < TG; ++tt) {
+        if (gb + tt < L.NT) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int c0 = (gb + tt) * 32 + 8 * q + 4 * half;
-                        float v[4];
+            for (int q = 0; q < 4; ++q) {
+                const int c0 = (gb + tt) * 32 + 8 * q + 4 * half;
+                float v[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[e] = acc[tt][4 * q + e];
-                            if (P.relu) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
-                        }
-                        float *o = P.y + r * L.N + c0;
-                        if ((L.N & 3) == 0 && c0 + 3 < L.N) {
-                            *(float4 *)o = make_float4(v[0], v[1], v[2], v[3]);
-                        } else {
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[tt][4 * q + e];
+                    if (P.relu) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
+                    acc[tt][4 * q + e] = v[e];
+                }
+                if (r < P.rows) {
+                    float *o = P.y + r * L.N + c0;
+                    if ((L.N & 3) == 0 && c0 + 3 < L.N) {
+                        *(float4 *)o = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (c0 + e < L.N) o[e] = v[e];
-                        }
+                        for (int e = 0; e < 4; ++e)
+                            if (c0 + e < L.N) o[e] = v[e];
                     }
                 }
             }
         }
+    }
+}
+
+template <int TG>
+__device__ __forceinline__ void dense_body(const DenseParams &P, unsigned char *buf, int lane, int w,
+                                           int tid) {
+    const int gb = (blockIdx.y * kDW + w) * TG;
+    for (long r0 = (long)blockIdx.x * kRows; r0 < P.rows; r0 += (long)gridDim.x * kRows) {
+        f32x16 acc[TG];
+        dense_tile_accumulate<TG>(P, buf, r0, gb, lane, tid, acc);
+        dense_tile_store<TG>(P, r0, gb, lane, acc);
     }
 }
 
@@ -879,6 +896,69 @@ __global__ __launch_bounds__(kDThreads) void dense_kernel(DenseParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     dense_body<TG>(P, smem, lane, w, tid);
+}
+
+// ---- vote_layer tail in ONE launch (layers_util.py:17-23): the last hidden conv1d (K -> H <= 128, BN folded, ReLU),
+//      the offset conv1d (H -> 3, no activation) and out = xyz + clip(offsets) -- three launches before.  A workgroup
+//      owns 32 rows: its four waves produce the 32 x H hidden tile exactly as dense_kernel<1> does (and write it, it is
+//      the layer's feature output), park it in LDS as the split-bf16 B operand of the next layer (what the second launch
+//      re-created from the fp32 tensor: the same bits), and wave 0 runs the H -> 3 layer with the same MFMA sequence
+//      and finishes the translation.  Bit-identical to the three-launch form.
+struct VoteTailParams {
+    DenseParams D;          // hidden layer (relu = 1)
+    LayerDesc L2;           // offset layer, N = 3
+    float *offsets;         // [rows, 3]
+    const float *xyz;       // [rows, 3]
+    float *out;             // [rows, 3]
+    float lo[3];
+};
+__global__ __launch_bounds__(kDThreads) void vote_tail_kernel(VoteTailParams V) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int half = lane >> 5, col = lane & 31;
+    const DenseParams &P = V.D;
+    const int stride2 = P.L.NT * 32 * 4 + 16;          // hidden tile rows in LDS: NT * 32 channels, hi/lo planes
+    for (long r0 = (long)blockIdx.x * kRows; r0 < P.rows; r0 += (long)gridDim.x * kRows) {
+        f32x16 acc[1];
+        dense_tile_accumulate<1>(P, smem, r0, w, lane, tid, acc);
+        dense_tile_store<1>(P, r0, w, lane, acc);
+        if (w < P.L.NT) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float v[4] = {acc[0][4 * q + 0], acc[0][4 * q + 1], acc[0][4 * q + 2], acc[0][4 * q + 3]};
+                store_quad<3>(smem + col * stride2 + (4 * w + q) * 32 + half * 8, v);
+            }
+        }
+        __syncthreads();
+        if (w == 0) {
+            const LayerDesc &L2 = V.L2;
+            f32x16 a2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bv = *(const float4 *)(L2.bias + 8 * q + 4 * half);
+                a2[4 * q + 0] = bv.x; a2[4 * q + 1] = bv.y; a2[4 * q + 2] = bv.z; a2[4 * q + 3] = bv.w;
+            }
+            const unsigned char *arow = smem + col * stride2 + half * 32;
+            const uint4 *wb = L2.w + lane;
+            for (int ks = 0; ks < L2.KS; ++ks) {
+                const uint4 wh = wb[ks * 128], wl = wb[ks * 128 + 64];
+                const uint4 ah = *(const uint4 *)(arow + ks * 64), al = *(const uint4 *)(arow + ks * 64 + 16);
+                a2 = mfma_bf16(wh, ah, a2);
+                a2 = mfma_bf16(wl, ah, a2);
+                a2 = mfma_bf16(wh, al, a2);
+            }
+            const long r = r0 + col;
+            if (half == 0 && r < P.rows) {
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                    const float o = a2[e];
+                    V.offsets[r * 3 + e] = o;
+                    V.out[r * 3 + e] = V.xyz[r * 3 + e] + sa::fmin_nn(sa::fmax_nn(o, V.lo[e]), -V.lo[e]);
+                }
+            }
+        }
+        __syncthreads();
+    }
 }
 
 // vote_layer tail (layers_util.py:21-23): out = xyz + clip(off, lo, -lo), lo = MAX_TRANSLATE_RANGE (< 0)
@@ -1284,6 +1364,37 @@ extern "C" int sa_dense(long rows, int K, int N, const float *x, const void *wpa
     if (P.tg == 1) hipLaunchKernelGGL(dense_kernel<1>, dim3(gx, ysplit), dim3(kDThreads), lds, stream, P);
     else if (P.tg == 2) hipLaunchKernelGGL(dense_kernel<2>, dim3(gx, ysplit), dim3(kDThreads), lds, stream, P);
     else hipLaunchKernelGGL(dense_kernel<4>, dim3(gx, ysplit), dim3(kDThreads), lds, stream, P);
+    SA_CHECK_LAUNCH();
+    return SA_OK;
+}
+
+// vote_layer tail: hidden = relu(x W1 + b1) [rows,H], offsets = hidden W2 + b2 [rows,3], out = xyz + clip(offsets, lo, -lo)
+// in one launch (vote_tail_kernel).  H <= 128 (one workgroup holds a 32-row hidden tile): SA_ERR_UNSUPPORTED otherwise,
+// the caller then uses sa_dense twice and sa_vote_translate.  Same bits as that three-launch form.
+extern "C" int sa_vote_tail(long rows, int K, int H, const float *x, const void *w1pack, const float *bias1,
+                            const void *w2pack, const float *bias2, float *hidden, float *offsets, const float *xyz,
+                            float lo_x, float lo_y, float lo_z, float *out, hipStream_t stream) {
+    if (rows <= 0 || K <= 0 || H <= 0 || !x || !w1pack || !bias1 || !w2pack || !bias2 || !hidden || !offsets || !xyz || !out)
+        return SA_ERR_INVALID;
+    if (H > kDW * 32) return SA_ERR_UNSUPPORTED;
+    VoteTailParams V{};
+    DenseParams &P = V.D;
+    P.x = x; P.y = hidden; P.rows = rows; P.relu = 1;
+    P.L.w = (const uint4 *)w1pack; P.L.bias = bias1; P.L.K = K; P.L.N = H;
+    P.L.KS = roundup(K, 16) / 16;
+    P.L.NT = roundup(H, 32) / 32;
+    P.KC = P.L.KS * 16 < 256 ? P.L.KS * 16 : 256;
+    P.stride = P.KC * 4 + 16;
+    P.tg = 1;
+    V.L2.w = (const uint4 *)w2pack; V.L2.bias = bias2; V.L2.K = H; V.L2.N = 3;
+    V.L2.KS = roundup(H, 16) / 16;
+    V.L2.NT = 1;
+    V.offsets = offsets; V.xyz = xyz; V.out = out;
+    V.lo[0] = lo_x; V.lo[1] = lo_y; V.lo[2] = lo_z;
+    const size_t lds1 = (size_t)kRows * P.stride, lds2 = (size_t)kRows * (P.L.NT * 32 * 4 + 16);
+    const long tiles = (rows + kRows - 1) / kRows;
+    hipLaunchKernelGGL(vote_tail_kernel, dim3((unsigned)(tiles < 8192 ? tiles : 8192)), dim3(kDThreads), lds1 > lds2 ? lds1 : lds2,
+                       stream, V);
     SA_CHECK_LAUNCH();
     return SA_OK;
 }

@@ -51,6 +51,9 @@ GRID_BALL_QUERY_MIN_N = int(__import__("os").environ.get("SA_GRID_BQ_MIN_N", "20
 MAX_TRANSLATE_RANGE = (-3.0, -2.0, -3.0)
 
 
+_UNSUPPORTED = -3
+
+
 def _dense(x, layer, relu):
     """tf_util.conv1d 1x1 (+ folded BN) (+ ReLU) on [..., K] -> [..., N]."""
     rows = x.numel() // layer.K
@@ -68,18 +71,33 @@ def vote_layer(xyz, points, mlp_list, is_training, bn_decay, bn, scope, variable
     vs = variables or W.default_variables()
     xyz = T.f32_cuda(xyz, "xyz")
     points = T.f32_cuda(points, "points")
-    for i, _channel in enumerate(mlp_list):
-        points = _dense(points, vs.layer("%s/vote_layer_%d" % (scope, i), bn), relu=True)
-    ctr_offsets = _dense(points, vs.layer(scope + "/vote_offsets", False), relu=False)
+    hidden = [vs.layer("%s/vote_layer_%d" % (scope, i), bn) for i, _channel in enumerate(mlp_list)]
+    last = vs.layer(scope + "/vote_offsets", False)
     out = torch.empty_like(xyz)
     lo = MAX_TRANSLATE_RANGE
+    for layer in hidden[:-1]:
+        points = _dense(points, layer, relu=True)
+    if hidden and "dense" not in _ABLATE:
+        # the last hidden layer, the offset layer and the translation in one launch (three before)
+        h = hidden[-1]
+        rows = points.numel() // h.K
+        feats = torch.empty(points.shape[:-1] + (h.N,), dtype=torch.float32, device=points.device)
+        ctr_offsets = torch.empty(points.shape[:-1] + (3,), dtype=torch.float32, device=points.device)
+        st = N.lib().sa_vote_tail(rows, h.K, h.N, points.data_ptr(), h.w.data_ptr(), h.bias.data_ptr(), last.w.data_ptr(),
+                                  last.bias.data_ptr(), feats.data_ptr(), ctr_offsets.data_ptr(), xyz.data_ptr(),
+                                  float(lo[0]), float(lo[1]), float(lo[2]), out.data_ptr(), N.current_stream())
+        if st != _UNSUPPORTED:
+            N.check(st, "vote_tail")
+            return out, feats, ctr_offsets
+    if hidden:
+        points = _dense(points, hidden[-1], relu=True)
+    ctr_offsets = _dense(points, last, relu=False)
     st = N.lib().sa_vote_translate(xyz.numel() // 3, xyz.data_ptr(), ctr_offsets.data_ptr(), float(lo[0]),
                                    float(lo[1]), float(lo[2]), out.data_ptr(), N.current_stream())
     N.check(st, "vote_translate")
     return out, points, ctr_offsets
 
 
-_UNSUPPORTED = -3
 
 
 def _ffps_into(npoint, xyz, points, start, end, out, col, ctr, matrix_only=False):

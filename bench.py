@@ -117,6 +117,9 @@ def _algorithmic(name, a):
         return 0, b * m * (2 * c * 4 + 4), "gather_point m=%d c=%d" % (m, c)
     if name == "sa_vote_translate":
         return 0, a[0] * 36, "vote_translate"
+    if name == "sa_vote_tail":                       # hidden conv1d + offset conv1d + translation, one launch
+        rows, K, H = a[0:3]
+        return 2 * rows * (K * H + H * 3), rows * (K + H + 3 + 3 + 3) * 4 + (K * H + H * 3) * 4, "vote_tail %dx%d->%d->3" % (rows, K, H)
     return 0, 0, name
 
 
@@ -216,7 +219,7 @@ def _pmc_mlp_util():
 
 def roofline_of(stage, frames):
     k = stage["kernel"]
-    if k in ("sa_group_mlp_max", "sa_group_mlp_max_layer", "sa_dense", "sa_calc_square_dist_split", "sa_calc_square_dist_split_ws", "sa_calc_square_dist_self_ws"):
+    if k in ("sa_group_mlp_max", "sa_group_mlp_max_layer", "sa_dense", "sa_vote_tail", "sa_calc_square_dist_split", "sa_calc_square_dist_split_ws", "sa_calc_square_dist_self_ws"):
         peak = MFMA_BF16_PEAK_TF if not k.startswith("sa_calc_square_dist") else VALU_F32_PEAK_TF
         a = stage.get("tflops", 0.0)
         return dict(kernel=stage["label"], bound="mfma", achieved=a, peak=peak, unit="TFLOP/s",
@@ -464,7 +467,7 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
         bq_ms = sum(s["avg_ms"] * s["calls_per_step"] for s in bq)
         bq_mb = sum(s["mbytes"] * s["calls_per_step"] for s in bq)
         gflop_step = sum(s["gflop"] * s["calls_per_step"] for s in stages
-                         if s["kernel"] in ("sa_group_mlp_max", "sa_group_mlp_max_layer", "sa_dense"))
+                         if s["kernel"] in ("sa_group_mlp_max", "sa_group_mlp_max_layer", "sa_dense", "sa_vote_tail"))
         mb_step = sum(s["mbytes"] * s["calls_per_step"] for s in stages)
         line["roofline"] = roofline_of(dom, len(frames))
         line["whole_step"] = {

@@ -175,6 +175,12 @@ int sa_dense(long rows, int K, int N, const float *x, const void *wpack, const f
 /* vote_layer tail (layers_util.py:21-23): out = xyz + clip(off, lo, -lo), lo = MAX_TRANSLATE_RANGE. */
 int sa_vote_translate(long npoints, const float *xyz, const float *off, float lo_x, float lo_y,
                       float lo_z, float *out, sa_stream_t stream);
+/* The whole vote_layer tail in one launch (layers_util.py:17-23): hidden = relu(x W1 + b1) [rows,H] (the layer's
+ * feature output), offsets = hidden W2 + b2 [rows,3] (no activation), out = xyz + clip(offsets, lo, -lo).  The same
+ * bits as sa_dense, sa_dense, sa_vote_translate.  H <= 128: SA_ERR_UNSUPPORTED otherwise. */
+int sa_vote_tail(long rows, int K, int H, const float *x, const void *w1pack, const float *bias1, const void *w2pack,
+                 const float *bias2, float *hidden, float *offsets, const float *xyz, float lo_x, float lo_y,
+                 float lo_z, float *out, sa_stream_t stream);
 
 /* ---- next row after the backbone: TF graph code in the reference ------------------- */
 

@@ -352,6 +352,38 @@ def test_ball_query_multi_band_equals_single_band(gpu, oracle):
         _check_ball(idx[i].cpu().numpy(), cnt[i].cpu().numpy(), ridx, rcnt)
 
 
+@pytest.mark.parametrize("n,m,dil", [(1, 3, 1), (63, 5, 0), (64, 9, 1), (65, 130, 1), (512, 256, 0), (513, 33, 1), (1024, 512, 1),
+                                     (1025, 77, 0), (2048, 101, 1)])
+def test_ball_query_one_query_per_wave_form(gpu, oracle, n, m, dil):
+    # n <= 2048 takes ball_query_small_kernel (the layer3 / layer4 shapes of the backbone): every register-step count,
+    # ragged last step, bands of 1..64 samples that fill early or never, duplicated points, empty balls
+    import ctypes
+    N = pkg("utils._native")
+    rng = np.random.default_rng(n * 7 + m)
+    b = 3
+    xyz1 = _cloud(rng, b, n, scale=4.0, dup=n // 8)
+    near = xyz1[:, rng.integers(0, n, m - m // 3)] + rng.normal(0, 0.05, (b, m - m // 3, 3)).astype(np.float32)
+    near[:, ::5] = xyz1[:, rng.integers(0, n, (m - m // 3 + 4) // 5)]          # centres that ARE points: d2 == 0
+    xyz2 = np.concatenate([near, _cloud(rng, b, m // 3, scale=40.0)], 1).astype(np.float32)   # far ones: empty balls
+    radii, nss = [0.3, 0.9, 2.5, 40.0], [1, 17, 64, 32]
+    lo = [0.0] + radii[:-1]
+    t1, t2 = _t(xyz1, gpu), _t(xyz2, gpu)
+    idx = [torch.full((b, m, s_), -1, dtype=torch.int32, device=gpu) for s_ in nss]
+    cnt = [torch.full((b, m), -1, dtype=torch.int32, device=gpu) for _ in nss]
+    st = N.lib().sa_query_ball_point_multi(
+        b, n, m, 4, (ctypes.c_float * 4)(*lo), (ctypes.c_float * 4)(*radii), (ctypes.c_int * 4)(*nss), dil,
+        t1.data_ptr(), t2.data_ptr(), (ctypes.c_void_p * 4)(*[t.data_ptr() for t in idx]),
+        (ctypes.c_void_p * 4)(*[t.data_ptr() for t in cnt]), N.current_stream())
+    assert st == 0
+    for i in range(4):
+        if dil:
+            ridx, rcnt = oracle.query_ball_point_dilated(lo[i], radii[i], nss[i], xyz1, xyz2)
+        else:
+            ridx, rcnt = oracle.query_ball_point(radii[i], nss[i], xyz1, xyz2)
+        _check_ball(idx[i].cpu().numpy(), cnt[i].cpu().numpy(), ridx, rcnt)
+    assert (cnt[0].cpu().numpy() == 0).any() and (cnt[3].cpu().numpy() == min(32, n)).any()
+
+
 # ----------------------------------------------------------------------------------- sqdist
 @pytest.mark.parametrize("n,m,c", [(5, 7, 3), (64, 64, 67), (300, 200, 131), (512, 512, 16)])
 def test_calc_square_dist_bit_exact(gpu, oracle, n, m, c):
@@ -633,6 +665,44 @@ def test_dense(gpu, oracle, rows, K, N, relu):
     ref = oracle.dense(x, w, bias, relu)
     err = np.abs(y.cpu().numpy() - ref).max() / np.abs(ref).max()
     assert err < MLP_TOL, "relative error %g" % err
+
+
+@pytest.mark.parametrize("rows,K,H", [(2048, 256, 128), (70, 100, 64), (33, 16, 40), (1, 300, 128)])
+def test_vote_tail_one_launch_equals_the_three_launches(gpu, oracle, rows, K, H):
+    # sa_vote_tail == sa_dense (ReLU) -> sa_dense (H -> 3) -> sa_vote_translate, bit for bit, and within the MLP bar of
+    # the oracle's vote layer
+    N_ = pkg("utils._native")
+    Wt = pkg("utils.weights")
+    rng = np.random.default_rng(rows + K + H)
+    x = rng.normal(0, 1, (rows, K)).astype(np.float32)
+    xyz = rng.uniform(-30, 30, (rows, 3)).astype(np.float32)
+    w1 = rng.normal(0, 1 / np.sqrt(K), (K, H)).astype(np.float32)
+    b1 = rng.normal(0, 0.2, H).astype(np.float32)
+    w2 = rng.normal(0, 4 / np.sqrt(H), (H, 3)).astype(np.float32)          # offsets beyond the clip range on some rows
+    b2 = rng.normal(0, 0.5, 3).astype(np.float32)
+    L1, L2 = Wt.PackedLayer(w1, b1, gpu), Wt.PackedLayer(w2, b2, gpu)
+    tx, tp = _t(x, gpu), _t(xyz, gpu)
+    lo = (-3.0, -2.0, -3.0)
+    lib, st = N_.lib(), N_.current_stream()
+    f32 = lambda *sh: torch.full(sh, -77.0, dtype=torch.float32, device=gpu)
+    h_a, o_a, out_a, h_b, o_b, out_b = f32(rows, H), f32(rows, 3), f32(rows, 3), f32(rows, H), f32(rows, 3), f32(rows, 3)
+    assert lib.sa_dense(rows, K, H, tx.data_ptr(), L1.w.data_ptr(), L1.bias.data_ptr(), 1, h_a.data_ptr(), st) == 0
+    assert lib.sa_dense(rows, H, 3, h_a.data_ptr(), L2.w.data_ptr(), L2.bias.data_ptr(), 0, o_a.data_ptr(), st) == 0
+    assert lib.sa_vote_translate(rows, tp.data_ptr(), o_a.data_ptr(), *lo, out_a.data_ptr(), st) == 0
+    assert lib.sa_vote_tail(rows, K, H, tx.data_ptr(), L1.w.data_ptr(), L1.bias.data_ptr(), L2.w.data_ptr(), L2.bias.data_ptr(),
+                            h_b.data_ptr(), o_b.data_ptr(), tp.data_ptr(), *lo, out_b.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    for a, b_ in ((h_a, h_b), (o_a, o_b), (out_a, out_b)):
+        assert np.array_equal(a.cpu().numpy().view(np.uint32), b_.cpu().numpy().view(np.uint32))
+    ref_h = oracle.dense(x, w1, b1, True)
+    ref_o = oracle.dense(ref_h, w2, b2, False)
+    assert np.abs(h_b.cpu().numpy() - ref_h).max() / np.abs(ref_h).max() < MLP_TOL
+    assert np.abs(o_b.cpu().numpy() - ref_o).max() / np.abs(ref_o).max() < MLP_TOL
+    o = o_b.cpu().numpy()
+    assert np.array_equal(out_b.cpu().numpy(), xyz + np.minimum(np.maximum(o, np.float32(lo)), -np.float32(lo)))
+    assert (np.abs(o) > 3.0).any()
+    assert lib.sa_vote_tail(rows, K, 160, tx.data_ptr(), L1.w.data_ptr(), L1.bias.data_ptr(), L2.w.data_ptr(), L2.bias.data_ptr(),
+                            h_b.data_ptr(), o_b.data_ptr(), tp.data_ptr(), *lo, out_b.data_ptr(), st) == -3
 
 
 # ----------------------------------------------------------------------------------- API behaviour
