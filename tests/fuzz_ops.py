@@ -92,7 +92,7 @@ def case_gather(rng):
 
 
 def case_ball(rng):
-    b, n = int(rng.integers(1, 3)), int(rng.choice([1, 30, 64, 511, 512, 513, 2000, 5000]))
+    b, n = int(rng.integers(1, 3)), int(rng.choice([1, 30, 64, 65, 511, 512, 513, 1024, 1025, 2000, 2048, 2049, 5000]))
     m, ns = int(rng.integers(1, 200)), int(rng.choice([1, 2, 16, 32, 33, 64, 65, 100, 300]))
     xyz = cloud(rng, b, n, 3, dup=float(rng.choice([0, 0.2])), lattice=bool(rng.integers(0, 2)))
     ctr = xyz[:, rng.integers(0, n, m)] + (rng.normal(0, 0.2, (b, m, 3)).astype(np.float32) if rng.integers(0, 2) else 0)
@@ -219,6 +219,28 @@ def case_misc(rng):
     gi = rng.integers(-1, n, (b, m, 6)).astype(np.int32)
     gg = rng.integers(-4, 5, (b, m, 6, c)).astype(np.float32)
     return eq("group_point_grad", G.group_point_grad(t(inp), t(gi), t(gg)), O.group_point_grad(inp, gi, gg), (b, n, c, m))
+
+
+def case_vote_tail(rng):
+    # sa_vote_tail against the three launches it replaces: the same bits
+    rows, K, H = int(rng.choice([1, 31, 32, 33, 500, 2048])), int(rng.choice([1, 16, 100, 256, 300])), int(rng.choice([1, 3, 32, 40, 64, 128]))
+    x = rng.normal(0, 1, (rows, K)).astype(np.float32)
+    xyz = rng.uniform(-30, 30, (rows, 3)).astype(np.float32)
+    L1 = Wt.PackedLayer(rng.normal(0, 1 / np.sqrt(K), (K, H)).astype(np.float32), rng.normal(0, 0.2, H).astype(np.float32), dev)
+    L2 = Wt.PackedLayer(rng.normal(0, 3 / np.sqrt(H), (H, 3)).astype(np.float32), rng.normal(0, 0.5, 3).astype(np.float32), dev)
+    tx, tp, lo = t(x), t(xyz), (-3.0, -2.0, -3.0)
+    lib, st = N.lib(), N.current_stream()
+    new = lambda *sh: torch.full(sh, -5.0, dtype=torch.float32, device=dev)
+    h_a, o_a, out_a, h_b, o_b, out_b = new(rows, H), new(rows, 3), new(rows, 3), new(rows, H), new(rows, 3), new(rows, 3)
+    ok = lib.sa_dense(rows, K, H, tx.data_ptr(), L1.w.data_ptr(), L1.bias.data_ptr(), 1, h_a.data_ptr(), st) == 0
+    ok = ok and lib.sa_dense(rows, H, 3, h_a.data_ptr(), L2.w.data_ptr(), L2.bias.data_ptr(), 0, o_a.data_ptr(), st) == 0
+    ok = ok and lib.sa_vote_translate(rows, tp.data_ptr(), o_a.data_ptr(), *lo, out_a.data_ptr(), st) == 0
+    ok = ok and lib.sa_vote_tail(rows, K, H, tx.data_ptr(), L1.w.data_ptr(), L1.bias.data_ptr(), L2.w.data_ptr(), L2.bias.data_ptr(),
+                                 h_b.data_ptr(), o_b.data_ptr(), tp.data_ptr(), *lo, out_b.data_ptr(), st) == 0
+    if not ok:
+        return "vote_tail: a launch failed %r" % ((rows, K, H),)
+    return (eq("vote_tail hidden", h_b, h_a.cpu().numpy(), (rows, K, H)) or eq("vote_tail offsets", o_b, o_a.cpu().numpy(), (rows, K, H))
+            or eq("vote_tail out", out_b, out_a.cpu().numpy(), (rows, K, H)))
 
 
 def case_fps_big(rng):
@@ -370,7 +392,7 @@ def case_prob_iou(rng):
 
 
 CASES = [case_fps, case_fps, case_fps_dist, case_fps_preidx, case_gather, case_ball, case_ball, case_sqdist, case_mlp, case_mlp,
-         case_mlp, case_interp, case_boxes, case_misc, case_pooling, case_prob_iou]
+         case_mlp, case_interp, case_boxes, case_misc, case_pooling, case_prob_iou, case_vote_tail]
 
 
 def main():
