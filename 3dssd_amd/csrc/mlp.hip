@@ -393,7 +393,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? SA_MLP_WPE8 : 4) void group_mlp_
     const int G0 = P.L[0].KS * 2;                     // 8-channel groups of the input tile
     SA_T0();
 
-    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    int istride;
+    const int item0 = sa::xcd_block(blockIdx.x, gridDim.x, nitems, istride);
+    if (item0 < 0) return;
+    for (int item = item0; item < nitems; item += istride) {
         SA_COUNT(0);
         SA_COUNT(1);
         // ---- gather the [32 rows x cin] input tile (features first, then relative xyz:
@@ -699,7 +702,12 @@ __global__ __launch_bounds__(kThreads, 2) void group_mlp_wide_kernel(WideParams 
     const int G0 = P.L[0].KS * 2;
     const int tgl = (LL.NT + kNW - 1) / kNW;
 
-    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    // XCD x takes a contiguous eighth of every pass over the items (sa::xcd_block): a frame's feature rows go to one
+    // or two L2s, not eight
+    int istride;
+    const int item0 = sa::xcd_block(blockIdx.x, gridDim.x, nitems, istride);
+    if (item0 < 0) return;
+    for (int item = item0; item < nitems; item += istride) {
         gather_tile<kWRows, kThreads, PR>(P, bufA, P.strideA, item, ngran, G0, tid);
         int ent[2][4], cn[2][4];
 #pragma unroll

@@ -248,7 +248,9 @@ __device__ __forceinline__ void rw_body(const RwParams &P) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ngran = __builtin_amdgcn_readfirstlane(P.hdr[0]);
     const int ntiles = (ngran + 3) >> 2;
-    if ((int)blockIdx.x * NW >= ntiles) return;          // persistent grid sized for the densest plan: no work, no copy
+    int gstride;                                         // XCD x takes a contiguous eighth of every pass over the tiles
+    const int bx = sa::xcd_block(blockIdx.x, gridDim.x, (ntiles + NW - 1) / NW, gstride);
+    if (bx < 0 || bx * NW >= ntiles) return;             // persistent grid sized for the densest plan: no work, no copy
     RW_T0();
     // one-time copy of the packed weights and biases: all loads of a layer are issued before its stores
     {
@@ -278,7 +280,7 @@ __device__ __forceinline__ void rw_body(const RwParams &P) {
     //  tools/microbench/mfma_valu_overlap.hip.  Neither unequal s_setprio priorities nor staggered wave starts
     //  changed the measured time of these kernels: it tracks MFMA-busy + VALU-issue cycles.)
     const int row = lane & 31, half = lane >> 5;
-    const int gw = blockIdx.x * NW + w, nwaves = gridDim.x * NW;
+    const int gw = bx * NW + w, nwaves = gstride * NW;
     if (gw >= ntiles) return;
     // this wave's tiles: gw, gw + nwaves, ...  Cursors of the three pipeline stages: compute (tc), feature loads (one
     // tile ahead), index loads (two ahead); past the end they stay on the last tile.
@@ -510,7 +512,9 @@ __device__ __forceinline__ void rs_body(const RwParams &P) {
 
     const int ngran = __builtin_amdgcn_readfirstlane(P.hdr[0]);
     const int ntiles = (ngran + 3) >> 2;
-    if ((int)blockIdx.x * NW >= ntiles) return;          // persistent grid sized for the densest plan
+    int gstride;                                         // XCD x takes a contiguous eighth of every pass over the tiles
+    const int bx = sa::xcd_block(blockIdx.x, gridDim.x, (ntiles + NW - 1) / NW, gstride);
+    if (bx < 0 || bx * NW >= ntiles) return;             // persistent grid sized for the densest plan
 
     for (int i = tid; i < NT1 * 32; i += NW * 64) b0[i] = P.bias[0][i];
     for (int i = tid; i < NT2 * 32; i += NW * 64) b1[i] = P.bias[1][i];
@@ -519,8 +523,8 @@ __device__ __forceinline__ void rs_body(const RwParams &P) {
 
     // every wave of a workgroup runs the same number of tiles (barriers inside); tiles past the end resolve to
     // invalid plan entries (ball 0 is read, nothing is written)
-    const int nwaves = gridDim.x * NW, gw = blockIdx.x * NW + w;
-    const int npass = (ntiles - (int)blockIdx.x * NW + nwaves - 1) / nwaves;
+    const int nwaves = gstride * NW, gw = bx * NW + w;
+    const int npass = (ntiles - bx * NW + nwaves - 1) / nwaves;
     int tc = gw, tf = gw + nwaves;
 
     // ---- prologue: chunk 0 into slot 0, chunks 1 .. DEPTH staged; first tile's rows and features

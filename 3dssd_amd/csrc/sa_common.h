@@ -89,4 +89,21 @@ __device__ __forceinline__ void bf16_split(float x, unsigned &hi, unsigned &lo) 
     lo = bf16_rne_bits(r);
 }
 
+// ---- workgroup id -> position in the work list, XCD-aware ---------------------------------------------
+// Block b of a launch is observed to run on XCD b % 8 (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement": a
+// speed hint, no contract).  Kernels that walk a list in frame order take their position from xcd_block() instead of
+// blockIdx.x: of the G workgroups launched, the first A8 = roundup8(min(G, need)) take part (`need` = workgroups that
+// have work in the first pass -- grids are sized for the densest row plan, the plan at hand is usually shorter -- so the
+// work stays spread over all eight XCDs), and the A8 / 8 of them on one XCD get CONTIGUOUS positions: every pass over
+// the list gives an XCD one contiguous eighth, a frame's points and features are fetched into one or two of the eight
+// L2s instead of all of them.  Returns the position (a bijection of [0, A8)), -1 for a workgroup that sits out, and the
+// stride between passes; the identity with stride G when A8 does not fit the grid.  A wrong guess about the placement
+// only costs the saving.
+__device__ __forceinline__ int xcd_block(int b, int G, int need, int &stride) {
+    const int A8 = ((need < G ? need : G) + 7) & ~7;
+    if (A8 > G || A8 == 0) { stride = G; return b; }
+    stride = A8;
+    return b >= A8 ? -1 : (b & 7) * (A8 >> 3) + (b >> 3);
+}
+
 }  // namespace sa
