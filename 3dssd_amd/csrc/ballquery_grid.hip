@@ -149,7 +149,15 @@ __global__ __launch_bounds__(kQWaves * 64) void bq_grid_query_kernel(int n, int 
                                                                      const float *__restrict__ xyz2,
                                                                      const int *__restrict__ ws, GBands B) {
     __shared__ int s_hits[kQWaves][kMaxBands][kCap];
-    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    int b = blockIdx.y, bx = blockIdx.x;
+    if ((gridDim.x & 7) == 0 && (gridDim.y & 7) == 0) {
+        // XCD-aware (block L is observed to run on XCD L % 8, sa_common.h): the queries of frame f run on XCD f % 8, whose L2
+        // then holds that frame's points, cell table and sorted list alone
+        const unsigned L = blockIdx.y * gridDim.x + blockIdx.x, G8 = 8u * gridDim.x;
+        b = (int)(8u * (L / G8) + (L & 7u));
+        bx = (int)((L % G8) >> 3);
+    }
+    const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // wave-uniform: the per-query loads are scalar
     const float *P = xyz1 + (size_t)b * n * 3;
     const int *cell_start = ws + (size_t)b * ws_stride(n);
@@ -158,7 +166,7 @@ __global__ __launch_bounds__(kQWaves * 64) void bq_grid_query_kernel(int n, int 
     const float mnx = params[0], mnz = params[1], inv = params[2];
     int (*hits)[kCap] = s_hits[w];
 
-    for (int q = blockIdx.x * kQWaves + w; q < m; q += gridDim.x * kQWaves) {
+    for (int q = bx * kQWaves + w; q < m; q += gridDim.x * kQWaves) {
         const size_t qi = (size_t)b * m + q;
         const float x2 = xyz2[qi * 3 + 0], y2 = xyz2[qi * 3 + 1], z2 = xyz2[qi * 3 + 2];
         const int cx = min(kNX - 1, max(0, (int)((x2 - mnx) * inv)));
