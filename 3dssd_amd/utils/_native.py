@@ -85,6 +85,10 @@ def lib():
             raise NativeLibraryError(
                 "HIP extension not built: %s is missing. Run `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        # torch first: it brings its own libamdhip64, and the kernels must register with the HIP runtime whose streams they
+        # are launched on.  Loaded before torch, this library would pull in /opt/rocm's copy -- two runtimes in one
+        # process, every launch then fails (seen with build() and smoke() in one interpreter).
+        import torch  # noqa: F401
         h = ctypes.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(h, name)  # AttributeError if the symbol is not exported
