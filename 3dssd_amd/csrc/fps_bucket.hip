@@ -28,6 +28,7 @@ constexpr int kW = 8;                  // waves per workgroup (2 per SIMD)
 constexpr int kT = kW * 64;            // 512 threads
 constexpr int kNB = 64;                // buckets == table entries == lanes of a wave
 constexpr int kBPW = kNB / kW;         // buckets owned by a wave
+static_assert(kBPW == 8, "the touched-bucket dispatch below names the eight buckets of a wave");
 constexpr int kSL = 4;                 // points per lane per bucket
 constexpr int kBS = 64 * kSL;          // points per bucket
 constexpr int kCap = kNB * kBS;        // 16384 points
@@ -66,6 +67,54 @@ struct Table {
     unsigned key[2][kNB];
     float4 pt[2][kNB];
 };
+
+typedef float vecf __attribute__((ext_vector_type(kPPT)));
+typedef unsigned vecu __attribute__((ext_vector_type(kPPT)));
+
+// Re-evaluation of my bucket I (compile-time: its 4 slots per lane are registers) against the new point (ox, oy, oz):
+// running minima updated, the bucket's new (max, tie key, point) published into table buffer `par`.
+template <int I>
+__device__ __forceinline__ void bucket_update(const vecf &X, const vecf &Y, const vecf &Z, vecf &TD, const vecu &TK, float ox,
+                                              float oy, float oz, Table &tbl, int par, int w, int lane) {
+    float nb = -1.0f;                   // tf_sampling_g.cu:141
+    int nj = 0;
+    // (packed v_pk_*_f32 arithmetic was tried here: the aligned register pairs it needs made the
+    //  kernel spill and it measured 10 % slower)
+#pragma unroll
+    for (int s = 0; s < kSL; ++s) {
+        const int r = I * kSL + s;
+        const float dx = X[r] - ox, dy = Y[r] - oy, dz = Z[r] - oz;
+        const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));   // as fps.hip
+        const float t2 = sa::fmin_nn(d, TD[r]);
+        TD[r] = t2;
+        const bool g = t2 > nb;         // strict: the smallest tie key among equal maxima
+        nb = g ? t2 : nb;
+        nj = g ? s : nj;
+    }
+    const float Mw = sa::wave_allmax(nb);
+    unsigned long long cand = __ballot(nb == Mw);
+    unsigned tkw = TK[I * kSL];
+#pragma unroll
+    for (int s = 1; s < kSL; ++s) tkw = nj == s ? TK[I * kSL + s] : tkw;
+    if (__builtin_popcountll(cand) > 1) {           // equal maxima in several lanes: minimum tie key
+        const unsigned mykey = nb == Mw ? tkw : kNoKey;
+        const unsigned kmin = sa::wave_allmin_u32(mykey);
+        cand = __ballot(mykey == kmin);             // keys are unique
+    }
+    const int wl = __builtin_ctzll(cand);
+    if (lane == wl) {
+        float cx = X[I * kSL], cy = Y[I * kSL], cz = Z[I * kSL];
+#pragma unroll
+        for (int s = 1; s < kSL; ++s) {
+            const bool sel = nj == s;
+            cx = sel ? X[I * kSL + s] : cx; cy = sel ? Y[I * kSL + s] : cy; cz = sel ? Z[I * kSL + s] : cz;
+        }
+        const int b = I * kW + w;
+        tbl.val[par][b] = Mw;
+        tbl.key[par][b] = tkw;
+        tbl.pt[par][b] = make_float4(cx, cy, cz, 0.0f);
+    }
+}
 
 __global__ __launch_bounds__(kT) void fps3_wave_bucket_kernel(int n, int m, const float *__restrict__ inp,
                                                              long in_bstride, int *__restrict__ out, int out_stride,
@@ -127,8 +176,6 @@ __global__ __launch_bounds__(kT) void fps3_wave_bucket_kernel(int n, int m, cons
 
     // ---- my points: bucket 8i+w, sorted positions (8i+w)*256 + 4*lane + s; the four slots of a lane are then
     //      re-ordered by tie key (kept in registers).
-    typedef float vecf __attribute__((ext_vector_type(kPPT)));
-    typedef unsigned vecu __attribute__((ext_vector_type(kPPT)));
     vecf X, Y, Z, TD;
     vecu TK;
     const int pos0 = w * kBS + lane * kSL;
@@ -199,49 +246,9 @@ __global__ __launch_bounds__(kT) void fps3_wave_bucket_kernel(int n, int m, cons
 #endif
         FP_T(0)
         // ---- re-evaluate my active buckets and publish their new entries
-#pragma unroll
-        for (int i = 0; i < kBPW; ++i) {
-            if ((mine >> (8 * i)) & 1ull) {
-                float nb = -1.0f;                   // tf_sampling_g.cu:141
-                int nj = 0;
-                // (packed v_pk_*_f32 arithmetic was tried here: the aligned register pairs it needs made the
-                //  kernel spill and it measured 10 % slower)
-#pragma unroll
-                for (int s = 0; s < kSL; ++s) {
-                    const int r = i * kSL + s;
-                    const float dx = X[r] - ox, dy = Y[r] - oy, dz = Z[r] - oz;
-                    const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));   // as fps.hip
-                    const float t2 = sa::fmin_nn(d, TD[r]);
-                    TD[r] = t2;
-                    const bool g = t2 > nb;         // strict: the smallest tie key among equal maxima
-                    nb = g ? t2 : nb;
-                    nj = g ? s : nj;
-                }
-                const float Mw = sa::wave_allmax(nb);
-                unsigned long long cand = __ballot(nb == Mw);
-                unsigned tkw = TK[i * kSL];
-#pragma unroll
-                for (int s = 1; s < kSL; ++s) tkw = nj == s ? TK[i * kSL + s] : tkw;
-                if (__builtin_popcountll(cand) > 1) {           // equal maxima in several lanes: minimum tie key
-                    const unsigned mykey = nb == Mw ? tkw : kNoKey;
-                    const unsigned kmin = sa::wave_allmin_u32(mykey);
-                    cand = __ballot(mykey == kmin);             // keys are unique
-                }
-                const int wl = __builtin_ctzll(cand);
-                if (lane == wl) {
-                    float cx = X[i * kSL], cy = Y[i * kSL], cz = Z[i * kSL];
-#pragma unroll
-                    for (int s = 1; s < kSL; ++s) {
-                        const bool sel = nj == s;
-                        cx = sel ? X[i * kSL + s] : cx; cy = sel ? Y[i * kSL + s] : cy; cz = sel ? Z[i * kSL + s] : cz;
-                    }
-                    const int b = i * kW + w;
-                    s_tbl.val[par][b] = Mw;
-                    s_tbl.key[par][b] = tkw;
-                    s_tbl.pt[par][b] = make_float4(cx, cy, cz, 0.0f);
-                }
-            }
-        }
+#define SA_FPSB_IF(I) if ((mine >> (8 * I)) & 1ull) bucket_update<I>(X, Y, Z, TD, TK, ox, oy, oz, s_tbl, par, w, lane);
+        SA_FPSB_IF(0) SA_FPSB_IF(1) SA_FPSB_IF(2) SA_FPSB_IF(3) SA_FPSB_IF(4) SA_FPSB_IF(5) SA_FPSB_IF(6) SA_FPSB_IF(7)
+#undef SA_FPSB_IF
         FP_T(1)
         // ---- carry my untouched entries forward into this iteration's buffer
         if (owner && !need) {
