@@ -835,6 +835,44 @@ def test_grid_ball_query_matches_oracle(gpu, oracle, n, m, scale, radii, nss, di
         _check_ball(idx[i], cnt[i], ridx, rcnt)
 
 
+@pytest.mark.parametrize("b,n,m", [(8, 3000, 64), (16, 2500, 96), (8, 2100, 30), (8, 2200, 40)])
+def test_grid_ball_query_frame_to_xcd_mapping(gpu, oracle, b, n, m):
+    # b a multiple of 8 and ceil(m / 4) workgroups per frame a multiple of 8: the query kernel remaps (frame, workgroup) so
+    # that frame f runs on XCD f % 8 (ballquery_grid.hip); every frame different, every query still answered for its own
+    # frame.  m = 30: a ragged last workgroup under the remap; m = 40 (10 workgroups per frame): the plain mapping.
+    rng = np.random.default_rng(b * 1000 + m)
+    xyz1 = _cloud(rng, b, n, scale=3.0, dup=n // 10)
+    xyz1[:, :, 1] *= 0.1
+    xyz2 = np.ascontiguousarray(xyz1[:, rng.permutation(n)[:m]] + rng.normal(0, 0.05, (b, m, 3)).astype(np.float32))
+    radii, nss = [0.3, 0.8, 2.0], [16, 32, 64]
+    rmins = [0.0] + radii[:-1]
+    idx, cnt = _run_grid_bq(gpu, xyz1, xyz2, rmins, radii, nss, True)
+    for i in range(3):
+        ridx, rcnt = oracle.query_ball_point_dilated(rmins[i], radii[i], nss[i], xyz1, xyz2)
+        _check_ball(idx[i], cnt[i], ridx, rcnt)
+
+
+@pytest.mark.parametrize("b,n,c1", [(8, 2048, 16), (16, 1920, 5), (8, 1024, 16)])
+def test_distance_matrix_frame_to_xcd_mapping(gpu, oracle, b, n, c1):
+    # b a multiple of 8 and T (T + 1) / 2 tiles a multiple of 8 (n = 1920, 2048, 4096): the packed symmetric kernel remaps
+    # (frame, tile) so that frame f is computed on XCD f % 8, with a per-frame rotation of the tile order (sqdist.hip);
+    # n = 1024 (36 tiles) keeps the plain mapping.  Every frame different: a wrong frame or a missed tile shows.
+    N = pkg("utils._native")
+    rng = np.random.default_rng(b + n)
+    xyz = _cloud(rng, b, n, scale=5.0)
+    feat = rng.normal(0, 1, (b, n, c1)).astype(np.float32)
+    tx, tf = _t(xyz, gpu), _t(feat, gpu)
+    lib = N.lib()
+    ws = torch.empty((lib.sa_calc_square_dist_ws_bytes(b, n, n, 3 + c1, 1) + 3) // 4, dtype=torch.float32, device=gpu)
+    dist = torch.full((b, n, n), -1.0, dtype=torch.float32, device=gpu)
+    assert lib.sa_calc_square_dist_self_ws(b, n, 3, c1, tx.data_ptr(), n, tf.data_ptr(), n, dist.data_ptr(), ws.data_ptr(),
+                                           N.current_stream()) == 0
+    f = np.concatenate([xyz, feat], -1)
+    got = dist.cpu().numpy()
+    for i in range(b):                                                  # frame by frame: bounded host memory
+        assert np.array_equal(got[i], oracle.calc_square_dist(f[i:i + 1], f[i:i + 1])[0]), "frame %d" % i
+
+
 def test_grid_ball_query_overflow_falls_back_to_full_scan(gpu, oracle):
     # a dense clump: > 512 candidates inside one ball -> the in-kernel ordered full scan path
     rng = np.random.default_rng(77)
