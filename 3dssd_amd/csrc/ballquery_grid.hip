@@ -7,9 +7,10 @@
 // histogram, scan, scatter -- order inside a cell is irrelevant); (2) per query, visit the 3 x 3 cells around it,
 // evaluate exactly the same d2 and thresholds as ballquery.hip on those candidates only, collect the hits of
 // every band in LDS, and place hit h at output slot rank(h) = #{hits with a smaller index} if rank < nsample.
-// A query whose candidate list overflows the LDS buffer is appended to a list in the workspace and redone by a
-// second, normally empty launch with the ordered full scan (kept out of the main kernel: the out-of-line call
-// alone raised its VGPR count from 39 to 126 and halved its occupancy).
+// A query whose candidate list overflows the LDS buffer (> kCap points of a band in its 3 x 3 cells: not on LiDAR frames) is
+// redone on the spot with the ordered full scan -- in the same wave, behind `#pragma unroll 1` loops: 42 VGPRs against 39
+// without the fallback, same occupancy.  (Until the end of round 2 such queries went to a list that a second, normally
+// empty launch worked off -- one launch more per layer; a first inline form had cost 126 VGPRs.)
 //
 // Cell geometry: cell = clamp(int((coord - min) * inv), 0, kNX-1) with cell size >= r_max * (1 + 1e-4): monotone in
 // the coordinate, so |dx| <= r_max implies a cell difference of at most 1 (the margin absorbs the fp32 rounding of
@@ -37,13 +38,11 @@ struct GBands {
 
 __device__ __forceinline__ float wave_allmin_f(float x) { return -sa::wave_allmax(-x); }
 
-// workspace per frame: cell_start[kNC + 1] ints | sorted[n] ints | params[4] floats (minx, minz, inv, 0);
-// after the b frames: overflow counter (4 ints, first used) | overflow list [b * m] of flat query ids
+// workspace per frame: cell_start[kNC + 1] ints | sorted[n] ints | params[4] floats (minx, minz, inv, 0)
 __host__ __device__ __forceinline__ size_t ws_stride(int n) { return ((size_t)(kNC + 1) + n + 4 + 3) / 4 * 4; }
 
 __global__ __launch_bounds__(1024) void bq_grid_build_kernel(int n, float cell_min, const float *__restrict__ xyz1,
                                                              int *__restrict__ ws) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) ws[(size_t)gridDim.x * ws_stride(n)] = 0;     // overflow counter
     __shared__ int s_cnt[kNC];
     __shared__ float s_red[4][16];
     __shared__ int s_wsum[16];
@@ -149,6 +148,7 @@ __global__ __launch_bounds__(kQWaves * 64) void bq_grid_query_kernel(int n, int 
                                                                      const float *__restrict__ xyz2,
                                                                      const int *__restrict__ ws, GBands B) {
     __shared__ int s_hits[kQWaves][kMaxBands][kCap];
+    __shared__ int s_fcnt[kQWaves][kMaxBands];
     int b = blockIdx.y, bx = blockIdx.x;
     if ((gridDim.x & 7) == 0 && (gridDim.y & 7) == 0) {
         // XCD-aware (block L is observed to run on XCD L % 8, sa_common.h): the queries of frame f run on XCD f % 8, whose L2
@@ -211,10 +211,16 @@ __global__ __launch_bounds__(kQWaves * 64) void bq_grid_query_kernel(int n, int 
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (overflow) {                            // too many candidates for the LDS lists: left to the second launch
-            if (lane == 0) {
-                int *ovf = const_cast<int *>(ws) + (size_t)gridDim.y * ws_stride(n);
-                ovf[4 + atomicAdd(ovf, 1)] = (int)qi;
+        if (overflow) {
+            // too many candidates for the LDS lists (a band with > kCap points in the 3 x 3 cells: does not happen on LiDAR
+            // frames): this query is redone right here by the ordered full scan, rows come out final
+            scan_all(B, P, n, x2, y2, z2, hits, s_fcnt[w], lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 1
+            for (int i = 0; i < B.nbands; ++i) {
+                const int c = s_fcnt[w][i], nsi = B.ns[i];
+                for (int l = lane; l < nsi; l += 64) B.idx[i][qi * nsi + l] = c > 0 ? hits[i][l < c ? l : 0] : 0;
+                if (lane == 0) B.cnt[i][qi] = c;
             }
             continue;
         }
@@ -245,34 +251,6 @@ __global__ __launch_bounds__(kQWaves * 64) void bq_grid_query_kernel(int n, int 
     }
 }
 
-// the queries the main kernel gave up on: ordered full scan, rows come out final (sorted, capped)
-__global__ __launch_bounds__(kQWaves * 64) void bq_grid_overflow_kernel(int nframes, int n, int m,
-                                                                        const float *__restrict__ xyz1,
-                                                                        const float *__restrict__ xyz2,
-                                                                        const int *__restrict__ ws, GBands B) {
-    __shared__ int s_hits[kQWaves][kMaxBands][kCap];
-    __shared__ int s_fcnt[kQWaves][kMaxBands];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int *ovf = ws + (size_t)nframes * ws_stride(n);
-    const int total = ovf[0];
-    int (*hits)[kCap] = s_hits[w];
-    for (int e = blockIdx.x * kQWaves + w; e < total; e += gridDim.x * kQWaves) {
-        const size_t qi = (size_t)ovf[4 + e];
-        const int b = (int)(qi / m);
-        const float *P = xyz1 + (size_t)b * n * 3;
-        const float x2 = xyz2[qi * 3 + 0], y2 = xyz2[qi * 3 + 1], z2 = xyz2[qi * 3 + 2];
-        scan_all(B, P, n, x2, y2, z2, hits, s_fcnt[w], lane);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < kMaxBands; ++i) {
-            if (i >= B.nbands) break;
-            const int c = s_fcnt[w][i], nsi = B.ns[i];
-            for (int l = lane; l < nsi; l += 64) B.idx[i][qi * nsi + l] = c > 0 ? hits[i][l < c ? l : 0] : 0;
-            if (lane == 0) B.cnt[i][qi] = c;
-        }
-    }
-}
-
 float sqrt_ge_threshold_g(float r) {
     if (!(r > 0.0f)) return 0.0f;
     float x = r * r;
@@ -287,7 +265,8 @@ float sqrt_ge_threshold_g(float r) {
 // Bytes of device workspace sa_query_ball_point_grid needs for (b, n, m).
 extern "C" size_t sa_query_ball_point_grid_ws_bytes(int b, int n, int m) {
     if (b <= 0 || n <= 0 || m <= 0) return 0;
-    return ((size_t)b * ws_stride(n) + 4 + (size_t)b * m) * sizeof(int);
+    (void)m;
+    return (size_t)b * ws_stride(n) * sizeof(int);
 }
 
 extern "C" int sa_query_ball_point_multi(int b, int n, int m, int nbands, const float *rmin, const float *rmax,
@@ -328,9 +307,6 @@ extern "C" int sa_query_ball_point_grid(int b, int n, int m, int nbands, const f
     int gx = (m + kQWaves - 1) / kQWaves;
     if (gx > 4096) gx = 4096;
     hipLaunchKernelGGL(bq_grid_query_kernel, dim3(gx, b), dim3(kQWaves * 64), 0, stream, n, m, xyz1, xyz2,
-                       (const int *)workspace, B);
-    SA_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bq_grid_overflow_kernel, dim3(64), dim3(kQWaves * 64), 0, stream, b, n, m, xyz1, xyz2,
                        (const int *)workspace, B);
     SA_CHECK_LAUNCH();
     return SA_OK;
