@@ -6,25 +6,32 @@ import torch
 from .builder.layer_builder import LayerBuilder
 from .utils import layers_util
 from .utils import _native as N
+from .utils.tf_ops import _tensor as T
 from .utils.weights import VariableStore
 
 
 class SABackbone:
     def __init__(self, arch, params, device="cuda:0", max_translate_range=(-3.0, -2.0, -3.0),
-                 aggregation_sa_feature=True):
+                 aggregation_sa_feature=True, precision=None):
+        """precision: None = per-scale rule of utils/weights.py (fp16 one-pass on the wide scales, split bf16 elsewhere),
+        "bf16x3" = split bf16 everywhere (~1e-5 of fp32, no range limit), "fp16" = one pass wherever the weights fit."""
         self.device = torch.device(device)
-        self.variables = VariableStore(params, self.device)
+        self.variables = params if isinstance(params, VariableStore) else VariableStore(params, self.device, precision)
         layers_util.AGGREGATION_SA_FEATURE = bool(aggregation_sa_feature)
         layers_util.MAX_TRANSLATE_RANGE = tuple(max_translate_range)
         self.layers = [LayerBuilder(i, False, arch, variables=self.variables) for i in range(len(arch))]
 
     def split_input(self, point_cloud):
         """The two tf.slice of single_stage_detector.py:117-118 in one launch: [B,n,3+C] -> xyz [B,n,3], features [B,n,C]."""
-        point_cloud = point_cloud.contiguous()
+        point_cloud = T.f32_cuda(point_cloud, "point_cloud")      # device / dtype checks, fp32, contiguous
+        T.require(point_cloud.dim() == 3 and point_cloud.shape[2] >= 3, "point_cloud must be [B, n, 3 + C]")
         bs, n, ch = point_cloud.shape
         l0_xyz = torch.empty((bs, n, 3), dtype=torch.float32, device=point_cloud.device)
         l0_points = torch.empty((bs, n, ch - 3), dtype=torch.float32, device=point_cloud.device)
-        N.copy_blocks([(point_cloud[:, :, 0:3], l0_xyz, bs, n, 3), (point_cloud[:, :, 3:], l0_points, bs, n, ch - 3)])
+        jobs = [(point_cloud[:, :, 0:3], l0_xyz, bs, n, 3)]
+        if ch > 3:                                                # an xyz-only cloud has no feature block to copy
+            jobs.append((point_cloud[:, :, 3:], l0_points, bs, n, ch - 3))
+        N.copy_blocks(jobs)
         return l0_xyz, l0_points
 
     def forward(self, point_cloud):
@@ -39,3 +46,8 @@ class SABackbone:
         return xyz_list, feature_list, fps_idx_list
 
     __call__ = forward
+
+    def raise_if_overflow(self):
+        """The fp16 scales guard their operand range (csrc/mlp_act.h); forward() does not synchronise, so the check is
+        explicit: call it after the results are complete (SAPipeline tickets do)."""
+        self.variables.raise_if_overflow("SA backbone")

@@ -28,13 +28,69 @@ class PostProcessor:
         N.check(st, "nms_bev")
         return idx, cnt
 
+    def class_unaware_format(self, pred_anchors_3d, pred_score):
+        """postprocessor.py:24-44 (RPN proposals of a class-aware head): pred_anchors_3d [bs,n,1|cls,7], pred_score
+        [bs,n,cls] -> ([bs,n,1,7], [bs,n,1]): the best class's score and, for class-aware boxes, that class's box
+        (first maximum on ties, like tf.argmax; the reference's one-hot multiply-and-sum selects exactly that row)."""
+        pred_score = T.f32_cuda(pred_score, "pred_score")
+        boxes = T.f32_cuda(pred_anchors_3d, "pred_anchors_3d")
+        T.require(boxes.dim() == 4 and boxes.shape[3] == 7, "class_unaware_format expects boxes [bs,n,1|cls,7]")
+        score, cls = pred_score.max(dim=-1, keepdim=True)
+        if boxes.shape[2] == 1:
+            return boxes, score
+        T.require(boxes.shape[2] == pred_score.shape[2], "class-aware boxes need one box per score channel")
+        # torch.max returns the FIRST maximum for ties on ROCm as well; stated explicitly through argmax of (score == max)
+        first = (pred_score == score).int().argmax(dim=-1, keepdim=True)
+        sel = torch.gather(boxes, 2, first[..., None].expand(-1, -1, 1, 7))
+        return sel, score
+
     def forward(self, pred_anchors_3d, pred_score, output_dict, bev=None):
-        """pred_anchors_3d [bs,n,1,7] or [bs,n,7] (class-agnostic boxes of the anchor-free head), pred_score
-        [bs,n,cls].  Appends pred_3d_bbox [bs,cls*max_out,7], pred_3d_score, pred_3d_cls_category, plus the raw
-        nms_idx / nms_cnt."""
-        T.require(pred_anchors_3d.dim() == 3 or (pred_anchors_3d.dim() == 4 and pred_anchors_3d.shape[2] == 1),
-                  "PostProcessor: class-aware boxes [bs,n,cls,7] are not supported (the anchor-free head is "
-                  "class-agnostic: [bs,n,1,7] or [bs,n,7])")
+        """postprocessor.py:49-123.  pred_anchors_3d [bs,n,7] / [bs,n,1,7] (class-agnostic boxes of the anchor-free head)
+        or [bs,n,cls,7] (class-aware: class i is suppressed on box set reg_i = min(i, k-1), :76-80), pred_score
+        [bs,n,cls'].  cls' != cls_num -> class_unaware_format first (:56-59).  Appends pred_3d_bbox
+        [bs,cls*max_out,7], pred_3d_score, pred_3d_cls_category (fixed size: max_out rows per class, padded with zero
+        boxes / scores and category -1), plus the raw nms_idx / nms_cnt."""
+        T.require(pred_anchors_3d.dim() in (3, 4) and pred_anchors_3d.shape[-1] == 7, "PostProcessor: boxes must be [bs,n,(k,)7]")
+        if pred_anchors_3d.dim() == 3:
+            pred_anchors_3d = pred_anchors_3d[:, :, None, :]
+        pred_score = T.f32_cuda(pred_score, "pred_score")
+        if pred_score.shape[-1] != self.cls_num:
+            pred_anchors_3d, pred_score = self.class_unaware_format(pred_anchors_3d, pred_score)
+        k = pred_anchors_3d.shape[2]
+        if k > 1:
+            return self._forward_class_aware(T.f32_cuda(pred_anchors_3d, "pred_anchors_3d"), pred_score, output_dict)
+        return self._forward_agnostic(pred_anchors_3d, pred_score, output_dict, bev)
+
+    def _forward_class_aware(self, boxes4, pred_score, output_dict):
+        """One NMS per class on that class's own boxes (reg_i = min(i, k-1))."""
+        bs, n, k, _ = boxes4.shape
+        C, K = self.cls_num, self.max_output_size
+        T.require(pred_score.shape[-1] == C, "pred_score must have cls_num channels here")
+        bev_all = torch.empty((bs, n, k, 4), dtype=torch.float32, device=boxes4.device)
+        st = N.lib().sa_boxes_to_bev(bs * n * k, boxes4.data_ptr(), bev_all.data_ptr(), N.current_stream())
+        N.check(st, "boxes_to_bev")
+        gb_l, sc_l, cat_l, idx_l, cnt_l = [], [], [], [], []
+        for i in range(C):
+            r = min(i, k - 1)
+            s_i = pred_score[:, :, i:i + 1].contiguous()
+            sub = PostProcessor(0, 1, K, self.nms_threshold)
+            idx, cnt = sub.nms(bev_all[:, :, r].contiguous(), s_i)                    # [bs,1,K], [bs,1]
+            valid = idx >= 0
+            safe = idx.clamp(min=0).long().reshape(bs, K)
+            gb_l.append(torch.gather(boxes4[:, :, r], 1, safe[..., None].expand(-1, -1, 7)) * valid.reshape(bs, K, 1))
+            sc_l.append(torch.gather(s_i[:, :, 0], 1, safe) * valid.reshape(bs, K))
+            cat_l.append(torch.where(valid.reshape(bs, K), torch.full((bs, K), i, dtype=torch.int32, device=idx.device),
+                                     torch.full((bs, K), -1, dtype=torch.int32, device=idx.device)))
+            idx_l.append(idx)
+            cnt_l.append(cnt)
+        output_dict.setdefault("pred_3d_bbox", []).append(torch.cat(gb_l, 1))
+        output_dict.setdefault("pred_3d_score", []).append(torch.cat(sc_l, 1))
+        output_dict.setdefault("pred_3d_cls_category", []).append(torch.cat(cat_l, 1))
+        output_dict.setdefault("nms_idx", []).append(torch.cat(idx_l, 1))
+        output_dict.setdefault("nms_cnt", []).append(torch.cat(cnt_l, 1))
+        return output_dict
+
+    def _forward_agnostic(self, pred_anchors_3d, pred_score, output_dict, bev=None):
         boxes = pred_anchors_3d.reshape(pred_anchors_3d.shape[0], pred_anchors_3d.shape[1], 7).contiguous()
         bs, n, _ = boxes.shape
         if bev is None:

@@ -327,7 +327,7 @@ extern "C" int sa_query_ball_point_multi(int b, int n, int m, int nbands, const 
         // that take this kernel in the backbone are small (512 / 256 centres per frame: 64 waves per frame at 8), where
         // the launch is one dependent scan per wave -- 2 queries per wave give 4x the waves and a quarter of the scan
         // (layer3 0.068 -> 0.025 ms, layer4 0.032 -> 0.013 ms).
-        static const bool small_form = !(getenv("SA_BQ_SMALL") && atoi(getenv("SA_BQ_SMALL")) == 0);
+        static const bool small_form = SA_KNOB("SA_BQ_SMALL", 1) != 0;
         if (small_form && n <= 2048) {                       // one query per wave, the frame in registers
             dim3 grid((m + kWavesPerWG - 1) / kWavesPerWG, b);
             if (n <= 512) hipLaunchKernelGGL(ball_query_small_kernel<8>, grid, dim3(kWavesPerWG * 64), 0, stream, n, m, xyz1, xyz2, B);

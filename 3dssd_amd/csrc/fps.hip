@@ -456,7 +456,7 @@ extern "C" int sa_fps_ex2(int b, int n, int c, int m, const float *inp, long in_
     const bool extras = (in_bstride != 0 && in_bstride != (long)n * c) || ctr != nullptr;
     // Layer-1 shape: the wave-bucket culled kernel (fps_bucket.hip), bit-identical output, ~1.4x faster than the
     // plain kernel at 16384 -> 4096.  SA_FPS_BUCKET_MIN_N = smallest n it is used for (0 = never).
-    static const int bucket_min_n = getenv("SA_FPS_BUCKET_MIN_N") ? atoi(getenv("SA_FPS_BUCKET_MIN_N")) : 8192;
+    static const int bucket_min_n = SA_KNOB("SA_FPS_BUCKET_MIN_N", 8192);
     if (c == 3 && bucket_min_n > 0 && n >= bucket_min_n && n <= 16384 && m >= 64)
         return sa_fps_bucket_ex2(b, n, m, inp, in_bstride, out, out_stride, idx_off, ctr, ctr_bstride, stream);
     const int ppt = ppt_for(n);

@@ -116,9 +116,12 @@ __device__ __forceinline__ void bucket_update(const vecf &X, const vecf &Y, cons
     }
 }
 
+// STATS (diagnostic entry sa_fps_bucket_stats only): also counts the bucket re-evaluations of the frame.
+template <bool STATS>
 __global__ __launch_bounds__(kT) void fps3_wave_bucket_kernel(int n, int m, const float *__restrict__ inp,
                                                              long in_bstride, int *__restrict__ out, int out_stride,
-                                                             int idx_off, float *__restrict__ ctr, long ctr_bstride) {
+                                                             int idx_off, float *__restrict__ ctr, long ctr_bstride,
+                                                             unsigned long long *__restrict__ stats) {
     __shared__ unsigned s_sorted[kCap];          // (morton << 14) | original index, ascending; 64 KiB;
 
     __shared__ float s_red[4][kW];
@@ -231,6 +234,7 @@ __global__ __launch_bounds__(kT) void fps3_wave_bucket_kernel(int n, int m, cons
 #ifdef SA_FPSB_PROF
     unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt0 = __builtin_readcyclecounter(), pact = 0, pmine = 0, pbusy = 0;
 #endif
+    unsigned long long nact = 0;
     for (int it = 1; it < m; ++it) {
         const int par = it & 1;
         // ---- which buckets can change?  lower bound of the distance from the new point to each box
@@ -241,6 +245,7 @@ __global__ __launch_bounds__(kT) void fps3_wave_bucket_kernel(int n, int m, cons
         const bool need = lb * kSkipMargin < val;
         const unsigned long long act = __ballot(need);
         const unsigned long long mine = (act >> w) & 0x0101010101010101ull;   // bit 8i <-> my bucket 8i+w
+        if (STATS) nact += __builtin_popcountll(act);
 #ifdef SA_FPSB_PROF
         pact += __builtin_popcountll(act); pmine += __builtin_popcountll(mine); pbusy += mine != 0;
 #endif
@@ -276,6 +281,7 @@ __global__ __launch_bounds__(kT) void fps3_wave_bucket_kernel(int n, int m, cons
         if (tid == 0) o[it] = (int)tie_key_index((unsigned)__builtin_amdgcn_readlane((int)key, bl)) + idx_off;
         FP_T(4)
     }
+    if (STATS && tid == 0) { stats[2 * bidx] = nact; stats[2 * bidx + 1] = (unsigned long long)(m - 1); }
     if (ctr) {                                       // the picked points themselves (gather_point fused, layers_util.py:116-119)
         __syncthreads();
         float *cq = ctr + (size_t)bidx * ctr_bstride;
@@ -299,8 +305,20 @@ __global__ __launch_bounds__(kT) void fps3_wave_bucket_kernel(int n, int m, cons
 extern "C" int sa_fps_bucket_ex2(int b, int n, int m, const float *inp, long in_bstride, int *out, int out_stride,
                                  int idx_off, float *ctr, long ctr_bstride, hipStream_t stream) {
     if (b <= 0 || n <= 0 || n > kCap || m <= 0 || !inp || !out || out_stride < m) return SA_ERR_INVALID;
-    hipLaunchKernelGGL(fps3_wave_bucket_kernel, dim3(b), dim3(kT), 0, stream, n, m, inp, in_bstride, out, out_stride,
-                       idx_off, ctr, ctr_bstride);
+    hipLaunchKernelGGL(fps3_wave_bucket_kernel<false>, dim3(b), dim3(kT), 0, stream, n, m, inp, in_bstride, out, out_stride,
+                       idx_off, ctr, ctr_bstride, (unsigned long long *)nullptr);
+    SA_CHECK_LAUNCH();
+    return SA_OK;
+}
+
+// Diagnostic (bench.py's `evaluated_pairs`, tests): the same picks, plus per frame stats[2f] = number of bucket
+// re-evaluations (each = 256 point slots against the new pick) and stats[2f+1] = m - 1 picks.  The reference kernel
+// evaluates (m - 1) * n pairs (tf_sampling_g.cu:139-160).
+extern "C" int sa_fps_bucket_stats(int b, int n, int m, const float *inp, int *out, unsigned long long *stats,
+                                   hipStream_t stream) {
+    if (b <= 0 || n <= 0 || n > kCap || m <= 0 || !inp || !out || !stats) return SA_ERR_INVALID;
+    hipLaunchKernelGGL(fps3_wave_bucket_kernel<true>, dim3(b), dim3(kT), 0, stream, n, m, inp, 0l, out, m, 0,
+                       (float *)nullptr, 0l, stats);
     SA_CHECK_LAUNCH();
     return SA_OK;
 }

@@ -144,7 +144,7 @@ Variant g_variants[] = {
 // reference's scratch, tf_sampling.cpp:149-155) holds the slots.
 extern "C" int sa_fps_coop_ex(int b, int n, int c, int m, const float *inp, float *temp, int *out, int out_stride,
                               int idx_off, hipStream_t stream) {
-    static const int enabled = getenv("SA_FPS_COOP") ? atoi(getenv("SA_FPS_COOP")) : 1;
+    static const int enabled = SA_KNOB("SA_FPS_COOP", 1);
     if (!enabled || !temp || ((uintptr_t)temp & 7) || m > 65535 || n <= kBlock) return SA_ERR_UNSUPPORTED;
     Variant *v = nullptr;
     for (auto &cand : g_variants)
@@ -181,7 +181,7 @@ extern "C" int sa_fps_coop_ex(int b, int n, int c, int m, const float *inp, floa
         const float *inp_f = inp + (size_t)f0 * n * c;
         int *out_f = out + (size_t)f0 * out_stride;
         void *args[] = {&n, &m, &gshift, &inp_f, &slots, &out_f, &out_stride, &idx_off};
-        static const int plain = getenv("SA_FPS_COOP_PLAIN") ? atoi(getenv("SA_FPS_COOP_PLAIN")) : 0;
+        static const int plain = SA_KNOB("SA_FPS_COOP_PLAIN", 0);
         const hipError_t le = plain ? hipLaunchKernel(v->fn, dim3(nf * G), dim3(kBlock), args, 0, stream)
                                     : hipLaunchCooperativeKernel(v->fn, dim3(nf * G), dim3(kBlock), args, 0, stream);
         if (le != hipSuccess) {

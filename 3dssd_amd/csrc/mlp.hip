@@ -30,6 +30,7 @@
 
 #include "sa_common.h"
 #include "mlp_plan.h"
+#include "mlp_act.h"
 
 namespace {
 
@@ -63,6 +64,7 @@ struct MlpParams {
     int nl;
     LayerDesc L[kMaxLayers];
     int strideA, strideB, lds_bytes;  // bytes
+    int *ovf;           // fp16 form: raised when a converted activation left the fp16 range (mlp_act.h); may be null
 };
 
 #ifdef SA_MLP_TIMING
@@ -99,12 +101,11 @@ __device__ __forceinline__ f32x16 mfma_f16(uint4 a, uint4 b, f32x16 c) {
 constexpr __host__ __device__ int grp_bytes(int PR) { return PR == 3 ? 32 : 16; }   // one 8-channel group of an LDS row
 constexpr __host__ __device__ int wblk(int PR) { return PR == 3 ? 128 : 64; }       // uint4 per (tile, k-step) of weights
 
-__device__ __forceinline__ unsigned cvt2_f16(float a, float b) {
-    const f32x2 v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
-}
-__device__ __forceinline__ uint4 cvt8_f16(const float (&v)[8]) {
-    return make_uint4(cvt2_f16(v[0], v[1]), cvt2_f16(v[2], v[3]), cvt2_f16(v[4], v[5]), cvt2_f16(v[6], v[7]));
+// fp16 conversions go through mlp_act.h: every converted fragment is range-checked into the scalar mask `det`
+__device__ __forceinline__ uint4 cvt8_f16(const float (&v)[8], sa::f16_guard_t &det) {
+    const uint4 r = make_uint4(sa::cvt2_f16(v[0], v[1]), sa::cvt2_f16(v[2], v[3]), sa::cvt2_f16(v[4], v[5]), sa::cvt2_f16(v[6], v[7]));
+    sa::f16_guard_signed(r, det);
+    return r;
 }
 // acc += W x for one k-step: a_* = the MFMA A operand planes, b_* = the B operand planes
 template <int PR, bool WFIRST>
@@ -128,28 +129,38 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4 &hi, uint4 &lo
 
 // 8 consecutive channels of a row -> their LDS group (hi/lo planes, or one fp16 plane)
 template <int PR>
-__device__ __forceinline__ void store_group(unsigned char *dst, const float (&v)[8]) {
+__device__ __forceinline__ void store_group(unsigned char *dst, const float (&v)[8], sa::f16_guard_t &det) {
     if (PR == 3) {
         uint4 hi, lo;
         split8(v, hi, lo);
         *(uint4 *)dst = hi;
         *(uint4 *)(dst + 16) = lo;
     } else {
-        *(uint4 *)dst = cvt8_f16(v);
+        *(uint4 *)dst = cvt8_f16(v, det);
     }
 }
-// 4 consecutive channels (one accumulator quad after ReLU) -> half a group
+// 4 consecutive channels (one accumulator quad, ReLU applied HERE) -> half a group
 template <int PR>
-__device__ __forceinline__ void store_quad(unsigned char *dst, const float (&v)[4]) {
+__device__ __forceinline__ void store_quad_relu(unsigned char *dst, const float (&a)[4], sa::f16_guard_t &det) {
     if (PR == 3) {
         unsigned h[4], l[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sa::bf16_split(v[e], h[e], l[e]);
+        for (int e = 0; e < 4; ++e) sa::bf16_split(sa::fmax_nn(a[e], 0.0f), h[e], l[e]);
         *(uint2 *)dst = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
         *(uint2 *)(dst + 16) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
     } else {
-        *(uint2 *)dst = make_uint2(cvt2_f16(v[0], v[1]), cvt2_f16(v[2], v[3]));
+        const uint2 r = make_uint2(sa::cvt2_f16_relu(a[0], a[1]), sa::cvt2_f16_relu(a[2], a[3]));
+        sa::f16_guard(r, det);
+        *(uint2 *)dst = r;
     }
+}
+// the same without an activation (values already final): split-bf16 only (vote tail)
+__device__ __forceinline__ void store_quad_bf16(unsigned char *dst, const float (&v)[4]) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sa::bf16_split(v[e], h[e], l[e]);
+    *(uint2 *)dst = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+    *(uint2 *)(dst + 16) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
 }
 
 // acc[tt] += sum_ks (hi*hi + lo*hi + hi*lo) for the TG output tiles starting at gb.  WFIRST: weights are the
@@ -236,7 +247,7 @@ __device__ __forceinline__ void gather8(const MlpParams &P, long pt, long ball, 
 //    only 32..128 slots execute.
 template <int ROWS, int NTHR, int PR>
 __device__ __forceinline__ void gather_tile(const MlpParams &P, unsigned char *buf, int stride, int item,
-                                            int ngran, int G0, int tid) {
+                                            int ngran, int G0, int tid, sa::f16_guard_t &det) {
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
     // rows lane and lane+64 (ROWS == 64) / lane&31 (ROWS == 32) resolved by this lane
@@ -264,7 +275,7 @@ __device__ __forceinline__ void gather_tile(const MlpParams &P, unsigned char *b
         const float4 f0 = *(const float4 *)(P.feat + pt * P.C + g * 8);
         const float4 f1 = *(const float4 *)(P.feat + pt * P.C + g * 8 + 4);
         const float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-        if (live) store_group<PR>(buf + row * stride + g * grp_bytes(PR), v);
+        if (live) store_group<PR>(buf + row * stride + g * grp_bytes(PR), v, det);
     }
     const int GT = G0 - GF;                                 // tail groups per row (1 or 2; all of them if C%4 != 0)
     const int totT = ROWS * GT;
@@ -296,14 +307,14 @@ __device__ __forceinline__ void gather_tile(const MlpParams &P, unsigned char *b
             const int x = g * 8 + e - P.C;
             v[e] = x < 0 ? fv[e] : (x == 0 ? px : (x == 1 ? py : (x == 2 ? pz : 0.0f)));
         }
-        if (live) store_group<PR>(buf + row * stride + g * grp_bytes(PR), v);
+        if (live) store_group<PR>(buf + row * stride + g * grp_bytes(PR), v, det);
     }
 }
 
 // ---- hidden layer, D^T form: out[row][cout] = relu(bias + sum_k W[k][cout] * in[row][k]) ----------
 template <int TG, int NW, int PR>
 __device__ __forceinline__ void layer_hidden(const unsigned char *in, int strideIn, unsigned char *outb,
-                                             int strideOut, const LayerDesc &L, int lane, int w) {
+                                             int strideOut, const LayerDesc &L, int lane, int w, sa::f16_guard_t &det) {
     constexpr int GB = grp_bytes(PR);
     const int half = lane >> 5, col = lane & 31;
     const unsigned char *arow = in + col * strideIn + half * GB;
@@ -326,10 +337,8 @@ __device__ __forceinline__ void layer_hidden(const unsigned char *in, int stride
                 unsigned char *orow = outb + col * strideOut + (gb + tt) * 4 * GB + 8 * half;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = sa::fmax_nn(acc[tt][4 * q + e], 0.0f);
-                    store_quad<PR>(orow + q * GB, v);
+                    const float v[4] = {acc[tt][4 * q], acc[tt][4 * q + 1], acc[tt][4 * q + 2], acc[tt][4 * q + 3]};
+                    store_quad_relu<PR>(orow + q * GB, v, det);
                 }
             }
         }
@@ -381,12 +390,13 @@ __device__ __forceinline__ int pick_tg(int NT) {
 // wave runs the whole stack on its own item -- no cross-wave barrier, 8x more items in flight per CU to
 // hide the idx -> point gather latency.
 template <int NW, int PR>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? SA_MLP_WPE8 : 4) void group_mlp_max_kernel(MlpParams P) {
+// (the fp16 form with its range guard is compiled for 2 waves per SIMD: at 128 registers it spilled 60 of them)
+__global__ __launch_bounds__(NW * 64, PR == 1 ? 2 : (NW == 8 ? SA_MLP_WPE8 : 4)) void group_mlp_max_kernel(MlpParams P) {
     constexpr int kThr = NW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *bufA = smem;
     unsigned char *bufB = smem + kRows * P.strideA;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ngran = __builtin_amdgcn_readfirstlane(P.hdr[0]);
     const int nitems = (ngran + 3) >> 2;               // 32-row tiles of the plan
     const LayerDesc &LL = P.L[P.nl - 1];
@@ -396,12 +406,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? SA_MLP_WPE8 : 4) void group_mlp_
     int istride;
     const int item0 = sa::xcd_block(blockIdx.x, gridDim.x, nitems, istride);
     if (item0 < 0) return;
+    sa::f16_guard_t det = 0;                           // fp16 range guard (mlp_act.h), scalar registers
     for (int item = item0; item < nitems; item += istride) {
         SA_COUNT(0);
         SA_COUNT(1);
         // ---- gather the [32 rows x cin] input tile (features first, then relative xyz:
         //      layers_util.py:160-165) into bufA as hi/lo bf16
-        gather_tile<kRows, kThr, PR>(P, bufA, P.strideA, item, ngran, G0, tid);
+        gather_tile<kRows, kThr, PR>(P, bufA, P.strideA, item, ngran, G0, tid, det);
         // the tile's plan entries and ball counts, wave-uniform
         int ent[4], cn[4];
 #pragma unroll
@@ -419,10 +430,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? SA_MLP_WPE8 : 4) void group_mlp_
             const int si = (l & 1) ? P.strideB : P.strideA, so = (l & 1) ? P.strideA : P.strideB;
             switch (pick_tg<NW>(P.L[l].NT)) {
 #if SA_MLP_MAXTG >= 4
-                case 4: layer_hidden<4, NW, PR>(in, si, ob, so, P.L[l], lane, w); break;
+                case 4: layer_hidden<4, NW, PR>(in, si, ob, so, P.L[l], lane, w, det); break;
 #endif
-                case 2: layer_hidden<2, NW, PR>(in, si, ob, so, P.L[l], lane, w); break;
-                default: layer_hidden<1, NW, PR>(in, si, ob, so, P.L[l], lane, w); break;
+                case 2: layer_hidden<2, NW, PR>(in, si, ob, so, P.L[l], lane, w, det); break;
+                default: layer_hidden<1, NW, PR>(in, si, ob, so, P.L[l], lane, w, det); break;
             }
             __syncthreads();
         }
@@ -443,6 +454,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? SA_MLP_WPE8 : 4) void group_mlp_
         __syncthreads();
         SA_TICK(2)
     }
+    if (PR == 1) sa::f16_overflow_report(det, P.ovf, lane);
     SA_TFLUSH(tid == 0)
 }
 
@@ -467,7 +479,7 @@ struct WideParams {
 template <int TG, int PR>
 __device__ __forceinline__ void wide_hidden(const unsigned char *in, int strideIn, unsigned char *outb,
                                             int strideOut, const LayerDesc &L, int tile_lo, int tile_hi,
-                                            int lane, int w) {
+                                            int lane, int w, sa::f16_guard_t &det) {
     asm volatile("" : "+v"(lane));
     constexpr int GB = grp_bytes(PR), WB = wblk(PR), KSB = 2 * GB;
     const int half = lane >> 5, col = lane & 31;
@@ -550,10 +562,8 @@ __device__ __forceinline__ void wide_hidden(const unsigned char *in, int strideI
                     unsigned char *orow = outb + (j * 32 + col) * strideOut + (gb + tt - tile_lo) * 4 * GB + 8 * half;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        float v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = sa::fmax_nn(acc[tt][j][4 * q + e], 0.0f);
-                        store_quad<PR>(orow + q * GB, v);
+                        const float v[4] = {acc[tt][j][4 * q], acc[tt][j][4 * q + 1], acc[tt][j][4 * q + 2], acc[tt][j][4 * q + 3]};
+                        store_quad_relu<PR>(orow + q * GB, v, det);
                     }
                 }
             }
@@ -631,7 +641,8 @@ __device__ __forceinline__ void wide_last_partial(f32x16 (&acc)[TGL][2], const u
 
 template <int TGL, int PR>
 __device__ __forceinline__ void wide_item_layers(const WideParams &WP, unsigned char *bufA, unsigned char *bufB,
-                                                 const int (&ent)[2][4], const int (&cn)[2][4], int lane, int w) {
+                                                 const int (&ent)[2][4], const int (&cn)[2][4], int lane, int w,
+                                                 sa::f16_guard_t &det) {
     const MlpParams &P = WP.M;
     const int nl = P.nl;
     const LayerDesc &LL = P.L[nl - 1];
@@ -640,8 +651,8 @@ __device__ __forceinline__ void wide_item_layers(const WideParams &WP, unsigned 
         const unsigned char *in = (l & 1) ? bufB : bufA;
         unsigned char *ob = (l & 1) ? bufA : bufB;
         const int si = (l & 1) ? P.strideB : P.strideA, so = (l & 1) ? P.strideA : P.strideB;
-        if (P.L[l].NT >= 2 * kNW) wide_hidden<2, PR>(in, si, ob, so, P.L[l], 0, P.L[l].NT, lane, w);
-        else wide_hidden<1, PR>(in, si, ob, so, P.L[l], 0, P.L[l].NT, lane, w);
+        if (P.L[l].NT >= 2 * kNW) wide_hidden<2, PR>(in, si, ob, so, P.L[l], 0, P.L[l].NT, lane, w, det);
+        else wide_hidden<1, PR>(in, si, ob, so, P.L[l], 0, P.L[l].NT, lane, w, det);
         __syncthreads();
     }
     f32x16 acc[TGL][2];
@@ -663,8 +674,8 @@ __device__ __forceinline__ void wide_item_layers(const WideParams &WP, unsigned 
             const int t_hi = min(P.L[l].NT, t_lo + WP.tiles_per_chunk);
             if (c > 0) __syncthreads();               // previous chunk fully consumed before it is overwritten
             // with 128 accumulator registers live (TGL == 4) only the one-tile form fits the register file
-            if (TGL < 4 && t_hi - t_lo >= 2 * kNW) wide_hidden<2, PR>(in, si, ob, so, P.L[l], t_lo, t_hi, lane, w);
-            else wide_hidden<1, PR>(in, si, ob, so, P.L[l], t_lo, t_hi, lane, w);
+            if (TGL < 4 && t_hi - t_lo >= 2 * kNW) wide_hidden<2, PR>(in, si, ob, so, P.L[l], t_lo, t_hi, lane, w, det);
+            else wide_hidden<1, PR>(in, si, ob, so, P.L[l], t_lo, t_hi, lane, w, det);
             __syncthreads();
             const int ks_lo = t_lo * 2, ks_hi = min(LL.KS, t_hi * 2);
             if (ks_lo < ks_hi) wide_last_partial<TGL, PR>(acc, ob, so, LL, ks_lo, ks_hi, lane, w);
@@ -707,8 +718,9 @@ __global__ __launch_bounds__(kThreads, 2) void group_mlp_wide_kernel(WideParams 
     int istride;
     const int item0 = sa::xcd_block(blockIdx.x, gridDim.x, nitems, istride);
     if (item0 < 0) return;
+    sa::f16_guard_t det = 0;                           // fp16 range guard (mlp_act.h), scalar registers
     for (int item = item0; item < nitems; item += istride) {
-        gather_tile<kWRows, kThreads, PR>(P, bufA, P.strideA, item, ngran, G0, tid);
+        gather_tile<kWRows, kThreads, PR>(P, bufA, P.strideA, item, ngran, G0, tid, det);
         int ent[2][4], cn[2][4];
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
@@ -717,11 +729,12 @@ __global__ __launch_bounds__(kThreads, 2) void group_mlp_wide_kernel(WideParams 
             cn[g >> 2][g & 3] = __builtin_amdgcn_readfirstlane(e >= 0 ? P.cnt[sa::plan_ball(e)] : 0);
         }
         __syncthreads();
-        if (tgl <= 1) wide_item_layers<1, PR>(WP, bufA, bufB, ent, cn, lane, w);
-        else if (tgl <= 2) wide_item_layers<2, PR>(WP, bufA, bufB, ent, cn, lane, w);
-        else wide_item_layers<4, PR>(WP, bufA, bufB, ent, cn, lane, w);
+        if (tgl <= 1) wide_item_layers<1, PR>(WP, bufA, bufB, ent, cn, lane, w, det);
+        else if (tgl <= 2) wide_item_layers<2, PR>(WP, bufA, bufB, ent, cn, lane, w, det);
+        else wide_item_layers<4, PR>(WP, bufA, bufB, ent, cn, lane, w, det);
         __syncthreads();
     }
+    if (PR == 1) sa::f16_overflow_report(det, P.ovf, lane);
 }
 
 // ---- dense layer on rows: y = act(x W + b), x [rows,K] fp32 -> y [rows,N] fp32 (conv1d 1x1:
@@ -934,7 +947,7 @@ __global__ __launch_bounds__(kDThreads) void vote_tail_kernel(VoteTailParams V) 
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float v[4] = {acc[0][4 * q + 0], acc[0][4 * q + 1], acc[0][4 * q + 2], acc[0][4 * q + 3]};
-                store_quad<3>(smem + col * stride2 + (4 * w + q) * 32 + half * 8, v);
+                store_quad_bf16(smem + col * stride2 + (4 * w + q) * 32 + half * 8, v);
             }
         }
         __syncthreads();
@@ -1134,7 +1147,7 @@ int roundup(int x, int q) { return (x + q - 1) / q * q; }
 int sa_rowwave_try(int b, int n, int m, int ns, int c, const float *xyz, const float *feat, const float *new_xyz,
                    const int *idx, const int *cnt, int nl, const int *dims, const void *const *wpack,
                    const float *const *bias, float *out, int out_stride, int out_off, const int *plan_hdr,
-                   const int *plan_gran, long max_tiles, int fp16, hipStream_t stream, int *st);
+                   const int *plan_gran, long max_tiles, int fp16, int *overflow, hipStream_t stream, int *st);
 
 // Upper bound of the plan length: next fit never leaves two consecutive tiles with a combined fill <= 4 granules, so
 // the list is shorter than twice the granules (+ the padding of the last tile).
@@ -1187,7 +1200,7 @@ extern "C" int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float 
                                 const float *new_xyz, const int *idx, const int *cnt, int nl,
                                 const int *dims, const void *const *wpack, const float *const *bias,
                                 float *out, int out_stride, int out_off, void *ws, size_t ws_bytes, int flags,
-                                hipStream_t stream) {
+                                int *overflow, hipStream_t stream) {
     if (b <= 0 || n <= 0 || m <= 0 || ns <= 0 || c < 0 || nl < 1 || nl > kMaxLayers) return SA_ERR_INVALID;
     if (!xyz || !new_xyz || !idx || !cnt || !out || !dims || !wpack || !bias) return SA_ERR_INVALID;
     if (c > 0 && !feat) return SA_ERR_INVALID;
@@ -1213,7 +1226,7 @@ extern "C" int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float 
     {
         int st = SA_OK;
         if (sa_rowwave_try(b, n, m, ns, c, xyz, feat, new_xyz, idx, cnt, nl, dims, wpack, bias, out, out_stride,
-                           out_off, hdr, gran, max_tiles, fp16 ? 1 : 0, stream, &st))
+                           out_off, hdr, gran, max_tiles, fp16 ? 1 : 0, overflow, stream, &st))
             return st;
     }
     const int abytes = fp16 ? 2 : 4;               // LDS bytes per activation channel (one fp16 plane / hi + lo bf16)
@@ -1221,7 +1234,7 @@ extern "C" int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float 
     P.xyz = xyz; P.feat = feat; P.new_xyz = new_xyz; P.idx = idx; P.cnt = cnt; P.out = out;
     P.n = n; P.m = m; P.ns = ns; P.C = c; P.nballs = nballs;
     P.out_stride = out_stride; P.out_off = out_off; P.nl = nl;
-    P.hdr = hdr; P.gran = gran;
+    P.hdr = hdr; P.gran = gran; P.ovf = overflow;
     int wA = roundup(dims[0], 16), wB = 0;
     for (int l = 0; l < nl; ++l) {
         P.L[l].w = (const uint4 *)wpack[l];
@@ -1248,7 +1261,7 @@ extern "C" int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float 
     const long nitems = max_tiles;             // the densest plan; workgroups past the planned tiles leave at once
     int max_nt = 0;
     for (int l = 0; l < nl; ++l) if (P.L[l].NT > max_nt) max_nt = P.L[l].NT;
-    static const int narrow_nt = getenv("SA_MLP_NARROW_NT") ? atoi(getenv("SA_MLP_NARROW_NT")) : 4;  // tuning knob
+    static const int narrow_nt = SA_KNOB("SA_MLP_NARROW_NT", 4);  // tuning knob
     const bool narrow = max_nt <= narrow_nt && lds <= 40 * 1024;   // default: <= 128 output channels everywhere
     if (narrow) {
         const int grid = (int)(nitems < 65536 ? nitems : 65536);
@@ -1260,7 +1273,7 @@ extern "C" int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float 
     // ---- wide path: 64-row items, last hidden layer chunked until the buffers fit
     // 64-row items halve the L2 weight traffic; measured faster only where that traffic is the bound -- the
     // 1024-channel last layer of layer4 (0.344 -> 0.307 ms); SA_MLP_WIDE=1/0 forces it on / off for every shape
-    static const int wide_env = getenv("SA_MLP_WIDE") ? atoi(getenv("SA_MLP_WIDE")) : -1;
+    static const int wide_env = SA_KNOB("SA_MLP_WIDE", -1);
     const bool use_wide = wide_env >= 0 ? wide_env != 0 : P.L[nl - 1].NT >= 32;
     if (use_wide && P.L[nl - 1].NT <= 4 * kNW) {
         WideParams WP{};
@@ -1306,7 +1319,7 @@ int sa_rowwave_try_layer(int b, int n, int m, const int *ns, int c, const float 
                          const float *new_xyz, const int *const *idx, const int *const *cnt, const int *dims,
                          const void *const *wpack, const float *const *bias, float *out, int out_stride,
                          const int *out_off, const int *const *plan_hdr, const int *const *plan_gran,
-                         const long *max_tiles, const int *fp16, hipStream_t stream, int *st);
+                         const long *max_tiles, const int *fp16, int *overflow, hipStream_t stream, int *st);
 
 // All scales of one SA layer (layers_util.py:134-181): scale i has nsample ns[i], index / count tensors idx[i] /
 // cnt[i], layer widths dims[i*(nl+1) ..], weights wpack[i*nl ..] / bias[i*nl ..], output slice out_off[i], plan
@@ -1316,7 +1329,8 @@ extern "C" int sa_group_mlp_max_layer(int nscale, int b, int n, int m, const int
                                       const float *feat, const float *new_xyz, const int *const *idx,
                                       const int *const *cnt, int nl, const int *dims, const void *const *wpack,
                                       const float *const *bias, float *out, int out_stride, const int *out_off,
-                                      void *const *ws, const size_t *ws_bytes, const int *flags, hipStream_t stream) {
+                                      void *const *ws, const size_t *ws_bytes, const int *flags, int *overflow,
+                                      hipStream_t stream) {
     if (nscale < 1 || !ns || !idx || !cnt || !dims || !wpack || !bias || !out_off || !ws || !ws_bytes || !flags)
         return SA_ERR_INVALID;
     if (nscale == 3 && nl == 3 && b > 0 && m > 0 && c >= 0 && xyz && new_xyz && out) {
@@ -1337,14 +1351,14 @@ extern "C" int sa_group_mlp_max_layer(int nscale, int b, int n, int m, const int
         if (ok) {
             int st = SA_OK;
             if (sa_rowwave_try_layer(b, n, m, ns, c, xyz, feat, new_xyz, idx, cnt, dims, wpack, bias, out, out_stride,
-                                     out_off, hdr, gran, max_tiles, fp16, stream, &st))
+                                     out_off, hdr, gran, max_tiles, fp16, overflow, stream, &st))
                 return st;
         }
     }
     for (int i = 0; i < nscale; ++i) {
         const int st = sa_group_mlp_max(b, n, m, ns[i], c, xyz, feat, new_xyz, idx[i], cnt[i], nl, dims + (nl + 1) * i,
                                         wpack + nl * i, bias + nl * i, out, out_stride, out_off[i], ws[i], ws_bytes[i],
-                                        flags[i], stream);
+                                        flags[i], overflow, stream);
         if (st != SA_OK) return st;
     }
     return SA_OK;

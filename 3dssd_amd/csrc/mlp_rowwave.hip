@@ -19,6 +19,7 @@
 
 #include "sa_common.h"
 #include "mlp_plan.h"
+#include "mlp_act.h"
 
 namespace {
 
@@ -41,6 +42,7 @@ struct RwParams {
     int N3;        // true output channels of the last layer
     const int *gran;   // row plan (mlp_plan.h): granule entries, 4 per 32-row tile
     const int *hdr;    // hdr[0] = number of granules (written by mlp_plan_kernel earlier on the stream)
+    int *ovf;          // fp16 form: raised when a converted activation left the fp16 range (mlp_act.h); may be null
 };
 
 __device__ __forceinline__ f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) {
@@ -71,16 +73,15 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4 &hi, uint4 &lo
     split2(v[4], v[5], hi.z, lo.z);
     split2(v[6], v[7], hi.w, lo.w);
 }
-// the fp16 operand form (PR == 1, see mlp.hip "Operand precision"): one plane, v_cvt_pk_f16_f32 (nearest even)
-__device__ __forceinline__ unsigned cvt2_f16(float a, float b) {
-    const f32x2 v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
-}
-// 8 fp32 -> the operand planes of precision PR (lo is untouched for PR == 1)
+// 8 fp32 -> the operand planes of precision PR (lo is untouched for PR == 1).  The fp16 operand form (PR == 1, see
+// mlp.hip "Operand precision") is one plane, v_cvt_pk_f16_f32 (nearest even); `det` is the range guard of mlp_act.h.
 template <int PR>
-__device__ __forceinline__ void to_planes(const float (&v)[8], uint4 &hi, uint4 &lo) {
+__device__ __forceinline__ void to_planes(const float (&v)[8], uint4 &hi, uint4 &lo, sa::f16_guard_t &det) {
     if (PR == 3) split8(v, hi, lo);
-    else hi = make_uint4(cvt2_f16(v[0], v[1]), cvt2_f16(v[2], v[3]), cvt2_f16(v[4], v[5]), cvt2_f16(v[6], v[7]));
+    else {
+        hi = make_uint4(sa::cvt2_f16(v[0], v[1]), sa::cvt2_f16(v[2], v[3]), sa::cvt2_f16(v[4], v[5]), sa::cvt2_f16(v[6], v[7]));
+        sa::f16_guard_signed(hi, det);
+    }
 }
 
 #ifdef SA_RW_TIMING
@@ -162,7 +163,7 @@ __device__ __forceinline__ void load_group(const RwParams &P, const RowRef &rr, 
 // acc (D^T form: reg r of lane (row, h) = channel (r&3) + 8*(r>>2) + 4h of the tile) -> ReLU -> the two
 // B-operand fragments (k-steps 2*ct and 2*ct+1 of the next layer) of this lane
 template <int KSN, int PR = 3>
-__device__ __forceinline__ void acc_to_frags(const f32x16 &acc, int ct, uint4 (&fh)[KSN], uint4 (&fl)[KSN]) {
+__device__ __forceinline__ void acc_to_frags(const f32x16 &acc, int ct, uint4 (&fh)[KSN], uint4 (&fl)[KSN], sa::f16_guard_t &det) {
 #pragma unroll
     for (int hk = 0; hk < 2; ++hk) {
         if (2 * ct + hk < KSN) {
@@ -179,12 +180,13 @@ __device__ __forceinline__ void acc_to_frags(const f32x16 &acc, int ct, uint4 (&
                 }
                 split8(v, fh[2 * ct + hk], fl[2 * ct + hk]);
             } else {
-                // fp16: convert first, then swap the PACKED pairs -- half the cross-half moves
+                // fp16: convert (+ packed ReLU + range guard, mlp_act.h) first, then swap the PACKED pairs -- half the
+                // cross-half moves
                 unsigned pa[2], pb[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    pa[j] = cvt2_f16(sa::fmax_nn(acc[8 * hk + 2 * j], 0.0f), sa::fmax_nn(acc[8 * hk + 2 * j + 1], 0.0f));
-                    pb[j] = cvt2_f16(sa::fmax_nn(acc[8 * hk + 4 + 2 * j], 0.0f), sa::fmax_nn(acc[8 * hk + 4 + 2 * j + 1], 0.0f));
+                    pa[j] = sa::cvt2_f16_relu(acc[8 * hk + 2 * j], acc[8 * hk + 2 * j + 1]);
+                    pb[j] = sa::cvt2_f16_relu(acc[8 * hk + 4 + 2 * j], acc[8 * hk + 4 + 2 * j + 1]);
                 }
                 uint4 f;
                 {
@@ -193,6 +195,7 @@ __device__ __forceinline__ void acc_to_frags(const f32x16 &acc, int ct, uint4 (&
                     f = make_uint4(s0[0], s1[0], s0[1], s1[1]);
                 }
                 fh[2 * ct + hk] = f;
+                sa::f16_guard(f, det);
             }
         }
     }
@@ -232,7 +235,7 @@ __device__ __forceinline__ void hidden_layer(const uint4 *W, const float *bias, 
         }
 #pragma unroll
         for (int tt = 0; tt < TG; ++tt)
-            if (ct0 + tt < NT) acc_to_frags<KSN>(acc[tt], ct0 + tt, oh, ol);
+            if (ct0 + tt < NT) { sa::f16_guard_t nodet = 0; acc_to_frags<KSN>(acc[tt], ct0 + tt, oh, ol, nodet); }
     }
 }
 
@@ -540,6 +543,7 @@ __device__ __forceinline__ void rs_body(const RwParams &P) {
         for (int ks = 0; ks < KS0; ++ks) load_group(P, cur, tl, 2 * ks + half, raw[ks]);
     }
     RowRef nxt = load_row_ref(P, ngran, tf, row);
+    sa::f16_guard_t det = 0;                 // fp16 range guard (mlp_act.h), scalar registers
 
     RW_TICK(0)
     for (int q = 0; q < npass; ++q) {
@@ -551,7 +555,7 @@ __device__ __forceinline__ void rs_body(const RwParams &P) {
         }
         uint4 h0[KS0], l0[KS0];
 #pragma unroll
-        for (int ks = 0; ks < KS0; ++ks) to_planes<PR>(raw[ks], h0[ks], l0[ks]);
+        for (int ks = 0; ks < KS0; ++ks) to_planes<PR>(raw[ks], h0[ks], l0[ks], det);
         int ent[4], cn[4];                       // the tile's plan entries / ball counts, wave-uniform
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -567,7 +571,7 @@ __device__ __forceinline__ void rs_body(const RwParams &P) {
             f32x16 ae;
             load_bias_tile(b0, ct, half, ae);
             rs_tile_mma<KS0, G, PR, NW, PPW, DEPTH, CPP, true>(P, X, stage, h0, l0, ct * KS0, ae);
-            acc_to_frags<KS1, PR>(ae, ct, h1, l1);
+            acc_to_frags<KS1, PR>(ae, ct, h1, l1, det);
         }
         RW_TICK(2)
         // ---- hidden layer 1
@@ -577,7 +581,7 @@ __device__ __forceinline__ void rs_body(const RwParams &P) {
             f32x16 ae;
             load_bias_tile(b1, ct, half, ae);
             rs_tile_mma<KS1, G, PR, NW, PPW, DEPTH, CPP, true>(P, X, stage, h1, l1, KT0 + ct * KS1, ae);
-            acc_to_frags<KS2, PR>(ae, ct, h2, l2);
+            acc_to_frags<KS2, PR>(ae, ct, h2, l2, det);
         }
         RW_TICK(3)
         // ---- last layer (D form), granule maxima, relu(max + bias) written per ball run (layers_util.py:178-181)
@@ -606,6 +610,7 @@ __device__ __forceinline__ void rs_body(const RwParams &P) {
         nxt = load_row_ref(P, ngran, tf, row);
         RW_TICK(5)
     }
+    if (PR == 1) sa::f16_overflow_report(det, P.ovf, lane);
     RW_FLUSH(gw)
 }
 template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF, int DEPTH, int PR, int CPP, int PF>
@@ -715,8 +720,8 @@ bool sig_is(const ScaleSig &s, int a, int b, int c, int d, int e, int f) {
 static bool rowwave_scale(int b, int n, int m, int ns, int c, const float *xyz, const float *feat, const float *new_xyz,
                           const int *idx, const int *cnt, int nl, const int *dims, const void *const *wpack,
                           const float *const *bias, float *out, int out_stride, int out_off, const int *plan_hdr,
-                          const int *plan_gran, long max_tiles, RwParams &P, ScaleSig &S) {
-    static const bool enabled = !(getenv("SA_MLP_ROWWAVE") && atoi(getenv("SA_MLP_ROWWAVE")) == 0);
+                          const int *plan_gran, long max_tiles, int *overflow, RwParams &P, ScaleSig &S) {
+    static const bool enabled = SA_KNOB("SA_MLP_ROWWAVE", 1) != 0;
     if (!enabled || nl != 3) return false;
     if (!(c == 1 || (c > 0 && (c & 7) == 0))) return false;  // input layouts the in-register gather handles
     // 32-bit element offsets everywhere (and a float-exact ball / m)
@@ -734,7 +739,7 @@ static bool rowwave_scale(int b, int n, int m, int ns, int c, const float *xyz, 
     P.n = n; P.m = m; P.ns = ns; P.C = c; P.nballs = (long)b * m;
     P.out_stride = out_stride; P.out_off = out_off;
     P.N3 = dims[3];
-    P.hdr = plan_hdr; P.gran = plan_gran;
+    P.hdr = plan_hdr; P.gran = plan_gran; P.ovf = overflow;
     P.m_shift = -1;
     for (int sft = 0; sft < 31; ++sft) if (m == (1 << sft)) P.m_shift = sft;
     P.inv_m = 1.0f / (float)m;
@@ -752,16 +757,16 @@ int sa_rowwave_try_layer(int b, int n, int m, const int *ns, int c, const float 
                          const float *new_xyz, const int *const *idx, const int *const *cnt, const int *dims,
                          const void *const *wpack, const float *const *bias, float *out, int out_stride,
                          const int *out_off, const int *const *plan_hdr, const int *const *plan_gran,
-                         const long *max_tiles, const int *fp16, hipStream_t stream, int *st) {
-    static const bool on = !(getenv("SA_MLP_MULTI") && atoi(getenv("SA_MLP_MULTI")) == 0);
-    static const bool stream_enabled = !(getenv("SA_MLP_ROWSTREAM") && atoi(getenv("SA_MLP_ROWSTREAM")) == 0);
+                         const long *max_tiles, const int *fp16, int *overflow, hipStream_t stream, int *st) {
+    static const bool on = SA_KNOB("SA_MLP_MULTI", 1) != 0;
+    static const bool stream_enabled = SA_KNOB("SA_MLP_ROWSTREAM", 1) != 0;
     if (!on) return 0;
     RwParams P[3];
     ScaleSig S[3];
     long mt[3];
     for (int i = 0; i < 3; ++i) {
         if (!rowwave_scale(b, n, m, ns[i], c, xyz, feat, new_xyz, idx[i], cnt[i], 3, dims + 4 * i, wpack + 3 * i,
-                           bias + 3 * i, out, out_stride, out_off[i], plan_hdr[i], plan_gran[i], max_tiles[i], P[i], S[i]))
+                           bias + 3 * i, out, out_stride, out_off[i], plan_hdr[i], plan_gran[i], max_tiles[i], overflow, P[i], S[i]))
             return 0;
         mt[i] = max_tiles[i];
     }
@@ -793,11 +798,11 @@ int sa_rowwave_try_layer(int b, int n, int m, const int *ns, int c, const float 
 int sa_rowwave_try(int b, int n, int m, int ns, int c, const float *xyz, const float *feat, const float *new_xyz,
                    const int *idx, const int *cnt, int nl, const int *dims, const void *const *wpack,
                    const float *const *bias, float *out, int out_stride, int out_off, const int *plan_hdr,
-                   const int *plan_gran, long max_tiles, int fp16, hipStream_t stream, int *st) {
+                   const int *plan_gran, long max_tiles, int fp16, int *overflow, hipStream_t stream, int *st) {
     RwParams P;
     ScaleSig S;
     if (!rowwave_scale(b, n, m, ns, c, xyz, feat, new_xyz, idx, cnt, nl, dims, wpack, bias, out, out_stride, out_off,
-                       plan_hdr, plan_gran, max_tiles, P, S))
+                       plan_hdr, plan_gran, max_tiles, overflow, P, S))
         return 0;
     const int KS0 = S.KS0, NT1 = S.NT1, KS1 = S.KS1, NT2 = S.NT2, KS2 = S.KS2, NT3 = S.NT3;
 #define SA_RW(K0, N1, K1, N2, K2, N3_, NW_, WPE_, WGS)                                              \
@@ -814,7 +819,7 @@ int sa_rowwave_try(int b, int n, int m, int ns, int c, const float *xyz, const f
     // the streamed kernel walks the three layers as one linear weight stream: they must be packed back to back
     // (utils/weights.py pack_scale does that); separately allocated layers take the generic kernel
     const bool contiguous = rowwave_contiguous(S, wpack, fp16);
-    static const bool stream_enabled = !(getenv("SA_MLP_ROWSTREAM") && atoi(getenv("SA_MLP_ROWSTREAM")) == 0);
+    static const bool stream_enabled = SA_KNOB("SA_MLP_ROWSTREAM", 1) != 0;
 #define SA_RS(K0, N1, K1, N2, K2, N3_, NW_, WPE_, WGS, D_, PR_, CPP_, PF_)                              \
     if (stream_enabled && contiguous && c != 1 && (PR_ == 1) == (fp16 != 0) && KS0 == K0 && NT1 == N1 && KS1 == K1 && NT2 == N2 && KS2 == K2 && NT3 == N3_) { \
         *st = launch_rs<K0, N1, K1, N2, K2, N3_, NW_, WPE_, 0, D_, PR_, CPP_, PF_>(P, max_tiles, WGS, stream); \

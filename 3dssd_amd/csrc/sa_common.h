@@ -14,6 +14,17 @@
         if (e__ != hipSuccess) return SA_ERR_LAUNCH;       \
     } while (0)
 
+// Kernel-selection knobs for A/B measurements.  The PRODUCT build reads nothing from the environment (the library is
+// stateless and its behaviour a function of its arguments only): SA_KNOB(name, default) is the constant `default`.
+// `make TUNE=1` (-DSA_TUNING_KNOBS, output lib3dssd_sa_tune.so, loaded by tools/ through 3dssd_amd.utils._native.LIB_PATH)
+// makes it getenv(name), read once.
+#ifdef SA_TUNING_KNOBS
+#include <stdlib.h>
+#define SA_KNOB(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#else
+#define SA_KNOB(name, dflt) (dflt)
+#endif
+
 namespace sa {
 
 // ---- DPP cross-lane moves (wave64, gfx9 encodings) ---------------------------------------

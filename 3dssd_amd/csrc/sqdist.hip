@@ -658,13 +658,13 @@ extern "C" int sa_calc_square_dist_split(int b, int n, int m, int c0, int c1, co
     if (b <= 0 || n <= 0 || m <= 0 || c0 <= 0 || c1 < 0 || !a0 || !b0 || !out) return SA_ERR_INVALID;
     if (c1 > 0 && (!a1 || !b1)) return SA_ERR_INVALID;
     RowSrc A{a0, c0, a1, c1}, Bm{b0, c0, b1, c1};
-    static const bool use_valu = getenv("SA_SQDIST_VALU") && atoi(getenv("SA_SQDIST_VALU")) != 0;
+    static const bool use_valu = SA_KNOB("SA_SQDIST_VALU", 0) != 0;
     if (use_valu) {
         dim3 grid((m + kT - 1) / kT, (n + kT - 1) / kT, b);
         hipLaunchKernelGGL(sqdist_kernel, grid, dim3(256), 0, stream, n, m, A, Bm, out);
     } else {
         // second form: needs the feature piece readable as float4 and tile-relative offsets that fit 32 bits
-        static const bool v1_only = getenv("SA_SQDIST_V1") && atoi(getenv("SA_SQDIST_V1")) != 0;
+        static const bool v1_only = SA_KNOB("SA_SQDIST_V1", 0) != 0;
         const bool v2 = !v1_only && (c1 % 4) == 0 && ((uintptr_t)a1 % 16) == 0 && ((uintptr_t)b1 % 16) == 0 &&
                         (long)kMT * (m > n ? m : n) + kMT < (1l << 31);
         const bool nt = (size_t)b * n * m * sizeof(float) > ((size_t)192 << 20);
@@ -708,7 +708,7 @@ static int sqdist_split_ws_impl(int b, int n, int m, int c0, int c1, const float
     if (b <= 0 || n <= 0 || m <= 0 || c0 <= 0 || c1 < 0 || !a0 || !b0 || !out) return SA_ERR_INVALID;
     if (c1 > 0 && (!a1 || !b1)) return SA_ERR_INVALID;
     const bool strided = (rs0 != 0 && rs0 != n) || (rs1 != 0 && rs1 != n);
-    static const bool packed_on = !(getenv("SA_SQDIST_PACKED") && atoi(getenv("SA_SQDIST_PACKED")) == 0);
+    static const bool packed_on = SA_KNOB("SA_SQDIST_PACKED", 1) != 0;
     const long big = (long)kMT * (m > n ? m : n) + kMT;
     if (!workspace || !packed_on || big >= (1l << 31) || ((uintptr_t)workspace % 16) != 0 || b > 65535) {
         if (strided) return SA_ERR_UNSUPPORTED;

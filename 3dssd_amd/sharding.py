@@ -18,13 +18,16 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init(backend=None):
+def init(backend=None, device_index=None):
+    """Process group of the node's ranks.  backend None: "nccl" (= RCCL) on GPUs, "gloo" on CPU.  device_index: the GPU
+    this rank uses (default LOCAL_RANK); ranks that SHARE a device (a functional check on a box with fewer GPUs than
+    ranks) must use "gloo" -- RCCL refuses two ranks on one device."""
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)        # RCCL binds its communicator to the current device
+            torch.cuda.set_device(local_rank if device_index is None else device_index)   # RCCL binds its communicator to the current device
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
@@ -43,9 +46,12 @@ def barrier():
 
 
 def reduce_timing(elapsed_s, frames_done, device="cpu"):
-    """(max elapsed over ranks, total frames over ranks)."""
+    """(max elapsed over ranks, total frames over ranks).  `device`: where the two scalars live for the reduction (the
+    rank's GPU under RCCL; ignored -- CPU -- under gloo)."""
     if not dist.is_initialized():
         return float(elapsed_s), int(frames_done)
+    if dist.get_backend() != "nccl":
+        device = "cpu"
     t = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=device)
     c = torch.tensor([float(frames_done)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -40,6 +40,38 @@ def kitti_like_batch(batch, n=16384, first_frame=0, dup_fraction=0.0):
     return np.stack([kitti_like_frame(first_frame + i, n, dup_fraction) for i in range(batch)])
 
 
+# Uniform-density WORST case of the distinct-row plan and of the culled samplers (bench.py --data dense): n points drawn
+# uniformly from a 3 m x 1 m x 3 m box = 1 820 points per cubic metre at n = 16384, i.e. ~61 points inside a radius-0.2
+# ball, so that every ball of every layer is full (nsample distinct rows, evaluated_frac -> 1), every ball-query band
+# overflows its candidate lists, and a D-FPS pick touches many buckets.  Not a LiDAR frame: a sensitivity bound.
+DENSE_BOX = ((-1.5, 1.5), (0.6, 1.6), (10.0, 13.0))
+
+
+def dense_frame(frame_id, n=16384):
+    rng = np.random.default_rng(FRAME_SEED + 7919 + int(frame_id))
+    pts = np.empty((n, 4), np.float32)
+    for a, (lo, hi) in enumerate(DENSE_BOX):
+        pts[:, a] = rng.uniform(lo, hi, n).astype(np.float32)
+    pts[:, 3] = rng.uniform(0.0, 1.0, n).astype(np.float32)
+    return pts
+
+
+DATA_VARIANTS = ("default", "dup10", "dense")
+
+
+def frame_of(variant, frame_id, n=16384):
+    """One frame of a bench.py --data variant: default = kitti_like_frame, dup10 = the same with 10 % of the rows
+    duplicated (the loader's with-replacement padding, kitti_dataloader.py:142-147; SURVEY.md 8d "KITTI-padded"),
+    dense = dense_frame."""
+    if variant == "default":
+        return kitti_like_frame(frame_id, n)
+    if variant == "dup10":
+        return kitti_like_frame(frame_id, n, dup_fraction=0.1)
+    if variant == "dense":
+        return dense_frame(frame_id, n)
+    raise ValueError("unknown data variant %r (one of %s)" % (variant, ", ".join(DATA_VARIANTS)))
+
+
 def _xavier(rng, cin, cout):
     lim = np.sqrt(6.0 / (cin + cout))  # tf.contrib.layers.xavier_initializer, tf_util.py:41
     return rng.uniform(-lim, lim, (cin, cout)).astype(np.float32)

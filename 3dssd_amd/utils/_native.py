@@ -27,19 +27,20 @@ SIGNATURES = {
     "sa_fps_dual_ex": [_c_int] * 3 + [_vp, _vp, _c_int, _c_int, _vp, _c_long, _vp, _c_long, _c_int, _c_int, _vp, _c_long, _vp,
                        _c_int, _c_int, _vp, _c_long, _vp],
     "sa_group_mlp_max_layer": [_c_int] * 4 + [_vp, _c_int, _vp, _vp, _vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _vp,
-                               _vp, _vp, _vp],
+                               _vp, _vp, _vp, _vp],
     "sa_fps_ex2": [_c_int] * 4 + [_vp, _c_long, _vp, _vp, _c_int, _c_int, _vp, _c_long, _vp],
     "sa_fps_bucket_ex2": [_c_int] * 3 + [_vp, _c_long, _vp, _c_int, _c_int, _vp, _c_long, _vp],
     "sa_fps_with_distance_ex2": [_c_int] * 3 + [_vp, _vp, _vp, _c_int, _c_int, _vp, _c_long, _vp, _c_long, _vp],
     "sa_calc_square_dist_self_ws": [_c_int] * 4 + [_vp, _c_int, _vp, _c_int, _vp, _vp, _vp],
     "sa_fps_bucket_ex": [_c_int] * 3 + [_vp, _vp, _c_int, _c_int, _vp],
+    "sa_fps_bucket_stats": [_c_int] * 3 + [_vp, _vp, _vp, _vp],
     "sa_fps_generic": [_c_int] * 4 + [_vp, _vp, _vp, _c_int, _vp],
     "sa_calc_square_dist_split": [_c_int] * 5 + [_vp, _vp, _vp, _vp, _vp, _vp],
     "sa_calc_square_dist_split_ws": [_c_int] * 5 + [_vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sa_query_ball_point_multi": [_c_int] * 4 + [_vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _vp],
     "sa_query_ball_point_grid": [_c_int] * 4 + [_vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _vp, _vp],
     "sa_group_mlp_max": [_c_int] * 5 + [_vp] * 5 + [_c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp,
-                         ctypes.c_size_t, _c_int, _vp],
+                         ctypes.c_size_t, _c_int, _vp, _vp],
     "sa_group_mlp_plan": [_c_int] * 3 + [_vp, _vp, _vp, _vp, _c_int, _vp, _vp, _c_int, _vp],
     "sa_dense": [_c_long, _c_int, _c_int, _vp, _vp, _vp, _c_int, _vp, _vp],
     "sa_decode_anchor_free": [_c_int] * 4 + [_vp] * 7,

@@ -41,13 +41,11 @@ AGGREGATION_SA_FEATURE = True
 #                second concurrent queue, throughput as mode 2 (10.4 k frames/s), +5 % in a 20-step run; the same launch
 #                on the issuing stream (5) gives 7.9 k -- a captured graph WITHOUT a helper-stream branch loses a quarter
 #                of the 16-stream throughput (also seen with modes 0 / 3), for reasons inside the graph executor.
-DFPS_SIDE_STREAM = int(__import__("os").environ.get("SA_DFPS_SIDE_STREAM", "6"))
-# timing experiments only (tools/ablate.sh): comma-separated kernel classes whose launches are SKIPPED (results are
-# then garbage): mlp:<scope>, dense, sqdist, fpsdist, dfps:<n>, bq, plan
-_ABLATE = set(filter(None, __import__("os").environ.get("SA_ABLATE", "").split(",")))
+# These are plain module attributes: nothing in the package reads the environment (experiments set them from tools/).
+DFPS_SIDE_STREAM = 6
 PLAN_LOG = None     # set to a list to collect (b, m, nsample, MACs per row, plan tensor) of every fused-MLP call
-MLP_PLAN_FLAGS = int(__import__("os").environ.get("SA_MLP_DENSE_PLAN", "0"))
-GRID_BALL_QUERY_MIN_N = int(__import__("os").environ.get("SA_GRID_BQ_MIN_N", "2048"))
+MLP_PLAN_FLAGS = 0  # sa_group_mlp_max flag bit 0 (all nsample rows instead of the distinct ones), A/B measurements
+GRID_BALL_QUERY_MIN_N = 2048
 MAX_TRANSLATE_RANGE = (-3.0, -2.0, -3.0)
 
 
@@ -58,8 +56,6 @@ def _dense(x, layer, relu):
     """tf_util.conv1d 1x1 (+ folded BN) (+ ReLU) on [..., K] -> [..., N]."""
     rows = x.numel() // layer.K
     y = torch.empty(x.shape[:-1] + (layer.N,), dtype=torch.float32, device=x.device)
-    if "dense" in _ABLATE:
-        return y
     st = N.lib().sa_dense(rows, layer.K, layer.N, x.data_ptr(), layer.w.data_ptr(), layer.bias.data_ptr(),
                           1 if relu else 0, y.data_ptr(), N.current_stream())
     N.check(st, "dense")
@@ -77,7 +73,7 @@ def vote_layer(xyz, points, mlp_list, is_training, bn_decay, bn, scope, variable
     lo = MAX_TRANSLATE_RANGE
     for layer in hidden[:-1]:
         points = _dense(points, layer, relu=True)
-    if hidden and "dense" not in _ABLATE:
+    if hidden:
         # the last hidden layer, the offset layer and the translation in one launch (three before)
         h = hidden[-1]
         rows = points.numel() // h.K
@@ -117,23 +113,20 @@ def _ffps_into(npoint, xyz, points, start, end, out, col, ctr, matrix_only=False
     # packed form: the operand is laid out once in the matrix kernel's LDS image, tiles are staged by plain copies
     ws = torch.empty((lib.sa_calc_square_dist_ws_bytes(b, n, n, 3 + c1, 1) + 3) // 4, dtype=torch.float32, device=dev)
     keep = None
-    if "sqdist" not in _ABLATE:
-        st = lib.sa_calc_square_dist_self_ws(b, n, 3, c1, xp, n_all, pp, n_all, dist.data_ptr(), ws.data_ptr(),
-                                             N.current_stream())
-        if st == _UNSUPPORTED:                      # strided sources need the packed form: copy the slice instead
-            keep = (xyz[:, start:end].contiguous(), points[:, start:end].contiguous())
-            st = lib.sa_calc_square_dist_split_ws(b, n, n, 3, c1, keep[0].data_ptr(), keep[1].data_ptr(),
-                                                  keep[0].data_ptr(), keep[1].data_ptr(), dist.data_ptr(),
-                                                  ws.data_ptr(), N.current_stream())
-        N.check(st, "calc_square_dist")
+    st = lib.sa_calc_square_dist_self_ws(b, n, 3, c1, xp, n_all, pp, n_all, dist.data_ptr(), ws.data_ptr(),
+                                         N.current_stream())
+    if st == _UNSUPPORTED:                          # strided sources need the packed form: copy the slice instead
+        keep = (xyz[:, start:end].contiguous(), points[:, start:end].contiguous())
+        st = lib.sa_calc_square_dist_split_ws(b, n, n, 3, c1, keep[0].data_ptr(), keep[1].data_ptr(),
+                                              keep[0].data_ptr(), keep[1].data_ptr(), dist.data_ptr(),
+                                              ws.data_ptr(), N.current_stream())
+    N.check(st, "calc_square_dist")
     if matrix_only:
         return dist
     temp = torch.empty((b, n), dtype=torch.float32, device=dev) if n > 16384 else None
     done = [False]
 
     def chain():
-        if "fpsdist" in _ABLATE:
-            return
         tp = temp.data_ptr() if temp is not None else None
         if ctr is not None:
             st = lib.sa_fps_with_distance_ex2(b, n, npoint, dist.data_ptr(), tp, out.data_ptr() + 4 * col, out.shape[1],
@@ -171,10 +164,16 @@ _IDENTITY_IDX = {}
 
 
 def _identity_idx(bs, start, cnt, dev):
-    """[bs, cnt] int32 tensor of start .. start+cnt-1 in every row (read-only, shared between calls)."""
+    """[bs, cnt] int32 tensor of start .. start+cnt-1 in every row.  READ-ONLY: the tensor is shared between calls (it
+    is the layer's `fps_idx` output when sampling is the identity, layers_util.py:92,100); a caller that wants to edit it
+    must clone it.  Never cached from inside a hipGraph capture: a tensor created there lives in that graph's private
+    pool and holds garbage until that graph replays."""
     key = (bs, start, cnt, str(dev))
     if key not in _IDENTITY_IDX:
-        _IDENTITY_IDX[key] = torch.arange(start, start + cnt, dtype=torch.int32, device=dev)[None].repeat(bs, 1).contiguous()
+        t = torch.arange(start, start + cnt, dtype=torch.int32, device=dev)[None].repeat(bs, 1).contiguous()
+        if torch.cuda.is_current_stream_capturing():
+            return t
+        _IDENTITY_IDX[key] = t
     return _IDENTITY_IDX[key]
 
 
@@ -198,17 +197,16 @@ def _dfps_into(npoint, xyz, start, end, out, col, ctr):
     done = [False]
 
     def chain():
-        if ("dfps:%d" % n) in _ABLATE:
-            return
         lib = N.lib()
         xp = xyz.data_ptr() + 4 * c * start
-        st = lib.sa_fps_ex2(b, n, c, npoint, xp, c * n_all, None, out.data_ptr() + 4 * col, out.shape[1], start,
-                            ctr.data_ptr() + 4 * 3 * col if ctr is not None else None,
-                            3 * ctr.shape[1] if ctr is not None else 0, N.current_stream())
-        if st != _UNSUPPORTED:
-            N.check(st, "farthest_point_sample")
-            done[0] = ctr is not None
-            return
+        if c == 3 and n <= 16384:                   # the register-resident kernels: no scratch, range read in place
+            st = lib.sa_fps_ex2(b, n, c, npoint, xp, c * n_all, None, out.data_ptr() + 4 * col, out.shape[1], start,
+                                ctr.data_ptr() + 4 * 3 * col if ctr is not None else None,
+                                3 * ctr.shape[1] if ctr is not None else 0, N.current_stream())
+            if st != _UNSUPPORTED:
+                N.check(st, "farthest_point_sample")
+                done[0] = ctr is not None
+                return
         # frames that do not fit the register-resident kernels: dense copy of the range, scratch, separate gather
         src = xyz if (start == 0 and end == n_all) else xyz[:, start:end].contiguous()
         temp = torch.empty((b, n), dtype=torch.float32, device=dev)
@@ -287,7 +285,7 @@ def sample_layer(xyz, points, fps_sample_range_list, fps_method_list, npoint_lis
     # ---- one matrix sampler + one coordinate sampler (an 'FS' range, or an F-FPS range and a D-FPS range): ONE launch
     #      for both (sa_fps_dual_ex, modes 5 / 6); anything else takes the per-sampler path below
     dual_done = f_handled = False
-    if DFPS_SIDE_STREAM in (5, 6) and "fpsdist" not in _ABLATE:
+    if DFPS_SIDE_STREAM in (5, 6):
         fparts = [(s0, e0, (c // 2 if k == "FS" else c), c0) for k, s0, e0, c, c0 in work if k in ("FS", "F-FPS")]
         dparts = [(s0, e0, (c // 2 if k == "FS" else c), (c0 + c // 2 if k == "FS" else c0)) for k, s0, e0, c, c0 in work
                   if k in ("FS", "D-FPS")]
@@ -322,8 +320,9 @@ def sample_layer(xyz, points, fps_sample_range_list, fps_method_list, npoint_lis
                 centres_ok = centres_ok and new_xyz is not None
                 work = []
             else:                                           # sizes the dual kernel does not take: sampler by sampler
-                st = lib.sa_fps_with_distance_ex(bs, fe - fs, fm, dist.data_ptr(), None, fps_idx.data_ptr() + 4 * fc,
-                                                 fps_idx.shape[1], fs, N.current_stream())
+                tmp = torch.empty((bs, fe - fs), dtype=torch.float32, device=dev) if fe - fs > 16384 else None
+                st = lib.sa_fps_with_distance_ex(bs, fe - fs, fm, dist.data_ptr(), tmp.data_ptr() if tmp is not None else None,
+                                                 fps_idx.data_ptr() + 4 * fc, fps_idx.shape[1], fs, N.current_stream())
                 N.check(st, "farthest_point_sample_with_distance")
                 centres_ok = False
                 work = [wk for wk in work if wk[0] == "D-FPS"] + [("D-FPS", s0, e0, c // 2, c0 + c // 2)
@@ -404,13 +403,7 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
         nsa = (ctypes.c_int * nscale)(*[int(v) for v in nsample_list])
         idxp = (ctypes.c_void_p * nscale)(*[t.data_ptr() for t in idx_list])
         cntp = (ctypes.c_void_p * nscale)(*[t.data_ptr() for t in cnt_list])
-        if "bq" in _ABLATE:
-            st = 0
-            for t_ in cnt_list:
-                t_.fill_(1)
-            for t_ in idx_list:
-                t_.zero_()
-        elif n_all >= GRID_BALL_QUERY_MIN_N and nscale <= 4:
+        if n_all >= GRID_BALL_QUERY_MIN_N and nscale <= 4:
             # large frames: per-frame x-z grid, candidates from the 3 x 3 cells around each centre (same outputs)
             ws = torch.empty((lib.sa_query_ball_point_grid_ws_bytes(bs, n_all, m) + 3) // 4, dtype=torch.int32, device=dev)
             st = lib.sa_query_ball_point_grid(bs, n_all, m, nscale, rmin, rmax, nsa, 1 if dilated_group else 0,
@@ -432,7 +425,7 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
             offs.append(acc)
             acc += ls[-1].N
         have_plans = nscale <= 4
-        if have_plans and "plan" not in _ABLATE:
+        if have_plans:
             st = lib.sa_group_mlp_plan(bs, m, nscale, nsa, cntp, (ctypes.c_void_p * nscale)(*[p[0].data_ptr() for p in plans]),
                                        new_points_concat.data_ptr(), ctot, (ctypes.c_int * nscale)(*offs),
                                        (ctypes.c_int * nscale)(*[ls[-1].N for ls in layers]), MLP_PLAN_FLAGS, stream)
@@ -440,9 +433,8 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
         # ---- the grouped MLPs of all scales: ONE C-ABI call per layer (one launch for the three-scale layers of the
         #      reference configuration: the scales are independent, every launch costs ~2 us of throughput)
         nls = {len(ls) for ls in layers}
-        ablated = [("mlp:%s" % scope) in _ABLATE or ("mlp:%s:%d" % (scope, i)) in _ABLATE for i in range(nscale)]
-        live = [i for i in range(nscale) if not ablated[i]]
-        if len(nls) == 1 and live:
+        live = list(range(nscale))
+        if len(nls) == 1:
             nl = nls.pop()
             k = len(live)
             dims_a = (ctypes.c_int * (k * (nl + 1)))(*[v for i in live for v in ([c_feat + 3] + [l.N for l in layers[i]])])
@@ -456,7 +448,7 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
                 (ctypes.c_void_p * k)(*[plans[i][0].data_ptr() for i in live]),
                 (ctypes.c_ulong * k)(*[plans[i][1] for i in live]),
                 (ctypes.c_int * k)(*[MLP_PLAN_FLAGS | (2 if have_plans else 0) | W.scale_flags(layers[i]) for i in live]),
-                stream)
+                vs.overflow.data_ptr(), stream)
             N.check(st, "group_mlp_max_layer")
         else:                                                               # scales of different depth: one by one
             for i in live:
@@ -469,7 +461,8 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
                                           points.data_ptr(), new_xyz.data_ptr(), idx_list[i].data_ptr(),
                                           cnt_list[i].data_ptr(), nl, dims, wp, bp,
                                           new_points_concat.data_ptr(), ctot, offs[i], plans[i][0].data_ptr(), plans[i][1],
-                                          MLP_PLAN_FLAGS | (2 if have_plans else 0) | W.scale_flags(ls), stream)
+                                          MLP_PLAN_FLAGS | (2 if have_plans else 0) | W.scale_flags(ls),
+                                          vs.overflow.data_ptr(), stream)
                 N.check(st, "group_mlp_max")
         if PLAN_LOG is not None:                                            # bench.py: rows evaluated per scale
             for i in live:

@@ -8,7 +8,6 @@ messages (lib/utils/tf_ops/grouping/tf_grouping.cpp:275-288,368-384,453-459).
 Rows of empty balls are zero-filled (the reference leaves them unwritten).
 """
 import ctypes
-import os
 
 import torch
 
@@ -24,7 +23,7 @@ def _check_xyz(op, xyz1, xyz2):
 
 # frames with at least this many points go through the grid ball query (csrc/ballquery_grid.hip), like the fused
 # per-layer call of layers_util.py; identical outputs, ~10x fewer distance evaluations on large frames
-GRID_BALL_QUERY_MIN_N = int(os.environ.get("SA_GRID_BALL_QUERY_MIN_N", "512"))
+GRID_BALL_QUERY_MIN_N = 512
 
 
 def _ball_query_one_band(op, min_radius, max_radius, nsample, dilated, xyz1, xyz2):

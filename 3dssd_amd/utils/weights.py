@@ -46,19 +46,40 @@ def bf16_to_f32(h):
 #             GPU for the bench seed): layer3 / layer4 scales (every contraction >= 128 wide) 4.1e-4 .. 7.1e-4, layer2
 #             (67/64/96-wide) up to 9.1e-4, layer1 (4/16/32-wide) up to 8.6e-4 against the 1e-3 bar -- hence the rule
 #             below: the wide scales, which hold 85 % of the MLP arithmetic, take the one-pass form, the narrow ones keep
-#             the three-pass form.  SA_MLP_PRECISION = auto (default) | bf16x3 | fp16 overrides the rule for A/B runs.
+#             the three-pass form.  MLP_PRECISION (module attribute, or VariableStore(..., precision=)) = "auto" |
+#             "bf16x3" | "fp16" overrides the rule; nothing is read from the environment.
+# fp16 range guards: a scale takes the fp16 form only when every folded weight fits (|w| < FP16_MAX_ABS) and no output
+# channel's weights sit in the fp16 subnormal range as a whole (column maximum >= FP16_MIN_COL_MAX = 2^-10, so that
+# every weight within a factor 16 of the column's largest keeps its 11 significant bits; BN folding with a tiny
+# gamma / sqrt(var) can scale a whole column down -- single tiny entries of a healthy column only add an absolute
+# error far below the column's scale).  Activations are converted with saturation by the kernels and a saturated
+# activation raises the overflow flag of the call (csrc/mlp_act.h; VariableStore.overflow, checked by
+# SABackbone.raise_if_overflow and by SAPipeline tickets).
 FP16_MIN_K = 128
 FP16_MAX_ABS = 6.0e4
+FP16_MIN_COL_MAX = 2.0 ** -10
+MLP_PRECISION = "auto"
 
 
-def scale_precision(ws):
+def fp16_weights_fit(w):
+    """True when the folded matrix [K, N] survives fp16: no overflow, no output column living in the subnormals."""
+    a = np.abs(np.asarray(w, np.float64))
+    if a.size == 0:
+        return True
+    if float(a.max()) >= FP16_MAX_ABS:
+        return False
+    colmax = a.max(axis=0)
+    live = colmax > 0
+    return bool((colmax[live] >= FP16_MIN_COL_MAX).all())
+
+
+def scale_precision(ws, mode=None):
     """Precision of one scale from its folded weight matrices [K, N] (rule above); fp16 is refused when a weight
-    would overflow it."""
-    import os
-    mode = os.environ.get("SA_MLP_PRECISION", "auto")
+    would overflow or underflow it."""
+    mode = mode or MLP_PRECISION
     if mode == "bf16x3":
         return "bf16x3"
-    fits = all(float(np.abs(w).max()) < FP16_MAX_ABS for w in ws)
+    fits = all(fp16_weights_fit(w) for w in ws)
     if mode == "fp16":
         return "fp16" if fits else "bf16x3"
     return "fp16" if fits and all(w.shape[0] >= FP16_MIN_K for w in ws) else "bf16x3"
@@ -129,13 +150,26 @@ def scale_flags(layers):
 class VariableStore:
     """name -> numpy parameter dict plus a cache of folded + packed layers on `device`."""
 
-    def __init__(self, params, device):
+    def __init__(self, params, device, precision=None):
         self.params = params
         self.device = torch.device(device)
+        self.precision = precision           # None: MLP_PRECISION rule; "bf16x3" / "fp16": forced for every scale
         self._cache = {}
+        # sticky fp16 range flag of every grouped-MLP call made with these variables (csrc/mlp_act.h): the kernels OR 1
+        # into it when an input feature or hidden activation left the fp16 range; read by raise_if_overflow()
+        self.overflow = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    def raise_if_overflow(self, what="grouped MLP"):
+        """Synchronising check of the sticky flag (one 4-byte read): a result computed after an fp16 overflow is
+        unspecified, so this raises instead of letting it through, and clears the flag."""
+        if int(self.overflow.item()) != 0:
+            self.overflow.zero_()
+            raise FloatingPointError(
+                "%s: an activation left the fp16 range (|x| > 65504) in a scale evaluated in fp16 -- results are invalid. "
+                "Use VariableStore(..., precision='bf16x3') (or weights.MLP_PRECISION = 'bf16x3') for these weights." % what)
 
     @classmethod
-    def from_checkpoint(cls, path, device, verify=True):
+    def from_checkpoint(cls, path, device, verify=True, precision=None):
         """Variables of a TensorFlow checkpoint written by the reference's trainer (`tf.train.Saver`,
         lib/core/trainer.py:157-174): `path` is a checkpoint prefix (`.../model-80000`) or a directory holding a
         `checkpoint` state file.  Read without TensorFlow (tf_checkpoint.py); optimizer slots are dropped."""
@@ -147,7 +181,7 @@ class VariableStore:
                 raise FileNotFoundError("no `checkpoint` state file in %s" % path)
         else:
             prefix = path
-        return cls(tf_checkpoint.load_checkpoint(prefix, verify=verify), device)
+        return cls(tf_checkpoint.load_checkpoint(prefix, verify=verify), device, precision)
 
     def layer(self, scope, bn=True):
         key = (scope, bool(bn))
@@ -158,6 +192,7 @@ class VariableStore:
 
     def scale(self, scopes, bn=True, precision=None):
         """The conv layers of one MLP scale, packed contiguously (pack_scale) at the scale's operand precision."""
+        precision = precision or self.precision
         key = (tuple(scopes), bool(bn), precision)
         if key not in self._cache:
             folded = [fold_conv_bn(self.params, sc, bn) for sc in scopes]

@@ -3,16 +3,22 @@
 
     python bench.py --gpus N --steps K --warmup W            (N > 1 without torchrun: spawns the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --data default|dup10|dense               (sensitivity of the data-dependent kernels)
     python bench.py --workload configs2|configs4             (the other single-GPU configurations of BASELINE.json)
 
-A "step" is one batch of 8 frames per GPU through the backbone, device-resident in and out.  Steps are
-issued round-robin on --streams HIP streams (frames in flight: FPS is a serial chain that keeps only one
-CU per frame busy, so throughput comes from overlapping the batches' chains); the timed region is
-bracketed by barrier + synchronize on both sides and all K steps complete inside it.  Rank 0 prints ONE
-JSON line; `roofline` describes the kernel with the largest share of GPU time, `stages` every kernel,
-`cpu_baseline` the CPU oracle timed on this host on a bounded sample of the same workload.
+A "step" is one batch of 8 DIFFERENT frames per GPU through the backbone, device-resident in and out: step i takes
+frames 8i .. 8i+7 (mod --pool, default 160 distinct frames per GPU) from a resident pool.  The executor is the
+package's own (3dssd_amd/pipeline.py, SAPipeline): --streams slots, each a HIP stream with a captured hipGraph and its
+own static input / intermediate / output buffers; a step = one block copy of the batch into the slot's input buffer +
+one graph replay, both inside the timed region.  (The layer-1 D-FPS is a serial chain that keeps one CU per frame
+busy: throughput comes from batches in flight.)  The timed region is bracketed by barrier + synchronize on both sides
+and all K steps complete inside it.  After it, --verify batches go through the same pipeline again and every output is
+compared bit for bit with the eager single-stream result of the same batch.  Rank 0 prints ONE JSON line: `roofline`
+describes the kernel with the largest share of GPU time, `stages` every C-ABI call, `cpu_baseline` the CPU oracle timed
+on this host on a bounded sample of the same workload.
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
@@ -24,21 +30,36 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-# The steps are issued on many HIP streams; the ROCm default of 4 hardware queues would serialise them
-# (measured: 16 queues + 16 streams = 1.6x the throughput of the default).  Must be set before HIP starts.
+# 16 hardware queues for the 16 slots (3dssd_amd/pipeline.py sets the same default); must happen before HIP starts.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E, MI355X_MICROARCH.md
-MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 / fp16 MFMA
 VALU_F32_PEAK_TF = 157.3
-TRAFFIC_PROFILE = os.path.join("profiles", "r02_traffic.json")   # committed rocprofv3 PMC pass (tools/gpu_prof.sh)
+MAX_CLOCK_MHZ = 2400.0      # MI355X_MICROARCH.md "Max clock"; cycles_per_pick is quoted at this clock (DVFS runs lower)
+FPS_FLOP_PER_PAIR = 11      # 3 sub + 3 mul/fma + min + compare/select chain, SURVEY.md 8d (3c + 2 with c = 3)
+TRAFFIC_PROFILES = [os.path.join("profiles", "r03_traffic.json"), os.path.join("profiles", "r02_traffic.json")]
 
 
 def pkg(name):
     return importlib.import_module("3dssd_amd." + name)
+
+
+# ------------------------------------------------------------------------------------------------ environment
+def env_knobs():
+    """Every environment variable that can change what is measured.  The package itself reads none (kernel-selection
+    knobs exist only in the `make TUNE=1` build, SA3D_LIB selects such a build); they are recorded in the line, and a
+    run with any SA_* / SA3D_* variable set is refused unless --allow-knobs."""
+    keys = sorted(k for k in os.environ if k.startswith(("SA_", "SA3D_")))
+    rec = {k: os.environ[k] for k in keys}
+    for k in ("GPU_MAX_HW_QUEUES", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "HSA_ENABLE_IPC_MODE_LEGACY",
+              "HIP_LAUNCH_BLOCKING", "AMD_SERIALIZE_KERNEL"):
+        if k in os.environ:
+            rec[k] = os.environ[k]
+    return rec, keys
 
 
 # ------------------------------------------------------------------------------------------------
@@ -123,6 +144,10 @@ def _algorithmic(name, a):
     return 0, 0, name
 
 
+MLP_CALLS = ("sa_group_mlp_max", "sa_group_mlp_max_layer")
+MFMA_CALLS = MLP_CALLS + ("sa_dense", "sa_vote_tail")
+
+
 def profile_stages(fn, iters):
     """Average duration of every C-ABI call of one step (`fn()`), measured live with events on the launch stream.
     Eager launches on ONE stream: these are kernel durations, not the overlapped multi-stream step time."""
@@ -163,92 +188,139 @@ def profile_stages(fn, iters):
 
 
 def _profile_json():
-    try:
-        return json.load(open(os.path.join(ROOT, TRAFFIC_PROFILE)))
-    except Exception:
-        return None
+    for rel in TRAFFIC_PROFILES:
+        try:
+            return json.load(open(os.path.join(ROOT, rel))), rel
+        except Exception:
+            continue
+    return None, None
+
+
+def _fps_kernel_names(stage):
+    """rocprofv3 names of the kernel a sampler call dispatches to (csrc/fps.hip sa_fps_ex2 / fps_coop.hip), newest
+    spelling first."""
+    label = stage["label"]
+    n = int(label.split("n=")[1].split("->")[0])
+    ppt = 1
+    while ppt * 1024 < n:
+        ppt *= 2
+    if stage["kernel"] in ("sa_fps_with_distance_ex", "sa_fps_with_distance_ex2"):
+        return ["fpsdist_reg_kernel<%d>" % ppt]
+    if " c=3" in label and 8192 <= n <= 16384:
+        return ["fps3_wave_bucket_kernel<false>", "fps3_wave_bucket_kernel"]
+    if " c=3" in label and n <= 16384:
+        return ["fps3_reg_kernel<%d>" % ppt]
+    c = int(label.split("c=")[1])
+    return ["fps_coop_kernel<%d, %d>" % (c, 4 if c == 3 else 1)]
 
 
 def _pmc_traffic(stage):
     """HBM bytes per launch of the stage's kernel from the COMMITTED rocprofv3 PMC pass (profiles/, made by
     tools/gpu_prof.sh + tools/summarize_prof.py: FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md +
-    WRITE_SIZE).  A snapshot keyed by kernel name, NOT collected in this run; None when the file is absent."""
-    d = _profile_json()
-    if d is None:
-        return None
-    label = stage["label"]
-    name = None
-    if stage["kernel"] in ("sa_fps_ex", "sa_fps_ex2") and " c=3" in label:
-        n = int(label.split("n=")[1].split("->")[0])
-        ppt = 1
-        while ppt * 1024 < n:
-            ppt *= 2
-        name = "fps3_reg_kernel<%d>" % ppt
-        if 8192 <= n <= 16384 and int(os.environ.get("SA_FPS_BUCKET_MIN_N", "8192")) > 0:
-            name = "fps3_wave_bucket_kernel"          # the culled kernel takes the layer-1 shape (fps.hip dispatch)
-    elif stage["kernel"] in ("sa_fps_with_distance_ex", "sa_fps_with_distance_ex2"):
-        n = int(label.split("n=")[1].split("->")[0])
-        ppt = 1
-        while ppt * 1024 < n:
-            ppt *= 2
-        name = "fpsdist_reg_kernel<%d>" % ppt
-    try:
-        return int(d[name]["hbm_bytes_per_launch"]) if name in d else None
-    except Exception:
-        return None
+    WRITE_SIZE).  A snapshot keyed by kernel name, NOT collected in this run; (None, None) when absent."""
+    d, rel = _profile_json()
+    if d is None or not stage["kernel"].startswith("sa_f"):
+        return None, None
+    for name in _fps_kernel_names(stage):
+        if name in d and "hbm_bytes_per_launch" in d[name]:
+            return int(d[name]["hbm_bytes_per_launch"]), rel
+    return None, None
 
 
 def _pmc_mlp_util():
     """MFMA utilisation of the grouped-MLP kernels from the committed PMC pass: sum of SQ_VALU_MFMA_BUSY_CYCLES over
     sum of (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), per launch, over the MLP kernels of one step."""
-    d = _profile_json()
+    d, rel = _profile_json()
     if d is None:
         return None
     busy = cap = 0.0
     per_kernel = {}
     for k, e in d.items():
-        if ("mlp_r" in k or "mlp_multi" in k or "group_mlp" in k) and "mfma_util" in e:
+        if ("mlp_r" in k or "mlp_multi" in k or "group_mlp" in k or "mlp_gemm" in k) and "mfma_util" in e:
             busy += e["mfma_busy_cycles_per_launch"]
             cap += e["gui_active_cycles_per_launch"] / 8.0 * 1024.0
             per_kernel[k] = e["mfma_util"]
     if cap <= 0:
         return None
     return dict(mfma_util=round(busy / cap, 4), per_kernel=per_kernel,
-                source="committed profile %s (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE), not this run" % TRAFFIC_PROFILE)
+                source="committed profile %s (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE), not this run" % rel)
 
 
-def roofline_of(stage, frames):
+def fps_bucket_evaluated(pts_xyz, m):
+    """Pair evaluations the culled layer-1 sampler really performs on these frames (sa_fps_bucket_stats: bucket
+    re-evaluations x 256 point slots), next to the reference's (m - 1) * n."""
+    lib = pkg("utils._native").lib()
+    b, n, _ = pts_xyz.shape
+    if not (8192 <= n <= 16384):
+        return None
+    out = torch.empty((b, m), dtype=torch.int32, device=pts_xyz.device)
+    stats = torch.zeros((b, 2), dtype=torch.int64, device=pts_xyz.device)
+    st = lib.sa_fps_bucket_stats(b, n, m, pts_xyz.data_ptr(), out.data_ptr(), stats.data_ptr(),
+                                 torch.cuda.current_stream().cuda_stream)
+    if st != 0:
+        return None
+    torch.cuda.synchronize()
+    return int(stats[:, 0].sum().item()) * 256
+
+
+def roofline_of(stage, frames, clock_mhz, evaluated_pairs=None):
     k = stage["kernel"]
-    if k in ("sa_group_mlp_max", "sa_group_mlp_max_layer", "sa_dense", "sa_vote_tail", "sa_calc_square_dist_split", "sa_calc_square_dist_split_ws", "sa_calc_square_dist_self_ws"):
+    if k in MFMA_CALLS or k.startswith("sa_calc_square_dist"):
         peak = MFMA_BF16_PEAK_TF if not k.startswith("sa_calc_square_dist") else VALU_F32_PEAK_TF
         a = stage.get("tflops", 0.0)
         return dict(kernel=stage["label"], bound="mfma", achieved=a, peak=peak, unit="TFLOP/s",
                     frac=round(a / peak, 5), traffic=None)
     a = stage.get("gbs", 0.0)
-    tr = _pmc_traffic(stage)
-    r = dict(kernel=stage["label"], bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s",
-             frac=round(a / HBM_PEAK_GBS, 6), traffic=tr,
-             traffic_source=("committed profile %s, not collected in this run" % TRAFFIC_PROFILE) if tr is not None else None,
-             algorithmic_bytes=int(stage["mbytes"] * 1e6), avg_launch_ms=stage.get("avg_ms"))
-    if k.startswith("sa_fps") or k == "sa_farthest_point_sample":
-        # FPS is a serial dependent chain on ONE CU per frame: neither HBM- nor MFMA-bound (SURVEY.md 8d); what
-        # bounds it is the latency of one pick.
-        n = int(stage["label"].split("n=")[1].split("->")[0])
-        m = int(stage["label"].split("->")[1].split()[0])
-        r["note"] = ("latency-bound serial chain (one workgroup = one CU per frame, m-1 dependent picks): the HBM "
-                     "fraction is tiny by nature; us_per_pick is the figure of merit")
-        r["us_per_pick"] = round(stage.get("avg_ms", 0.0) * 1e3 / max(m - 1, 1), 4)
-        r["cus_used"] = frames
-        r["reference_pair_evaluations"] = frames * (m - 1) * n
+    tr, rel = _pmc_traffic(stage)
+    if not (k.startswith("sa_fps") or k == "sa_farthest_point_sample"):
+        return dict(kernel=stage["label"], bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(a / HBM_PEAK_GBS, 6), traffic=tr,
+                    traffic_source=("committed profile %s, not collected in this run" % rel) if tr is not None else None,
+                    algorithmic_bytes=int(stage["mbytes"] * 1e6), avg_launch_ms=stage.get("avg_ms"))
+    # FPS: a serial dependent chain -- neither HBM- nor MFMA-bound (SURVEY.md 8d).  Reported as the reference's pair
+    # evaluations x 11 flop / time against the fp32 VALU peak ("VALU-equivalent"), with what is really evaluated, the
+    # latency per pick and the (tiny, by nature) HBM figures beside it.
+    label = stage["label"]
+    n = int(label.split("n=")[1].split("->")[0])
+    m = int(label.split("->")[1].split()[0])
+    c = int(label.split("c=")[1]) if "c=" in label else 3
+    ms = stage.get("avg_ms", 0.0)
+    pairs = frames * (m - 1) * n
+    flop_pair = 3 * c + 2
+    tf = pairs * flop_pair / ms / 1e9 if ms > 0 else 0.0
+    names = _fps_kernel_names(stage)
+    coop = names[0].startswith("fps_coop")
+    if coop:
+        g = 1
+        while 1024 * (4 if c == 3 else 1) * g < n:
+            g *= 2
+        wgs, note = frames * g, ("latency-bound serial chain: %d cooperating workgroups of 1024 threads per frame "
+                                 "(csrc/fps_coop.hip), one cross-workgroup arg-max exchange per pick" % g)
+    else:
+        wgs, note = frames, ("latency-bound serial chain: one workgroup (= one CU) per frame, m-1 dependent picks; "
+                             "bucket culling evaluates only the pairs near each pick")
+    r = dict(kernel=label, device_kernel=names[0], bound="latency", achieved=round(tf, 4), peak=VALU_F32_PEAK_TF,
+             unit="TFLOP/s", frac=round(tf / VALU_F32_PEAK_TF, 5),
+             basis="reference pair evaluations x %d flop / kernel time, against the fp32 VALU peak" % flop_pair,
+             traffic=tr, traffic_source=("committed profile %s, not collected in this run" % rel) if tr is not None else None,
+             algorithmic_bytes=int(stage["mbytes"] * 1e6), hbm_gbs=a, hbm_frac=round(a / HBM_PEAK_GBS, 7),
+             avg_launch_ms=ms, us_per_pick=round(ms * 1e3 / max(m - 1, 1), 4),
+             cycles_per_pick=round(ms * 1e3 / max(m - 1, 1) * clock_mhz, 1), clock_mhz=clock_mhz,
+             workgroups=wgs, cus_used=min(wgs, 256), reference_pair_evaluations=pairs, note=note)
+    if evaluated_pairs is not None:
+        r["evaluated_pairs"] = int(evaluated_pairs)
+        r["evaluated_frac"] = round(evaluated_pairs / max(pairs, 1), 5)
+        r["evaluated_tflops"] = round(evaluated_pairs * flop_pair / ms / 1e9, 4) if ms > 0 else 0.0
+        r["evaluated_frac_of_peak_on_cus_used"] = round(r["evaluated_tflops"] / (VALU_F32_PEAK_TF * min(wgs, 256) / 256.0), 5)
     return r
 
 
-def cpu_baseline(arch, params, batch, points, budget_s=20.0):
+def cpu_baseline(arch, params, batch, points, variant, budget_s=20.0):
     """The CPU oracle (a scalar C/OpenMP restatement of the reference kernels; the reference has no CPU
     path of its own) on `batch` frames of the same workload, repeated until ~budget_s."""
     from oracle import sa_oracle as O
     cfgs, syn = pkg("configs"), pkg("synthetic")
-    pts = syn.kitti_like_batch(batch, n=points)
+    pts = np.stack([syn.frame_of(variant, f, points) for f in range(batch)])
     O.lib()
     t0 = time.time()
     reps = 0
@@ -258,9 +330,13 @@ def cpu_baseline(arch, params, batch, points, budget_s=20.0):
         dt = time.time() - t0
         if dt > budget_s * 0.6 or reps >= 4:
             break
-    return dict(value=round(reps * batch / dt, 4), unit="frames/s", cores=os.cpu_count() or 1, kind="port",
-                sample="%d x %d frames of the same %d-pt workload through oracle.sa_backbone "
-                       "(OpenMP over frames/queries), %.1f s" % (reps, batch, points, dt))
+    cores = os.cpu_count() or 1
+    return dict(value=round(reps * batch / dt, 4), unit="frames/s", cores=cores, kind="port",
+                effective_parallelism="OpenMP over frames in the FPS stages (<= %d of the %d threads busy there: the "
+                                      "4 095-pick chain of a frame is serial on the CPU too), over queries / rows in "
+                                      "the ball-query and MLP stages" % (batch, cores),
+                sample="%d x %d frames of the same %d-pt workload (--data %s) through oracle.sa_backbone, %.1f s"
+                       % (reps, batch, points, variant, dt))
 
 
 # ------------------------------------------------------------------------------------------------ launch
@@ -277,9 +353,10 @@ def self_spawn(args):
     (the N in-graph towers of lib/core/trainer.py:120-155 become N processes)."""
     if not args.launch_check:
         have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-        if have < args.gpus:
+        if have < args.gpus and not args.allow_shared_device:
             sys.exit("bench.py --gpus %d: only %d GPU(s) visible on this node -- refusing to run fewer ranks than "
-                     "requested" % (args.gpus, have))
+                     "requested (--allow-shared-device runs the ranks on the GPUs there are, for a functional check of "
+                     "the multi-rank path; not a scaling point)" % (args.gpus, have))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
@@ -344,99 +421,115 @@ def overlap_probe(run, k):
                     "spans inside the steady window / its length"}
 
 
-def mlp_row_stats(net, pts):
+def mlp_row_stats(net, batches):
     """Rows of the grouped tensor per step: nominal (m x nsample, what the reference's conv2d evaluates), distinct
-    (sum of clamp(cnt, 1, ns)) and evaluated (8-row granules of the plan), from the plan headers of one eager step."""
+    (sum of clamp(cnt, 1, ns)) and evaluated (8-row granules of the plan), from the plan headers of eager steps over
+    `batches` (mean per step)."""
     lu = pkg("utils.layers_util")
-    lu.PLAN_LOG = []
-    net(pts)
-    torch.cuda.synchronize()
-    log, lu.PLAN_LOG = lu.PLAN_LOG, None
     nominal = distinct = evaluated = 0
     fl_nom = fl_eval = 0.0
-    for (b, m, ns, macs, plan) in log:
-        h = plan[:4].cpu().tolist()
-        nominal += b * m * ns
-        distinct += h[2]
-        evaluated += h[0] * 8
-        fl_nom += 2.0 * b * m * ns * macs
-        fl_eval += 2.0 * h[0] * 8 * macs
-    return dict(nominal=nominal, distinct=distinct, evaluated=evaluated,
-                evaluated_frac=round(evaluated / max(nominal, 1), 4),
-                gflop_nominal=round(fl_nom / 1e9, 3), gflop_evaluated=round(fl_eval / 1e9, 3))
+    for pts in batches:
+        lu.PLAN_LOG = []
+        net(pts)
+        torch.cuda.synchronize()
+        log, lu.PLAN_LOG = lu.PLAN_LOG, None
+        for (b, m, ns, macs, plan) in log:
+            h = plan[:4].cpu().tolist()
+            nominal += b * m * ns
+            distinct += h[2]
+            evaluated += h[0] * 8
+            fl_nom += 2.0 * b * m * ns * macs
+            fl_eval += 2.0 * h[0] * 8 * macs
+    k = max(len(batches), 1)
+    return dict(nominal=nominal // k, distinct=distinct // k, evaluated=evaluated // k,
+                evaluated_frac=round(evaluated / max(nominal, 1), 4), batches_sampled=len(batches),
+                gflop_nominal=round(fl_nom / 1e9 / k, 3), gflop_evaluated=round(fl_eval / 1e9 / k, 3))
+
+
+def _sha1(t):
+    return hashlib.sha1(t.detach().cpu().numpy().tobytes()).hexdigest()
+
+
+def verify_pipeline(pipe, batches, nverify):
+    """`nverify` DISTINCT batches through the pipeline with all slots in flight, each output compared bit for bit with
+    the eager single-stream result of the same batch (a replay that read another slot's scratch or input would differ)."""
+    nverify = min(nverify, len(batches))
+    if nverify <= 0:
+        return None
+    eager = []
+    for i in range(nverify):
+        xl, fl, _ = pipe.forward_eager(batches[i])
+        eager.append((xl[-1].clone(), fl[-1].clone()))
+    torch.cuda.synchronize()
+    equal, first = True, None
+    for r0 in range(0, nverify, pipe.nslots):
+        tickets = [(i, pipe.submit(batches[i], sync_source=False)) for i in range(r0, min(r0 + pipe.nslots, nverify))]
+        for i, t in tickets:
+            x, f = t.result()
+            ok = torch.equal(x, eager[i][0]) and torch.equal(f, eager[i][1])
+            equal = equal and ok
+            if first is None:
+                first = (_sha1(f), _sha1(eager[i][1]))
+    return {"batches": nverify, "slots_in_flight": min(pipe.nslots, nverify), "all_equal_eager": bool(equal),
+            "output_sha1_replay": first[0], "output_sha1_eager": first[1],
+            "note": "sha1 of the [B,256,512] feature output of pool batch 0: through the pipeline (graph replay, all "
+                    "slots busy with other batches) and eager on one stream"}
 
 
 def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
     cfgs, syn = pkg("configs"), pkg("synthetic")
     arch = cfgs.KITTI_3DSSD_ARCH
     params = syn.random_backbone_params(arch)
-    net = pkg("backbone").SABackbone(arch, params, dev, cfgs.KITTI_MAX_TRANSLATE_RANGE)
-    # this rank's frames: global frame f -> rank f mod world (weak scaling: `batch` frames per GPU)
-    frames = sh.frames_of_rank(0, args.batch * world, rank, world)
-    pts = torch.from_numpy(np.stack([syn.kitti_like_frame(f, points) for f in frames])).to(dev)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
-    graphs = None
     use_graphs = bool(args.graphs) and graphs_ok
-    if use_graphs:
-        # one captured hipGraph per stream (launch-bound host loop -> one replay per step); every graph
-        # owns its intermediate and output buffers, the input frames are static
-        for _ in range(2):
-            net(pts)
-        torch.cuda.synchronize()
-        graphs = []
-        for st in streams:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=st):
-                xl, fl, _ = net(pts)
-            graphs.append((g, xl[-1], fl[-1]))
-        torch.cuda.synchronize()
-        # setup, like the capture itself: every graph is replayed once (W warm-up steps reach only the first W graphs)
-        for st, (g, _x, _f) in zip(streams, graphs):
-            with torch.cuda.stream(st):
-                g.replay()
-        torch.cuda.synchronize()
+    pipe = pkg("pipeline").SAPipeline(arch, params, dev, batch=args.batch, points=points, channels=4,
+                                      streams=max(1, args.streams), graphs=use_graphs,
+                                      max_translate_range=cfgs.KITTI_MAX_TRANSLATE_RANGE)
+    net = pipe.net
+    # this rank's frame pool: global frame f -> rank f mod world (weak scaling: `batch` frames per GPU per step);
+    # `pool` distinct frames per GPU, resident; step i takes pool batch i mod nb
+    nb = max(1, args.pool // args.batch)
+    frames = sh.frames_of_rank(0, nb * args.batch * world, rank, world)
+    batches = [torch.from_numpy(np.stack([syn.frame_of(args.data, f, points) for f in frames[i * args.batch:(i + 1) * args.batch]])).to(dev)
+               for i in range(nb)]
+    torch.cuda.synchronize()
+    cursor = [0]
 
     def run(k, marks=None):
-        outs = []
-        for i in range(k):
-            j = i % len(streams)
-            with torch.cuda.stream(streams[j]):
-                if marks is not None:
-                    s_ev = torch.cuda.Event(enable_timing=True)
-                    s_ev.record()
-                if graphs is not None:
-                    graphs[j][0].replay()
-                    outs.append((graphs[j][1], graphs[j][2]))
-                else:
-                    xl, fl, _ = net(pts)
-                    outs.append((xl[-1], fl[-1]))
-                if marks is not None:
-                    e_ev = torch.cuda.Event(enable_timing=True)
-                    e_ev.record()
-                    marks.append((s_ev, e_ev))
-        return outs
+        tickets = []
+        for _ in range(k):
+            pts = batches[cursor[0] % nb]
+            cursor[0] += 1
+            if marks is not None:
+                st = pipe.slots[pipe._next].stream
+                s_ev = torch.cuda.Event(enable_timing=True)
+                s_ev.record(st)
+            tickets.append(pipe.submit(pts, sync_source=False))
+            if marks is not None:
+                e_ev = torch.cuda.Event(enable_timing=True)
+                e_ev.record(st)
+                marks.append((s_ev, e_ev))
+        return tickets
 
-    t_max, frames_total, host_issue_ms, outs = timed_region(sh, dev, run, args.steps, args.warmup, len(frames))
-    assert outs[-1][1].shape == (len(frames), 256, 512)
+    t_max, frames_total, host_issue_ms, tickets = timed_region(sh, dev, run, args.steps, args.warmup, args.batch)
+    x_last, f_last = tickets[-1].result()
+    assert f_last.shape == (args.batch, 256, 512) and x_last.shape == (args.batch, 256, 3)
     overlap = overlap_probe(run, min(args.steps, 96)) if rank == 0 else None
-    # latency of one batch alone on the device (no overlap), for the record: one graph replayed by itself (eager
-    # launches are partly host-bound -- ~0.6 ms of Python per step -- and measured 5.1-9.5 ms depending on the host)
+    # latency of one batch alone on the device (no overlap), for the record
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    for _ in range(3):
-        if graphs is not None:
-            with torch.cuda.stream(streams[0]):
-                graphs[0][0].replay()
-            streams[0].synchronize()
-        else:
-            net(pts)
-    torch.cuda.synchronize()
+    for i in range(3):
+        pipe.run_alone(batches[i % nb])
     latency_ms = (time.perf_counter() - t1) / 3 * 1e3
+    verify = verify_pipeline(pipe, batches, args.verify)
+    if verify is not None and not verify["all_equal_eager"]:
+        sys.exit("bench.py: a pipeline output differs from the eager result of the same batch -- refusing to report")
     if rank != 0:
         return None
-    stages = profile_stages(lambda: net(pts), args.profile_iters)
-    rows = mlp_row_stats(net, pts)
+    clock_mhz = MAX_CLOCK_MHZ
+    stages = profile_stages(lambda: net(batches[0]), args.profile_iters)
+    rows = mlp_row_stats(net, batches[:min(nb, 4)])
     ms_step = t_max / args.steps * 1e3
+    window_ms = t_max * 1e3
     line = {
         "metric": "point-cloud frames/sec through full SA backbone, KITTI 16384-pt" if points == 16384 else
                   "point-cloud frames/sec through full SA backbone, %d-pt frames" % points,
@@ -446,44 +539,65 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
         "dtype": "grouped MLP: fp16 x fp16 -> fp32 accumulate (one MFMA pass) on the scales whose contractions are all >= 128 "
                  "wide (layer3, layer4), split bf16 hi/lo (three passes) on the narrow scales and the aggregation layers; "
                  "fp32 for FPS / ball query / distance matrix",
-        "data": "synthetic KITTI-shape frames (seeded), random-init weights",
+        "data": "synthetic KITTI-shape frames (seeded, --data %s), %d DISTINCT frames per GPU cycled through the steps, "
+                "random-init weights" % (args.data, nb * args.batch),
         "config": {"workload": "%s: full 3DSSD SA backbone (3dssd.yaml rows 1-6), %d-pt frames, batch=%d per GPU"
                                % (tag, points, args.batch),
-                   "frames_per_step_per_gpu": len(frames), "streams": len(streams),
+                   "frames_per_step_per_gpu": args.batch, "streams": pipe.nslots, "data": args.data,
+                   "pool_frames_per_gpu": nb * args.batch,
+                   "executor": "3dssd_amd.pipeline.SAPipeline: per-slot static input buffer, one block copy + one "
+                               "hipGraph replay per step" if use_graphs else
+                               "3dssd_amd.pipeline.SAPipeline, eager launches on the slots' streams",
                    "sharding": "frame f -> rank f mod N, no data-path collective"},
+        "timed_window_ms": round(window_ms, 3),
         "single_stream_batch_latency_ms": round(latency_ms, 3),
+        "ramp_dominated": bool(window_ms < 20.0 * latency_ms),
+        "ramp_note": "a run shorter than ~20 single-batch latencies mostly measures filling and draining the %d slots "
+                     "(every chain starts with the ~3 ms layer-1 D-FPS); the steady-state rate needs --steps >= 100" % pipe.nslots,
         "host_issue_ms_per_step": round(host_issue_ms, 3),
         "hip_graphs": use_graphs,
+        "env_knobs": env_knobs()[0],
+        "verify": verify,
         "mlp_rows_per_step": rows,
         "overlap": overlap,
     }
+    if args.allow_shared_device and world > torch.cuda.device_count():
+        line["shared_device"] = ("%d ranks on %d GPU(s): a functional check of the multi-rank path, NOT a scaling point"
+                                 % (world, torch.cuda.device_count()))
     if stages:
         dom = max(stages, key=lambda s: s["avg_ms"] * s["calls_per_step"])
-        mlp = [s for s in stages if s["kernel"] in ("sa_group_mlp_max", "sa_group_mlp_max_layer")]
-        mlp_ms = sum(s["avg_ms"] * s["calls_per_step"] for s in stages
-                     if s["kernel"] in ("sa_group_mlp_max", "sa_group_mlp_max_layer", "sa_group_mlp_plan"))
+        mlp = [s for s in stages if s["kernel"] in MLP_CALLS]
+        mlp_only_ms = sum(s["avg_ms"] * s["calls_per_step"] for s in mlp)
+        plan_ms = sum(s["avg_ms"] * s["calls_per_step"] for s in stages if s["kernel"] == "sa_group_mlp_plan")
+        mlp_ms = mlp_only_ms + plan_ms
         mlp_fl = sum(s["gflop"] * s["calls_per_step"] for s in mlp)
         bq = [s for s in stages if s["kernel"] in ("sa_query_ball_point_multi", "sa_query_ball_point_grid")]
         bq_ms = sum(s["avg_ms"] * s["calls_per_step"] for s in bq)
         bq_mb = sum(s["mbytes"] * s["calls_per_step"] for s in bq)
-        gflop_step = sum(s["gflop"] * s["calls_per_step"] for s in stages
-                         if s["kernel"] in ("sa_group_mlp_max", "sa_group_mlp_max_layer", "sa_dense", "sa_vote_tail"))
+        gflop_step = sum(s["gflop"] * s["calls_per_step"] for s in stages if s["kernel"] in MFMA_CALLS)
         mb_step = sum(s["mbytes"] * s["calls_per_step"] for s in stages)
-        line["roofline"] = roofline_of(dom, len(frames))
+        evaluated = None
+        if dom["kernel"] in ("sa_fps_ex", "sa_fps_ex2") and " c=3" in dom["label"]:
+            m1 = int(dom["label"].split("->")[1].split()[0])
+            evaluated = fps_bucket_evaluated(batches[0][:, :, :3].contiguous(), m1)
+        line["roofline"] = roofline_of(dom, args.batch, clock_mhz, evaluated)
         line["whole_step"] = {
             "mlp_gflop_algorithmic": round(gflop_step, 2),
             "mfma_tflops": round(gflop_step / ms_step, 2), "mfma_frac_of_bf16_peak": round(gflop_step / ms_step / MFMA_BF16_PEAK_TF, 5),
             "algorithmic_mbytes": round(mb_step, 2), "hbm_gbs": round(mb_step / ms_step, 2),
             "hbm_frac": round(mb_step / ms_step / HBM_PEAK_GBS, 5),
             "note": "algorithmic work of one step (SURVEY 8d) / ms_per_step of the overlapped multi-stream run"}
+        ev_tf = rows["gflop_evaluated"] / mlp_ms if mlp_ms else 0.0
         line["roofline_grouped_mlp"] = {
-            "bound": "mfma", "achieved": round(mlp_fl / mlp_ms, 3) if mlp_ms else 0.0, "peak": MFMA_BF16_PEAK_TF,
-            "unit": "TFLOP/s", "frac": round(mlp_fl / mlp_ms / MFMA_BF16_PEAK_TF, 5) if mlp_ms else 0.0,
-            "evaluated_tflops": round(rows["gflop_evaluated"] / mlp_ms, 3) if mlp_ms else 0.0,
-            "note": "achieved = the reference's m x nsample rows (SURVEY 8d, 30.9 GFLOP/frame) / single-stream kernel "
-                    "time incl. the row-plan kernels; evaluated_tflops counts only the rows the kernels run (distinct "
-                    "rows of each ball, 8-row granules); issued MFMA flops = evaluated x 3 on the split-bf16 scales, x 1 on "
-                    "the fp16 scales",
+            "bound": "mfma", "achieved": round(ev_tf, 3), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+            "frac": round(ev_tf / MFMA_BF16_PEAK_TF, 5),
+            "nominal_tflops": round(mlp_fl / mlp_ms, 3) if mlp_ms else 0.0,
+            "nominal_frac": round(mlp_fl / mlp_ms / MFMA_BF16_PEAK_TF, 5) if mlp_ms else 0.0,
+            "kernel_ms": round(mlp_only_ms, 5), "plan_ms": round(plan_ms, 5),
+            "note": "achieved / frac = EXECUTED flops (rows the kernels run: the distinct rows of each ball in 8-row "
+                    "granules) / single-stream time of the MLP kernels incl. the row-plan kernels; nominal_* counts the "
+                    "reference's m x nsample rows (SURVEY 8d, 30.9 GFLOP/frame); issued MFMA flops = executed x 3 on the "
+                    "split-bf16 scales, x 1 on the fp16 scales",
             "pmc": _pmc_mlp_util()}
         line["roofline_ball_query"] = {
             "bound": "hbm", "achieved": round(bq_mb / bq_ms, 2) if bq_ms else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -494,7 +608,7 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
                                            "bandwidth-bound"}
         line["stages"] = stages
     if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only (the contract)
-        line["cpu_baseline"] = cpu_baseline(arch, params, min(args.batch, 8), points)
+        line["cpu_baseline"] = cpu_baseline(arch, params, min(args.batch, 8), points, args.data)
     return line
 
 
@@ -505,7 +619,7 @@ def workload_ffps_isolated(args, sh, rank, world, dev):
     batch, n, c, m = 32, 16384, 67, 4096
     rng = np.random.default_rng(20260925)
     frames = sh.frames_of_rank(0, batch * world, rank, world)
-    xyz = np.stack([syn.kitti_like_frame(f, n)[:, :3] for f in frames])
+    xyz = np.stack([syn.frame_of(args.data, f, n)[:, :3] for f in frames])
     feat = rng.normal(0, 0.5, (len(frames), n, c - 3)).astype(np.float32)
     pts = torch.from_numpy(np.concatenate([xyz, feat], 2)).to(dev)
 
@@ -516,16 +630,18 @@ def workload_ffps_isolated(args, sh, rank, world, dev):
     assert outs[-1].shape == (len(frames), m)
     if rank != 0:
         return None
+    clock_mhz = MAX_CLOCK_MHZ
     stages = profile_stages(lambda: S.farthest_point_sample(m, pts), max(1, min(args.profile_iters, 2)))
     line = {"metric": "frames/sec through feature-distance FPS 16384->4096 (3+64 channels), isolated",
             "value": round(frames_total / t_max, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(t_max / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic KITTI-shape xyz + N(0,0.5) features (seeded)",
             "config": {"workload": "configs[2]: F-FPS isolated, [%d,%d,%d] -> %d per frame, batch=%d per GPU" % (batch, n, c, m, batch),
-                       "frames_per_step_per_gpu": len(frames)},
-            "host_issue_ms_per_step": round(host_issue_ms, 3)}
+                       "frames_per_step_per_gpu": len(frames), "data": args.data},
+            "timed_window_ms": round(t_max * 1e3, 3),
+            "host_issue_ms_per_step": round(host_issue_ms, 3), "env_knobs": env_knobs()[0]}
     if stages:
-        line["roofline"] = roofline_of(max(stages, key=lambda s: s["avg_ms"]), len(frames))
+        line["roofline"] = roofline_of(max(stages, key=lambda s: s["avg_ms"]), len(frames), clock_mhz)
         line["stages"] = stages
     if not args.no_cpu_baseline and world == 1:
         from oracle import sa_oracle as O
@@ -548,21 +664,36 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="configs1", choices=["configs1", "configs2", "configs4"],
                     help="BASELINE.json configs[1] (default, the metric's configuration), configs[2], configs[4]")
+    ap.add_argument("--data", default="default", choices=list(pkg("synthetic").DATA_VARIANTS),
+                    help="default: SURVEY 8d generator; dup10: 10 %% duplicated rows (KITTI padding); dense: uniform box, every ball full")
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step")
     ap.add_argument("--points", type=int, default=None)
-    ap.add_argument("--streams", type=int, default=None, help="HIP streams the steps are issued on")
+    ap.add_argument("--pool", type=int, default=None, help="distinct frames per GPU the steps cycle through")
+    ap.add_argument("--streams", type=int, default=None, help="pipeline slots (HIP streams) the steps are issued on")
+    ap.add_argument("--verify", type=int, default=None, help="batches re-run through the pipeline and compared with eager (0: skip)")
     ap.add_argument("--profile-iters", type=int, default=3)
-    ap.add_argument("--graphs", type=int, default=1, help="1 (default): capture one hipGraph per stream and replay it; 0: eager launches")
+    ap.add_argument("--graphs", type=int, default=1, help="1 (default): one captured hipGraph per slot; 0: eager launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--allow-knobs", action="store_true", help="run although SA_* / SA3D_* environment variables are set (recorded in the line)")
+    ap.add_argument("--allow-shared-device", action="store_true",
+                    help="--gpus N with fewer than N GPUs visible: ranks share devices (functional check of the multi-rank path)")
     ap.add_argument("--launch-check", action="store_true", help="exercise only the launch path (works without a GPU)")
     args = ap.parse_args()
     assert args.gpus >= 1
-    defaults = {"configs1": dict(steps=128, warmup=24, batch=8, points=16384, streams=16),
-                "configs2": dict(steps=4, warmup=1, batch=32, points=16384, streams=1),
-                "configs4": dict(steps=16, warmup=4, batch=16, points=65536, streams=4)}[args.workload]
+    defaults = {"configs1": dict(steps=128, warmup=24, batch=8, points=16384, streams=16, pool=160, verify=32),
+                "configs2": dict(steps=4, warmup=1, batch=32, points=16384, streams=1, pool=32, verify=0),
+                "configs4": dict(steps=16, warmup=4, batch=16, points=65536, streams=4, pool=96, verify=8)}[args.workload]
     for k, v in defaults.items():
         if getattr(args, k) is None:
             setattr(args, k, v)
+
+    knobs, sa_keys = env_knobs()
+    if "SA_ABLATE" in os.environ:
+        sys.exit("bench.py: SA_ABLATE is set -- ablation runs skip kernels and are not benchmark results (tools/ablate.sh "
+                 "drives them through tools/, never through this script)")
+    if sa_keys and not args.allow_knobs:
+        sys.exit("bench.py: kernel-selection variables set in the environment (%s): refusing to measure a non-default "
+                 "configuration; pass --allow-knobs to run anyway (they are recorded in the line)" % ", ".join(sa_keys))
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         self_spawn(args)                                # does not return
@@ -570,13 +701,18 @@ def main():
     sh = pkg("sharding")
     if args.launch_check:
         return launch_check(args, sh)
-    rank, local_rank, world = sh.init()
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
+    ndev = torch.cuda.device_count()
+    rank, local_rank, world = sh.env_world()
+    if local_rank >= ndev and not args.allow_shared_device:
+        sys.exit("rank %d has no GPU (%d visible)" % (local_rank, ndev))
+    device_index = local_rank % ndev
+    rank, local_rank, world = sh.init(backend="gloo" if (args.allow_shared_device and world > ndev) else None,
+                                      device_index=device_index)
     assert world == args.gpus, ("bench.py --gpus %d but WORLD_SIZE=%d: launch with `python bench.py --gpus N` or "
                                 "torch.distributed.run --nproc-per-node N" % (args.gpus, world))
-    assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
-    assert local_rank < torch.cuda.device_count(), "rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count())
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     pkg("utils._native").lib()
 
     if args.workload == "configs1":

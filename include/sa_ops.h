@@ -76,6 +76,9 @@ int sa_fps_with_distance_ex(int b, int n, int m, const float *dist, float *temp,
  * for large frames (3dssd_amd/csrc/fps_bucket.hip). */
 int sa_fps_bucket_ex(int b, int n, int m, const float *inp, int *out, int out_stride, int idx_off,
                      sa_stream_t stream);
+/* Diagnostic: sa_fps_bucket_ex's picks plus, per frame, stats[2f] = bucket re-evaluations (256 point slots each) and
+ * stats[2f+1] = m - 1; the reference evaluates (m - 1) * n pairs.  stats: device, 2*b unsigned 64-bit words. */
+int sa_fps_bucket_stats(int b, int n, int m, const float *inp, int *out, unsigned long long *stats, sa_stream_t stream);
 /* The samplers with two fused neighbours of theirs in pointnet_sa_module_msg (layers_util.py:84-119), each one launch
  * less per layer: in_bstride = elements between consecutive frames of inp (0 = dense), so a range slice xyz[:, s:e] of
  * a larger tensor is sampled in place (tf.slice, layers_util.py:85-86); ctr != NULL additionally receives the picked
@@ -146,7 +149,14 @@ int sa_query_ball_point_grid(int b, int n, int m, int nbands, const float *rmin,
  * device scratch of sa_group_mlp_max_ws_bytes(b, m, ns) bytes (the per-call row plan).  flags bit 0: evaluate all
  * nsample rows of every ball instead (A/B measurements); bit 1: the plan in ws was built by sa_group_mlp_plan;
  * bit 2: wpack[] holds single-plane fp16 fragments and the scale runs one fp16 MFMA pass per k-step (fp32
- * accumulate) instead of the three split-bf16 passes -- chosen per scale by the host (utils/weights.py). */
+ * accumulate) instead of the three split-bf16 passes -- chosen per scale by the host (utils/weights.py).
+ * overflow (device int, may be NULL; fp16 form only): OR-ed with 1 when an input feature or a hidden activation left
+ * the fp16 range (|x| > 65504) -- the result of that call is then unspecified; the word is sticky, the caller zeroes
+ * and reads it (3dssd_amd/csrc/mlp_act.h).
+ * Preconditions of the default (distinct-row) mode: idx rows are in the ball query's output format -- entries
+ * cnt .. ns-1 of a row repeat entry 0 (tf_grouping_g.cu:245-248), which sa_query_ball_point* guarantee; a caller that
+ * builds idx / cnt itself passes flags bit 0.  ns <= 512 and b*m < 2^24 (row-plan entry fields): SA_ERR_UNSUPPORTED
+ * beyond that. */
 unsigned long sa_group_mlp_max_ws_bytes(int b, int m, int ns);
 /* The row plans of all scales of a layer in ONE launch: cnt[i] = pts_cnt of scale i, ws[i] = that scale's scratch,
  * out_off[i] / nout[i] = where scale i's channels go in out.  The layer's sa_group_mlp_max calls then pass
@@ -156,7 +166,7 @@ int sa_group_mlp_plan(int b, int m, int nscale, const int *ns, const int *const 
 int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float *xyz, const float *feat,
                      const float *new_xyz, const int *idx, const int *cnt, int nl, const int *dims,
                      const void *const *wpack, const float *const *bias, float *out, int out_stride,
-                     int out_off, void *ws, unsigned long ws_bytes, int flags, sa_stream_t stream);
+                     int out_off, void *ws, unsigned long ws_bytes, int flags, int *overflow, sa_stream_t stream);
 
 /* All scales of one SA layer in one call: scale i has nsample ns[i], idx[i] / cnt[i], layer widths
  * dims[i*(nl+1) .. (i+1)*(nl+1)), weights wpack[i*nl ..] / bias[i*nl ..], output slice out_off[i], plan scratch ws[i]
@@ -166,7 +176,7 @@ int sa_group_mlp_max_layer(int nscale, int b, int n, int m, const int *ns, int c
                            const float *new_xyz, const int *const *idx, const int *const *cnt, int nl, const int *dims,
                            const void *const *wpack, const float *const *bias, float *out, int out_stride,
                            const int *out_off, void *const *ws, const unsigned long *ws_bytes, const int *flags,
-                           sa_stream_t stream);
+                           int *overflow, sa_stream_t stream);
 
 /* y[rows,N] = act(x[rows,K] W + b): tf_util.conv1d 1x1 + folded BN (tf_util.py:51-124). */
 int sa_dense(long rows, int K, int N, const float *x, const void *wpack, const float *bias, int relu,

@@ -153,7 +153,7 @@ def case_mlp(rng):
     st = N.lib().sa_group_mlp_max(b, n, m, ns, c, tx.data_ptr(), tf.data_ptr() if c else None, tn.data_ptr(), ti.data_ptr(),
                                   tc.data_ptr(), nl, dm, (ctypes.c_void_p * nl)(*[l.w.data_ptr() for l in layers]),
                                   (ctypes.c_void_p * nl)(*[l.bias.data_ptr() for l in layers]), out.data_ptr(), dims[-1], 0,
-                                  plan.data_ptr(), plan_bytes, dense | Wt.scale_flags(layers), N.current_stream())
+                                  plan.data_ptr(), plan_bytes, dense | Wt.scale_flags(layers), None, N.current_stream())
     if st != 0:
         return "group_mlp_max status %d %s" % (st, (b, n, m, c, ns, dims))
     torch.cuda.synchronize()
@@ -333,7 +333,7 @@ def case_mlp_big(rng):
     st = N.lib().sa_group_mlp_max(b, n, m, ns, c, tx.data_ptr(), tf.data_ptr(), tn.data_ptr(), ti.data_ptr(), tc.data_ptr(), nl,
                                   (ctypes.c_int * 4)(*([c + 3] + dims)), (ctypes.c_void_p * nl)(*[l.w.data_ptr() for l in layers]),
                                   (ctypes.c_void_p * nl)(*[l.bias.data_ptr() for l in layers]), out.data_ptr(), dims[-1], 0,
-                                  plan.data_ptr(), plan_bytes, dense | Wt.scale_flags(layers), N.current_stream())
+                                  plan.data_ptr(), plan_bytes, dense | Wt.scale_flags(layers), None, N.current_stream())
     if st != 0:
         return "group_mlp_max(big) status %d" % st
     torch.cuda.synchronize()

@@ -35,6 +35,25 @@ def test_ctypes_table_matches_header():
     native.lib()       # resolves every symbol and sets argtypes
 
 
+def test_product_library_reads_no_environment():
+    """The kernel-selection knobs (SA_KNOB, csrc/sa_common.h) exist only in `make TUNE=1` builds: the shipped library
+    imports no getenv and holds no SA_* variable name, so its behaviour is a function of its arguments only."""
+    import subprocess
+    native = pkg("utils._native")
+    syms = subprocess.run(["nm", "-D", "--undefined-only", native.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in syms
+    blob = open(native.LIB_PATH, "rb").read()
+    for name in (b"SA_MLP_", b"SA_FPS_", b"SA_SQDIST_", b"SA_BQ_", b"SA_ABLATE"):
+        assert name not in blob, name
+    # and neither does the Python package (bench.py records / refuses what is left: SA3D_LIB selects a tuning build)
+    import glob
+    for f in glob.glob(os.path.join(ROOT, "3dssd_amd", "**", "*.py"), recursive=True):
+        src = open(f).read()
+        if f.endswith(os.path.join("utils", "_native.py")) or f.endswith("sharding.py") or f.endswith("pipeline.py"):
+            continue                                   # SA3D_LIB / torchrun's RANK.. / GPU_MAX_HW_QUEUES default
+        assert not re.search(r"os\.environ|getenv\(|environ\.get", src), f
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     native = pkg("utils._native")
     monkeypatch.setattr(native, "_LIB", None)

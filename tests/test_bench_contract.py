@@ -1,41 +1,83 @@
-"""The bench line committed under profiles/ (the output of `python bench.py` on the GPU box) carries every field of
-the driver's contract, and its algorithmic work model reproduces SURVEY.md 8d: 30.93 GFLOP of MLP per frame."""
+"""The bench lines committed under profiles/ (outputs of `python bench.py` on the GPU box, round 3) carry every field
+of the driver's contract, the round-3 additions (distinct frames, verification against eager, recorded environment,
+latency-bound roofline for FPS, executed-flop MFMA fraction), and their algorithmic work model reproduces SURVEY.md 8d:
+30.93 GFLOP of MLP per frame."""
 import json
 import os
 
+import pytest
+
 from conftest import ROOT
 
+MLP_CALLS = ("sa_group_mlp_max", "sa_group_mlp_max_layer")
 
-def _line():
-    with open(os.path.join(ROOT, "profiles", "r01_bench_s16_graphs.json")) as f:
+
+def _line(name="r03_bench_default.json"):
+    with open(os.path.join(ROOT, "profiles", name)) as f:
         return json.loads(f.read().strip().splitlines()[-1])
 
 
-def test_bench_line_has_the_contract_fields():
-    d = _line()
+@pytest.mark.parametrize("name", ["r03_bench_default.json", "r03_bench_20steps.json", "r03_bench_dup10.json", "r03_bench_dense.json"])
+def test_bench_line_has_the_contract_fields(name):
+    d = _line(name)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "env_knobs", "verify", "timed_window_ms", "ramp_dominated"):
         assert k in d, k
     assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"] and "configs[1]" in d["config"]["workload"]
+    assert "SAPipeline" in d["config"]["executor"] and d["config"]["pool_frames_per_gpu"] >= 128
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
-    c = d["cpu_baseline"]
-    for k in ("value", "unit", "cores", "kind", "sample"):
-        assert k in c, k
-    assert c["kind"] in ("port", "reference") and c["unit"] == d["unit"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
     # value = frames of all ranks / wall time of the timed steps
     frames = d["config"]["frames_per_step_per_gpu"] * d["n_gpus"]
     assert abs(d["value"] - frames / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+    assert abs(d["timed_window_ms"] - d["ms_per_step"] * d["steps"]) < 0.05 * d["timed_window_ms"]
+    # every pipeline output of the verification pass equalled the eager result of the same batch
+    v = d["verify"]
+    assert v["all_equal_eager"] is True and v["output_sha1_replay"] == v["output_sha1_eager"] and v["batches"] >= 16
+    assert not [k for k in d["env_knobs"] if k.startswith("SA_")]
+
+
+def test_default_line_cpu_baseline_and_ramp_flag():
+    d = _line()
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample", "effective_parallelism"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["unit"] == d["unit"]
+    assert d["ramp_dominated"] is False and d["steps"] >= 100
+    assert _line("r03_bench_20steps.json")["ramp_dominated"] is True      # the driver's 20-step run says so itself
+
+
+def test_fps_roofline_is_latency_bound_with_evaluated_pairs():
+    r = _line()["roofline"]
+    assert r["bound"] == "latency" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
+    assert r["device_kernel"].startswith("fps3_wave_bucket_kernel")
+    assert r["reference_pair_evaluations"] == 8 * 4095 * 16384
+    assert 0 < r["evaluated_pairs"] < r["reference_pair_evaluations"] and abs(r["evaluated_frac"] - r["evaluated_pairs"] / r["reference_pair_evaluations"]) < 1e-4
+    assert abs(r["achieved"] - r["reference_pair_evaluations"] * 11 / (r["avg_launch_ms"] * 1e9)) < 0.01
+    assert abs(r["cycles_per_pick"] - r["us_per_pick"] * r["clock_mhz"]) < 1.0 and r["cus_used"] == 8
+    assert abs(r["algorithmic_bytes"] / 8 / 1e6 - 0.213) < 0.001     # 213 KB algorithmic per frame for layer-1 FPS
 
 
 def test_algorithmic_mlp_work_matches_survey_8d():
     d = _line()
     frames = d["config"]["frames_per_step_per_gpu"]
-    mlp = sum(s["gflop"] * s["calls_per_step"] for s in d["stages"] if s["kernel"] in ("sa_group_mlp_max", "sa_dense"))
+    mlp = sum(s["gflop"] * s["calls_per_step"] for s in d["stages"] if s["kernel"] in MLP_CALLS + ("sa_dense", "sa_vote_tail"))
     assert abs(mlp / frames - 30.93) < 0.01            # 30.93 GFLOP per frame through the backbone
     fps = [s for s in d["stages"] if s["label"].startswith("fps n=16384")]
     assert len(fps) == 1 and fps[0]["calls_per_step"] == 1
-    assert abs(fps[0]["mbytes"] / frames - 0.213) < 0.001   # 213 KB algorithmic per frame for layer-1 FPS
+    g = d["roofline_grouped_mlp"]
+    rows = d["mlp_rows_per_step"]
+    # frac is on EXECUTED flops, the nominal figure stands beside it
+    ms = g["kernel_ms"] + g["plan_ms"]
+    assert abs(g["achieved"] - rows["gflop_evaluated"] / ms) < 0.5 and abs(g["frac"] - g["achieved"] / g["peak"]) < 1e-4
+    assert abs(g["nominal_tflops"] - rows["gflop_nominal"] / ms) < 1.0 and g["nominal_frac"] > g["frac"]
+
+
+def test_data_variants_move_the_data_dependent_counters():
+    base, dense, dup = _line(), _line("r03_bench_dense.json"), _line("r03_bench_dup10.json")
+    assert dense["config"]["data"] == "dense" and dup["config"]["data"] == "dup10"
+    assert dense["mlp_rows_per_step"]["evaluated_frac"] > 0.95 > 0.5 > base["mlp_rows_per_step"]["evaluated_frac"]
+    assert dense["value"] < base["value"]               # the uniform box is the slow case, and the line shows it

@@ -166,7 +166,7 @@ def test_grouped_mlp_is_permutation_invariant_inside_a_ball(gpu, c, ns, dims):
         st = N.lib().sa_group_mlp_max(b, n, m, ns, c, xyz.data_ptr(), feat.data_ptr(), new_xyz.data_ptr(), ix.data_ptr(),
                                       cnt.data_ptr(), nl, dm, (ctypes.c_void_p * nl)(*[l.w.data_ptr() for l in layers]),
                                       (ctypes.c_void_p * nl)(*[l.bias.data_ptr() for l in layers]), out.data_ptr(),
-                                      dims[-1], 0, plan.data_ptr(), plan_bytes, Wt.scale_flags(layers), N.current_stream())
+                                      dims[-1], 0, plan.data_ptr(), plan_bytes, Wt.scale_flags(layers), None, N.current_stream())
         assert st == 0
         torch.cuda.synchronize()
         return out
@@ -202,33 +202,44 @@ def test_backbone_batched_equals_per_frame_and_is_deterministic(gpu, frames):
 
 
 def test_graph_replay_on_concurrent_streams_equals_eager(gpu, frames):
-    """bench.py's execution mode: one captured hipGraph per stream, replays of several streams in flight at once.  Every
-    replay must reproduce the eager single-stream result bit for bit (no shared scratch between streams, workspace
-    counters reset inside the graph)."""
+    """The execution mode of the headline number: one captured hipGraph per stream, replays of several streams in flight
+    at once, EVERY STREAM ON A DIFFERENT BATCH (identical inputs would hide shared scratch: both streams would write the
+    same bytes).  Every replay must reproduce the eager single-stream result of ITS batch bit for bit, three rounds with
+    the batches rotated over the streams (tests/test_pipeline_gpu.py drives the packaged executor the same way)."""
     cfgs, syn = pkg("configs"), pkg("synthetic")
     arch = cfgs.KITTI_3DSSD_ARCH
     net = pkg("backbone").SABackbone(arch, syn.random_backbone_params(arch), gpu, cfgs.KITTI_MAX_TRANSLATE_RANGE)
-    xl, fl, _ = net(frames)
+    nstream = 4
+    batches = [torch.from_numpy(syn.kitti_like_batch(4, first_frame=200 + 4 * i)).to(gpu) for i in range(nstream)]
+    refs = []
+    for t in batches:
+        xl, fl, _ = net(t)
+        refs.append((xl[-1].clone(), fl[-1].clone()))
     torch.cuda.synchronize()
-    ref_xyz, ref_feat = xl[-1].clone(), fl[-1].clone()
-    streams = [torch.cuda.Stream(device=gpu) for _ in range(4)]
+    assert not torch.equal(refs[0][1], refs[1][1])
+    streams = [torch.cuda.Stream(device=gpu) for _ in range(nstream)]
     graphs = []
     for st in streams:
+        inp = torch.zeros_like(batches[0])
+        inp.copy_(batches[0])
+        torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=st):
-            gx, gf, _ = net(frames)
-        graphs.append((g, gx[-1], gf[-1]))
+            gx, gf, _ = net(inp)
+        graphs.append((g, inp, gx[-1], gf[-1]))
     torch.cuda.synchronize()
     for rnd in range(3):
-        for (g, ox, of), st in zip(graphs, streams):
+        for (g, inp, ox, of) in graphs:
             of.fill_(-1.0)                                   # on the default stream, before the replays of this round
         torch.cuda.synchronize()
-        for (g, _, _), st in zip(graphs, streams):
+        for j, ((g, inp, _, _), st) in enumerate(zip(graphs, streams)):
             with torch.cuda.stream(st):
+                inp.copy_(batches[(j + rnd) % nstream], non_blocking=True)
                 g.replay()
         torch.cuda.synchronize()
-        for g, ox, of in graphs:
-            assert torch.equal(ox, ref_xyz) and torch.equal(of, ref_feat), "round %d" % rnd
+        for j, (g, inp, ox, of) in enumerate(graphs):
+            rx, rf = refs[(j + rnd) % nstream]
+            assert torch.equal(ox, rx) and torch.equal(of, rf), "round %d stream %d" % (rnd, j)
 
 
 def test_non_finite_inputs_do_not_hang_or_leave_the_index_range(gpu):
