@@ -1002,7 +1002,8 @@ __global__ void vote_translate_kernel(long total, const float *__restrict__ xyz,
 // plain store; only balls of more than 32 distinct rows are split (atomic max on a row zeroed here).  Next fit is a
 // sequential rule; it is evaluated in parallel as a scan over FUNCTIONS phase -> (phase, advance) (phase = fill of
 // the current tile, 0..3): a thread folds its 8 balls for each of the 4 start phases, waves scan by composition.
-constexpr int kPlanThreads = 1024, kPlanBallsPerThread = 8;
+constexpr int kPlanThreads = 512, kPlanBallsPerThread = 8;
+constexpr int kPlanChunk = kPlanThreads * kPlanBallsPerThread;      // 4096 balls per workgroup
 
 struct PlanFn { int t[4]; };     // t[p] = advance << 2 | end phase, for start phase p
 __device__ __forceinline__ int plan_fn_at(const PlanFn &f, int p) {
@@ -1025,9 +1026,32 @@ __device__ __forceinline__ int plan_place(int g, int &ph) {
     ph = (ph + g) & 3;
     return pad;
 }
+__device__ __forceinline__ int plan_granules_of(const int *cnt, int ball, int nballs, int ns, int dense, int &rows) {
+    if (ball >= nballs) return 0;
+    int c = cnt[ball];
+    c = c < 1 ? 1 : (c > ns ? ns : c);
+    if (dense) c = ns;
+    rows += c;
+    return (c + 7) >> 3;
+}
+// inclusive scan by composition over the 64 lanes of a wave
+__device__ __forceinline__ PlanFn plan_wave_scan(PlanFn incl, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        PlanFn o;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) o.t[p] = __shfl_up(incl.t[p], d);
+        if (lane >= d) incl = plan_fn_compose(o, incl);
+    }
+    return incl;
+}
 
-// One workgroup per scale walks the scale's balls in chunks of 8192 (1024 threads x 8 balls), carrying the packing
-// state from chunk to chunk: no atomics, no counter to reset between calls, the same plan on every run.
+// A scale's balls are cut into chunks of 4096; workgroup (chunk, scale) packs ITS chunk.  The packing state in front of
+// the chunk (granules placed so far, fill of the open tile) is a function of all earlier balls: every workgroup
+// recomputes it with one summary pass over them -- a thread folds a contiguous run of balls into a phase -> (phase,
+// advance) function, a wave scan and a 8-entry serial composition give the total -- instead of waiting for its
+// predecessors (no atomics, no flags to reset between calls, the same plan on every run).  Until round 3 one workgroup
+// per scale walked its chunks one after the other: 61 us for layer1's 3 x 32 768 balls on three workgroups.
 constexpr int kPlanMaxScales = 4;
 struct PlanJob {
     const int *cnt;
@@ -1043,99 +1067,128 @@ struct PlanJobs {
 __global__ __launch_bounds__(kPlanThreads) void mlp_plan_kernel(PlanJobs J) {
     constexpr int NWV = kPlanThreads / 64;
     __shared__ int wfn[NWV][4];
+    __shared__ int wsum[NWV][2];
     __shared__ int nsplit_s;
-    __shared__ int split_ball[kPlanThreads * kPlanBallsPerThread];
-    const PlanJob job = J.j[blockIdx.x];
+    __shared__ int split_ball[kPlanChunk];
+    const PlanJob job = J.j[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nballs = J.nballs, ns = job.ns;
-    int base = 0;                                       // advance << 2 | phase in front of the current chunk
-    int rows_acc = 0, nsplit_acc = 0;
-    for (int chunk0 = 0; chunk0 < nballs; chunk0 += kPlanThreads * kPlanBallsPerThread) {
-        if (tid == 0) nsplit_s = 0;
-        const int ball0 = chunk0 + tid * kPlanBallsPerThread;
-        int g[kPlanBallsPerThread], rows = 0;
-#pragma unroll
-        for (int k = 0; k < kPlanBallsPerThread; ++k) {
-            const int ball = ball0 + k;
-            int c = 0;
-            if (ball < nballs) { c = job.cnt[ball]; c = c < 1 ? 1 : (c > ns ? ns : c); if (J.dense) c = ns; }
-            g[k] = (c + 7) >> 3;
-            rows += c;
-        }
+    const int chunk0 = blockIdx.x * kPlanChunk;
+    if (chunk0 >= nballs) return;
+    const bool last_chunk = chunk0 + kPlanChunk >= nballs;
+    if (tid == 0) nsplit_s = 0;
+
+    // ---- summary of the balls in front of this chunk: packing state `base`, distinct rows and split balls so far
+    int base = 0, rows_before = 0, nsplit_before = 0;
+    if (chunk0 > 0) {
+        const int per = (chunk0 + kPlanThreads - 1) / kPlanThreads;
+        const int b0 = tid * per, b1 = min(b0 + per, chunk0);
         PlanFn f;
+        int rows = 0, nsp = 0;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            int ph = p, adv = 0;
+        for (int p = 0; p < 4; ++p) f.t[p] = p;
+        for (int ball = b0; ball < b1; ball += 8) {     // 8 counts requested together, then folded (a load per ball in the
+            int g8[8];                                  // fold loop waited ~400 cycles for each of the up to 56 balls)
 #pragma unroll
-            for (int k = 0; k < kPlanBallsPerThread; ++k)
-                if (g[k] > 0) { adv += plan_place(g[k], ph); adv += g[k]; }
-            f.t[p] = (adv << 2) | ph;
+            for (int k = 0; k < 8; ++k) g8[k] = ball + k < b1 ? plan_granules_of(job.cnt, ball + k, nballs, ns, J.dense, rows) : 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int g = g8[k];
+                nsp += g > 4;
+                if (g > 0) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        int ph = f.t[p] & 3, adv = f.t[p] >> 2;
+                        adv += plan_place(g, ph) + g;
+                        f.t[p] = (adv << 2) | ph;
+                    }
+                }
+            }
         }
-        PlanFn incl = f;                                // inclusive scan by composition over the wave
+        const PlanFn incl = plan_wave_scan(f, lane);
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            PlanFn o;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) o.t[p] = __shfl_up(incl.t[p], d);
-            if (lane >= d) incl = plan_fn_compose(o, incl);
-        }
-        int rsum = rows;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) rsum += __shfl_xor(rsum, d);
+        for (int d = 32; d >= 1; d >>= 1) { rows += __shfl_xor(rows, d); nsp += __shfl_xor(nsp, d); }
         if (lane == 63) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) wfn[w][p] = incl.t[p];
         }
-        if (lane == 0) rows_acc += rsum;                // lane 0 of every wave: summed at the end through wfn
+        if (lane == 0) { wsum[w][0] = rows; wsum[w][1] = nsp; }
         __syncthreads();
-        int st = base, bend = base;                     // state in front of this wave / behind the chunk
 #pragma unroll
         for (int i = 0; i < NWV; ++i) {
-            const int y = wfn[i][bend & 3];
-            bend = (((bend >> 2) + (y >> 2)) << 2) | (y & 3);
-            if (i < w) st = bend;
+            const int y = wfn[i][base & 3];
+            base = (((base >> 2) + (y >> 2)) << 2) | (y & 3);
+            rows_before += wsum[i][0];
+            nsplit_before += wsum[i][1];
         }
-        {
-            PlanFn excl;                                // exclusive prefix of this thread inside its wave
-#pragma unroll
-            for (int p = 0; p < 4; ++p) { const int v = __shfl_up(incl.t[p], 1); excl.t[p] = lane == 0 ? p : v; }
-            const int y = plan_fn_at(excl, st & 3);
-            st = (((st >> 2) + (y >> 2)) << 2) | (y & 3);
-        }
-        int pos = st >> 2, ph = st & 3;
-#pragma unroll
-        for (int k = 0; k < kPlanBallsPerThread; ++k) {
-            if (g[k] > 0) {
-                const int ball = ball0 + k;
-                const int pad = plan_place(g[k], ph);
-                for (int j = 0; j < pad; ++j) job.gran[pos + j] = -1;
-                pos += pad;
-                const int split = g[k] > 4 ? 1 : 0;
-                for (int j = 0; j < g[k]; ++j) job.gran[pos + j] = (ball << 7) | (j << 1) | split;
-                pos += g[k];
-                if (split) split_ball[atomicAdd(&nsplit_s, 1)] = ball;
-            }
-        }
-        __syncthreads();
-        // rows of split balls are zeroed (their partial maxima meet through an atomic max): all threads, coalesced
-        const int nsp = nsplit_s;
-        for (int e = tid; e < nsp * job.N; e += kPlanThreads) {     // (ball, channel) pairs over all threads: a loop
-            const int i = e / job.N, c = e - i * job.N;             // over the balls alone was 64 of layer1's 92 us
-            J.out[(size_t)split_ball[i] * J.out_stride + job.out_off + c] = 0.0f;
-        }
-        nsplit_acc += nsp;
-        base = bend;
         __syncthreads();
     }
-    // header: granules (padded to whole tiles with invalid entries), split balls, distinct rows
-    if (lane == 0) wfn[w][0] = rows_acc;
+
+    // ---- this chunk
+    const int ball0 = chunk0 + tid * kPlanBallsPerThread;
+    int g[kPlanBallsPerThread], rows = 0;
+#pragma unroll
+    for (int k = 0; k < kPlanBallsPerThread; ++k) g[k] = plan_granules_of(job.cnt, ball0 + k, nballs, ns, J.dense, rows);
+    PlanFn f;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        int ph = p, adv = 0;
+#pragma unroll
+        for (int k = 0; k < kPlanBallsPerThread; ++k)
+            if (g[k] > 0) { adv += plan_place(g[k], ph); adv += g[k]; }
+        f.t[p] = (adv << 2) | ph;
+    }
+    const PlanFn incl = plan_wave_scan(f, lane);
+    int rsum = rows;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) rsum += __shfl_xor(rsum, d);
+    if (lane == 63) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) wfn[w][p] = incl.t[p];
+    }
+    if (lane == 0) wsum[w][0] = rsum;
     __syncthreads();
-    if (tid == 0) {
-        const int used = base >> 2, total = (used + 3) & ~3;
+    int st = base, bend = base, rows_chunk = 0;       // state in front of this wave / behind the chunk
+#pragma unroll
+    for (int i = 0; i < NWV; ++i) {
+        const int y = wfn[i][bend & 3];
+        bend = (((bend >> 2) + (y >> 2)) << 2) | (y & 3);
+        if (i < w) st = bend;
+        rows_chunk += wsum[i][0];
+    }
+    {
+        PlanFn excl;                                    // exclusive prefix of this thread inside its wave
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { const int v = __shfl_up(incl.t[p], 1); excl.t[p] = lane == 0 ? p : v; }
+        const int y = plan_fn_at(excl, st & 3);
+        st = (((st >> 2) + (y >> 2)) << 2) | (y & 3);
+    }
+    int pos = st >> 2, ph = st & 3;
+#pragma unroll
+    for (int k = 0; k < kPlanBallsPerThread; ++k) {
+        if (g[k] > 0) {
+            const int ball = ball0 + k;
+            const int pad = plan_place(g[k], ph);
+            for (int j = 0; j < pad; ++j) job.gran[pos + j] = -1;
+            pos += pad;
+            const int split = g[k] > 4 ? 1 : 0;
+            for (int j = 0; j < g[k]; ++j) job.gran[pos + j] = (ball << 7) | (j << 1) | split;
+            pos += g[k];
+            if (split) split_ball[atomicAdd(&nsplit_s, 1)] = ball;
+        }
+    }
+    __syncthreads();
+    // rows of split balls are zeroed (their partial maxima meet through an atomic max): all threads, coalesced
+    const int nsp = nsplit_s;
+    for (int e = tid; e < nsp * job.N; e += kPlanThreads) {         // (ball, channel) pairs over all threads
+        const int i = e / job.N, c = e - i * job.N;
+        J.out[(size_t)split_ball[i] * J.out_stride + job.out_off + c] = 0.0f;
+    }
+    // header (the workgroup of the last chunk): granules padded to whole tiles with invalid entries, split balls, rows
+    if (last_chunk && tid == 0) {
+        const int used = bend >> 2, total = (used + 3) & ~3;
         for (int q = used; q < total; ++q) job.gran[q] = -1;
-        int rows = 0;
-        for (int i = 0; i < NWV; ++i) rows += wfn[i][0];
-        job.hdr[0] = total; job.hdr[1] = nsplit_acc; job.hdr[2] = rows; job.hdr[3] = 0;
+        job.hdr[0] = total; job.hdr[1] = nsplit_before + nsp; job.hdr[2] = rows_before + rows_chunk; job.hdr[3] = 0;
     }
 }
 
@@ -1163,6 +1216,35 @@ extern "C" size_t sa_group_mlp_max_ws_bytes(int b, int m, int ns) {
     return (size_t)sa::kPlanHeaderInts * sizeof(int) + ((size_t)sa_plan_max_granules((long)b * m, ns) + 8) * sizeof(int);
 }
 
+// mlp_gemm.hip: the wide scales as a chain of three large-tile GEMMs over packed fp16 intermediates
+size_t sa_mlp_gemm_scratch_bytes(long max_tiles, const int *dims);
+bool sa_mlp_gemm_eligible(int c, int nl, const int *dims, int fp16);
+int sa_mlp_gemm_launch(int nscale, int b, int n, int m, const int *ns, int c, const float *xyz, const float *feat,
+                       const float *new_xyz, const int *const *idx, const int *const *cnt, const int *dims,
+                       const void *const *wpack, const float *const *bias, float *out, int out_stride, const int *out_off,
+                       const int *const *plan_hdr, const int *const *plan_gran, const long *max_tiles,
+                       void *const *scratch, int *overflow, hipStream_t stream);
+
+static size_t plan_bytes_aligned(int b, int m, int ns) { return (sa_group_mlp_max_ws_bytes(b, m, ns) + 255) & ~(size_t)255; }
+
+// Scratch for a scale that may take the GEMM chain: the row plan, then (256-byte aligned) the packed hidden activations
+// H1 | H2 of the densest plan.  A caller that passes only sa_group_mlp_max_ws_bytes gets the fused kernels.
+extern "C" size_t sa_group_mlp_gemm_ws_bytes(int b, int m, int ns, int c, int nl, const int *dims) {
+    if (b <= 0 || m <= 0 || ns <= 0 || !dims) return 0;
+    if (!sa_mlp_gemm_eligible(c, nl, dims, 1)) return sa_group_mlp_max_ws_bytes(b, m, ns);
+    const long max_tiles = (sa_plan_max_granules((long)b * m, ns) + 3) / 4;
+    return plan_bytes_aligned(b, m, ns) + sa_mlp_gemm_scratch_bytes(max_tiles, dims);
+}
+// does this call take the chain?  Opt-in: flags bit 4 (16).  Measured on layer4 of 3dssd.yaml (batch 8, both scales):
+// chain 157 us (phases 40 / 37 / 80) against 146 us for the fused kernels -- the packed intermediates H1 / H2 (18 + 37 MB
+// per scale) do not stay in the 4 MB per-XCD L2 between launches, every phase streams them through Infinity Cache / HBM
+// (~300 MB per layer call), and its stores stall at the memory write rate; DESIGN.md section 6 has the breakdown.
+static bool use_gemm_chain(int b, int m, int ns, int c, int nl, const int *dims, size_t ws_bytes, int flags) {
+    if (!(flags & 16) || (flags & 1) || !(flags & 4)) return false;
+    if (!sa_mlp_gemm_eligible(c, nl, dims, 1)) return false;
+    return ws_bytes >= sa_group_mlp_gemm_ws_bytes(b, m, ns, c, nl, dims);
+}
+
 // Row plans of ALL scales of an SA layer in one launch (one workgroup per scale).  cnt[i]: pts_cnt of scale i
 // [b, m]; ws[i]: scratch of sa_group_mlp_max_ws_bytes(b, m, ns[i]) bytes; out / out_stride / out_off[i] / nout[i]:
 // where scale i's pooled channels go (rows of balls with more than 32 distinct rows are zeroed here).  The
@@ -1182,7 +1264,7 @@ extern "C" int sa_group_mlp_plan(int b, int m, int nscale, const int *ns, const 
         J.j[i].ns = ns[i]; J.j[i].out_off = out_off[i]; J.j[i].N = nout[i];
     }
     J.nballs = (int)nballs; J.dense = flags & 1; J.out_stride = out_stride; J.out = out;
-    hipLaunchKernelGGL(mlp_plan_kernel, dim3(nscale), dim3(kPlanThreads), 0, stream, J);
+    hipLaunchKernelGGL(mlp_plan_kernel, dim3((unsigned)((nballs + kPlanChunk - 1) / kPlanChunk), nscale), dim3(kPlanThreads), 0, stream, J);
     SA_CHECK_LAUNCH();
     return SA_OK;
 }
@@ -1219,10 +1301,16 @@ extern "C" int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float 
         PlanJobs J{};
         J.j[0].cnt = cnt; J.j[0].hdr = hdr; J.j[0].gran = gran; J.j[0].ns = ns; J.j[0].out_off = out_off; J.j[0].N = dims[nl];
         J.nballs = (int)nballs; J.dense = flags & 1; J.out_stride = out_stride; J.out = out;
-        hipLaunchKernelGGL(mlp_plan_kernel, dim3(1), dim3(kPlanThreads), 0, stream, J);
+        hipLaunchKernelGGL(mlp_plan_kernel, dim3((unsigned)((nballs + kPlanChunk - 1) / kPlanChunk), 1), dim3(kPlanThreads), 0, stream, J);
         SA_CHECK_LAUNCH();
     }
     const bool fp16 = (flags & 4) != 0;
+    if (use_gemm_chain(b, m, ns, c, nl, dims, ws_bytes, flags)) {
+        const int *hdr_c = hdr, *gran_c = gran;
+        void *scratch = (char *)ws + plan_bytes_aligned(b, m, ns);
+        return sa_mlp_gemm_launch(1, b, n, m, &ns, c, xyz, feat, new_xyz, &idx, &cnt, dims, wpack, bias, out, out_stride,
+                                  &out_off, &hdr_c, &gran_c, &max_tiles, &scratch, overflow, stream);
+    }
     {
         int st = SA_OK;
         if (sa_rowwave_try(b, n, m, ns, c, xyz, feat, new_xyz, idx, cnt, nl, dims, wpack, bias, out, out_stride,
@@ -1354,6 +1442,26 @@ extern "C" int sa_group_mlp_max_layer(int nscale, int b, int n, int m, const int
                                      out_off, hdr, gran, max_tiles, fp16, overflow, stream, &st))
                 return st;
         }
+    }
+    // two wide scales (layer4 of 3dssd.yaml) whose plans are built: the GEMM chain of both in three launches
+    if (nscale == 2 && nl == 3 && b > 0 && m > 0 && xyz && new_xyz && out && feat) {
+        bool ok = true;
+        const int *hdr[2], *gran[2];
+        long max_tiles[2];
+        void *scratch[2];
+        for (int i = 0; i < 2 && ok; ++i) {
+            ok = (flags[i] & 2) && ns[i] > 0 && idx[i] && cnt[i] && ws[i] && dims[4 * i] == c + 3 &&
+                 use_gemm_chain(b, m, ns[i], c, nl, dims + 4 * i, ws_bytes[i], flags[i]);
+            for (int l = 0; l < 3 && ok; ++l) ok = dims[4 * i + l + 1] > 0 && wpack[3 * i + l] && bias[3 * i + l];
+            if (!ok) break;
+            hdr[i] = (const int *)ws[i];
+            gran[i] = hdr[i] + sa::kPlanHeaderInts;
+            max_tiles[i] = (sa_plan_max_granules((long)b * m, ns[i]) + 3) / 4;
+            scratch[i] = (char *)ws[i] + plan_bytes_aligned(b, m, ns[i]);
+        }
+        if (ok)
+            return sa_mlp_gemm_launch(2, b, n, m, ns, c, xyz, feat, new_xyz, idx, cnt, dims, wpack, bias, out, out_stride,
+                                      out_off, hdr, gran, max_tiles, scratch, overflow, stream);
     }
     for (int i = 0; i < nscale; ++i) {
         const int st = sa_group_mlp_max(b, n, m, ns[i], c, xyz, feat, new_xyz, idx[i], cnt[i], nl, dims + (nl + 1) * i,

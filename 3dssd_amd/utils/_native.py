@@ -99,6 +99,8 @@ def lib():
         h.sa_query_ball_point_grid_ws_bytes.restype = ctypes.c_size_t
         h.sa_group_mlp_max_ws_bytes.argtypes = [_c_int] * 3
         h.sa_group_mlp_max_ws_bytes.restype = ctypes.c_size_t
+        h.sa_group_mlp_gemm_ws_bytes.argtypes = [_c_int] * 5 + [_vp]
+        h.sa_group_mlp_gemm_ws_bytes.restype = ctypes.c_size_t
         h.sa_calc_square_dist_ws_bytes.argtypes = [_c_int] * 5
         h.sa_calc_square_dist_ws_bytes.restype = ctypes.c_size_t
         h.sa_host_crc32c.argtypes = [_vp, ctypes.c_size_t, ctypes.c_uint32]          # host helper: returns the CRC
@@ -131,8 +133,14 @@ def copy_blocks(jobs):
     check(lib().sa_copy_blocks(len(jobs), arr, current_stream()), "copy_blocks")
 
 
-def mlp_plan_ws(b, m, ns, device):
-    """Device scratch for the row plan of one sa_group_mlp_max call: (int32 tensor, size in bytes)."""
+def mlp_plan_ws(b, m, ns, device, c=None, dims=None):
+    """Device scratch of one sa_group_mlp_max call: (int32 tensor, size in bytes).  The row plan; with c and dims =
+    [c + 3, widths...] given, also the packed hidden activations of the GEMM chain where the scale is eligible for it
+    (sa_group_mlp_gemm_ws_bytes)."""
     import torch
-    nbytes = int(lib().sa_group_mlp_max_ws_bytes(int(b), int(m), int(ns)))
+    if dims is not None:
+        arr = (ctypes.c_int * len(dims))(*[int(d) for d in dims])
+        nbytes = int(lib().sa_group_mlp_gemm_ws_bytes(int(b), int(m), int(ns), int(c), len(dims) - 1, arr))
+    else:
+        nbytes = int(lib().sa_group_mlp_max_ws_bytes(int(b), int(m), int(ns)))
     return torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=device), nbytes

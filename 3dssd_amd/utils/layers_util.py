@@ -46,6 +46,7 @@ DFPS_SIDE_STREAM = 6
 PLAN_LOG = None     # set to a list to collect (b, m, nsample, MACs per row, plan tensor) of every fused-MLP call
 MLP_PLAN_FLAGS = 0  # sa_group_mlp_max flag bit 0 (all nsample rows instead of the distinct ones), A/B measurements
 GRID_BALL_QUERY_MIN_N = 2048
+MLP_GEMM_CHAIN = False  # True: eligible fp16 scales (layer4) run as three large-tile GEMM launches (flags bit 4); measured slower
 MAX_TRANSLATE_RANGE = (-3.0, -2.0, -3.0)
 
 
@@ -419,7 +420,10 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
         new_points_concat = torch.empty((bs, m, ctot), dtype=torch.float32, device=dev)
         c_feat = points.shape[2]
         # row plans of all scales in one launch: only the distinct rows of every ball are evaluated (mlp_plan.h)
-        plans = [N.mlp_plan_ws(bs, m, int(ns), dev) for ns in nsample_list]
+        # (+ the packed hidden activations of the opt-in GEMM chain, csrc/mlp_gemm.hip, when MLP_GEMM_CHAIN is set)
+        plans = [N.mlp_plan_ws(bs, m, int(ns), dev, c_feat, [c_feat + 3] + [l.N for l in layers[i]]
+                               if (MLP_GEMM_CHAIN and W.scale_flags(layers[i])) else None)
+                 for i, ns in enumerate(nsample_list)]
         offs, acc = [], 0
         for ls in layers:
             offs.append(acc)
@@ -447,7 +451,7 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
                 new_points_concat.data_ptr(), ctot, (ctypes.c_int * k)(*[offs[i] for i in live]),
                 (ctypes.c_void_p * k)(*[plans[i][0].data_ptr() for i in live]),
                 (ctypes.c_ulong * k)(*[plans[i][1] for i in live]),
-                (ctypes.c_int * k)(*[MLP_PLAN_FLAGS | (2 if have_plans else 0) | W.scale_flags(layers[i]) for i in live]),
+                (ctypes.c_int * k)(*[MLP_PLAN_FLAGS | (16 if MLP_GEMM_CHAIN else 0) | (2 if have_plans else 0) | W.scale_flags(layers[i]) for i in live]),
                 vs.overflow.data_ptr(), stream)
             N.check(st, "group_mlp_max_layer")
         else:                                                               # scales of different depth: one by one
@@ -461,7 +465,7 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
                                           points.data_ptr(), new_xyz.data_ptr(), idx_list[i].data_ptr(),
                                           cnt_list[i].data_ptr(), nl, dims, wp, bp,
                                           new_points_concat.data_ptr(), ctot, offs[i], plans[i][0].data_ptr(), plans[i][1],
-                                          MLP_PLAN_FLAGS | (2 if have_plans else 0) | W.scale_flags(ls),
+                                          MLP_PLAN_FLAGS | (16 if MLP_GEMM_CHAIN else 0) | (2 if have_plans else 0) | W.scale_flags(ls),
                                           vs.overflow.data_ptr(), stream)
                 N.check(st, "group_mlp_max")
         if PLAN_LOG is not None:                                            # bench.py: rows evaluated per scale

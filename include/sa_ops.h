@@ -158,6 +158,13 @@ int sa_query_ball_point_grid(int b, int n, int m, int nbands, const float *rmin,
  * builds idx / cnt itself passes flags bit 0.  ns <= 512 and b*m < 2^24 (row-plan entry fields): SA_ERR_UNSUPPORTED
  * beyond that. */
 unsigned long sa_group_mlp_max_ws_bytes(int b, int m, int ns);
+/* The same plus, for a scale the GEMM chain of 3dssd_amd/csrc/mlp_gemm.hip can take (three layers, fp16, c a multiple of
+ * 8, hidden widths multiples of 32 and >= 128, last width >= 256: layer4 of 3dssd.yaml), room for the packed fp16
+ * hidden activations of the densest row plan.  OPT-IN: sa_group_mlp_max / _layer take the chain -- three launches over
+ * large tiles, every weight byte fetched once per 128 rows -- only with flags bit 4 (16) set and ws_bytes >= this value;
+ * otherwise they run the one-launch fused kernels, which measured faster on the reference shapes (the intermediates
+ * round-trip through Infinity Cache / HBM).  Bit-identical results either way. */
+unsigned long sa_group_mlp_gemm_ws_bytes(int b, int m, int ns, int c, int nl, const int *dims);
 /* The row plans of all scales of a layer in ONE launch: cnt[i] = pts_cnt of scale i, ws[i] = that scale's scratch,
  * out_off[i] / nout[i] = where scale i's channels go in out.  The layer's sa_group_mlp_max calls then pass
  * flags | 2 (plan already built). */

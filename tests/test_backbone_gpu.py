@@ -150,3 +150,23 @@ def test_stress_65536_layer1_sampling_and_grouping(gpu, oracle):
     gi, gc = G.query_ball_point_dilated(0.4, 0.8, 64, t, ctr)
     ri, rc = oracle.query_ball_point_dilated(0.4, 0.8, 64, xyz, ctr.cpu().numpy())
     assert np.array_equal(gc.cpu().numpy(), rc) and np.array_equal(gi.cpu().numpy(), ri)
+
+
+def test_backbone_with_the_gemm_chain_opted_in_is_bit_identical(gpu):
+    # layers_util.MLP_GEMM_CHAIN: layer4's two fp16 scales as three large-tile GEMM launches over packed fp16
+    # intermediates (csrc/mlp_gemm.hip) instead of the fused kernels -- same operands, same accumulation order
+    cfgs, syn = pkg("configs"), pkg("synthetic")
+    lu = pkg("utils.layers_util")
+    arch = cfgs.KITTI_3DSSD_ARCH
+    net = pkg("backbone").SABackbone(arch, syn.random_backbone_params(arch), gpu)
+    pts = torch.from_numpy(syn.kitti_like_batch(3, first_frame=60)).to(gpu)
+    xl, fl, _ = net(pts)
+    torch.cuda.synchronize()
+    lu.MLP_GEMM_CHAIN = True
+    try:
+        xl2, fl2, _ = net(pts)
+        torch.cuda.synchronize()
+    finally:
+        lu.MLP_GEMM_CHAIN = False
+    assert torch.equal(fl[-1], fl2[-1]) and torch.equal(xl[-1], xl2[-1])
+    net.raise_if_overflow()

@@ -411,7 +411,8 @@ def _pad_like_ball_query(idx, cnt):
     return np.where(pad, idx[:, :, :1], idx)
 
 
-def _run_group_mlp(gpu, xyz, feat, new_xyz, idx, cnt, ws, bs, contiguous=True, flags=0, precision=None, overflow_ok=False):
+def _run_group_mlp(gpu, xyz, feat, new_xyz, idx, cnt, ws, bs, contiguous=True, flags=0, precision=None, overflow_ok=False,
+                   chain=False):
     """One sa_group_mlp_max call through the C ABI.  The fp16 range flag of the call must stay 0 unless overflow_ok (its
     value is left in _run_group_mlp.overflow)."""
     import ctypes
@@ -429,7 +430,8 @@ def _run_group_mlp(gpu, xyz, feat, new_xyz, idx, cnt, ws, bs, contiguous=True, f
     dims = (ctypes.c_int * (nl + 1))(*([c + 3] + [l.N for l in layers]))
     tx, tn, ti, tc = _t(xyz, gpu), _t(new_xyz, gpu), _t(idx, gpu), _t(cnt, gpu)
     tf = _t(feat, gpu) if feat is not None else None
-    plan, plan_bytes = N.mlp_plan_ws(b, m, ns, gpu)
+    # chain=True: scratch for the GEMM chain of csrc/mlp_gemm.hip as well (taken by the eligible fp16 scales)
+    plan, plan_bytes = N.mlp_plan_ws(b, m, ns, gpu, c, [c + 3] + [l.N for l in layers]) if chain else N.mlp_plan_ws(b, m, ns, gpu)
     ovf = torch.zeros(1, dtype=torch.int32, device=gpu)
     ovf_ptr = ovf.data_ptr()
     st = N.lib().sa_group_mlp_max(b, n, m, ns, c, tx.data_ptr(), tf.data_ptr() if tf is not None else None,
@@ -485,7 +487,8 @@ def test_group_mlp_max(gpu, oracle, c, ns, dims):
                                          (128, 32, [128, 128, 256], 45), (128, 16, [128, 256, 256], 45),
                                          (128, 64, [128, 192, 256], 20), (128, 8, [100, 130, 250], 33),
                                          (128, 32, [128, 128, 256], 700), (256, 16, [256, 256, 512], 45),
-                                         (256, 32, [256, 512, 1024], 45), (256, 16, [256, 256, 512], 700)])
+                                         (256, 32, [256, 512, 1024], 45), (256, 16, [256, 256, 512], 700),
+                                         (1, 8, [16, 16, 32], 5000), (64, 40, [64, 64, 128], 2100)])   # 10 000 / 4 200 balls: several 4096-ball chunks of the row plan
 def test_group_mlp_max_rowwave_shapes(gpu, oracle, c, ns, dims, m):
     # the LDS-resident-weight / register-resident-activation kernels (mlp_rowwave.hip; C = 128 rows take the
     # streamed-weight variant, several passes per workgroup at m = 700): every pooling layout
@@ -546,6 +549,38 @@ def test_group_mlp_max_operand_precisions(gpu, oracle, c, ns, dims, m):
         assert err < bar, "%s: relative error %g" % (precision, err)
         assert (got[cnt == 0] == 0).all()
         assert np.array_equal(got, _run_group_mlp(gpu, xyz, feat, new_xyz, pidx, cnt, ws, bs, flags=1, precision=precision))
+
+
+@pytest.mark.parametrize("c,ns,dims,m,b", [(256, 16, [256, 256, 512], 300, 2), (256, 32, [256, 512, 1024], 300, 2),
+                                           (256, 32, [256, 512, 1024], 257, 3), (128, 32, [128, 128, 256], 700, 2),
+                                           (128, 64, [128, 192, 256], 150, 1), (64, 48, [160, 128, 288], 211, 2)])
+def test_group_mlp_gemm_chain(gpu, oracle, c, ns, dims, m, b):
+    # the wide scales as three large-tile GEMM launches over packed fp16 intermediates (csrc/mlp_gemm.hip; opt-in): within the
+    # fp16 bar of the fp32 oracle, and BIT-IDENTICAL to the one-launch fused kernels of the same precision (same
+    # operands, same k order, fp32 accumulation in the matrix cores); ragged tile counts (rows not a multiple of the
+    # 128 / 256-row workgroup tiles, channel tiles not a multiple of 8), empty balls, balls of more than 32 rows (split
+    # across tiles: atomic max), dense and compact plans
+    rng = np.random.default_rng(c * 31 + ns + m)
+    n = 600
+    xyz = _cloud(rng, b, n, scale=4.0)
+    feat = rng.normal(0, 1, (b, n, c)).astype(np.float32)
+    new_xyz = xyz[:, rng.integers(0, n, m)] + rng.normal(0, 0.1, (b, m, 3)).astype(np.float32)
+    idx = rng.integers(0, n, (b, m, ns)).astype(np.int32)
+    cnt = rng.integers(0, ns + 1, (b, m)).astype(np.int32)
+    cnt[:, ::6] = 0
+    pidx = _pad_like_ball_query(idx, cnt)
+    ws, bs = _rand_layers(rng, [c + 3] + dims)
+    ref = oracle.group_mlp_max(xyz, feat, new_xyz, pidx, cnt, ws, bs)
+    got = _run_group_mlp(gpu, xyz, feat, new_xyz, pidx, cnt, ws, bs, precision="fp16", chain=True, flags=16)   # bit 4: the chain
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    print("gemm chain dims %s: %.2e of the fp32 oracle" % ([c + 3] + dims, err))
+    assert err < MLP_TOL, "relative error %g" % err
+    assert (got[cnt == 0] == 0).all()
+    fused = _run_group_mlp(gpu, xyz, feat, new_xyz, pidx, cnt, ws, bs, precision="fp16", chain=True)            # default: fused kernels
+    assert np.array_equal(got, fused)
+    # split bf16 never takes the chain (fp16 only): same call, other precision, still correct
+    got3 = _run_group_mlp(gpu, xyz, feat, new_xyz, pidx, cnt, ws, bs, precision="bf16x3", chain=True, flags=16)
+    assert np.abs(got3 - ref).max() / np.abs(ref).max() < 5e-5
 
 
 @pytest.mark.parametrize("c,ns,dims,m", [(128, 32, [128, 128, 256], 300),      # streamed row-wave kernel (layer3 shape)
