@@ -133,6 +133,13 @@ def _algorithmic(name, a):
     if name == "sa_dense":
         rows, K, N = a[0:3]
         return 2 * rows * K * N, rows * (K + N) * 4 + K * N * 4, "dense %dx%d->%d" % (rows, K, N)
+    if name == "sa_group_point":
+        b, n, c, m, ns = a[0:5]
+        return 0, b * (n * c * 4 + m * ns * 4 + m * ns * c * 4), "group_point m=%d ns=%d c=%d" % (m, ns, c)
+    if name in ("sa_query_ball_point", "sa_query_ball_point_dilated"):
+        b, n, m = a[0:3]
+        ns = a[4] if name == "sa_query_ball_point" else a[5]
+        return 8 * b * n * m, b * (n * 12 + m * 12 + m * ns * 4 + m * 4), "ball_query n=%d m=%d ns=%d" % (n, m, ns)
     if name == "sa_gather_point":
         b, n, m, c = a[0:4]
         return 0, b * m * (2 * c * 4 + 4), "gather_point m=%d c=%d" % (m, c)
@@ -657,13 +664,88 @@ def workload_ffps_isolated(args, sh, rank, world, dev):
     return line
 
 
+def workload_group_materialised(args, sh, rank, world, dev):
+    """The reference's UNFUSED neighbour-grouping sequence at the backbone's own shapes (layers_util.py:134-165):
+    per SA layer the ball query of every band, then group_point(xyz, idx) and group_point(features, idx) with the
+    grouped tensors [B,m,ns,C] materialised in HBM -- what BASELINE.json's "ball_query+group" HBM target refers to
+    (87.44 MB per frame, SURVEY.md 8d).  The benchmarked backbone never does this (the gather is fused into the MLP);
+    this workload exists to put a measured HBM fraction next to that target."""
+    cfgs, syn = pkg("configs"), pkg("synthetic")
+    G = pkg("utils.tf_ops.grouping.tf_grouping")
+    arch = cfgs.KITTI_3DSSD_ARCH
+    net = pkg("backbone").SABackbone(arch, syn.random_backbone_params(arch), dev, cfgs.KITTI_MAX_TRANSLATE_RANGE)
+    frames = sh.frames_of_rank(0, args.batch * world, rank, world)
+    pts = torch.from_numpy(np.stack([syn.frame_of(args.data, f, args.points) for f in frames])).to(dev)
+    xl, fl, _ = net(pts)
+    torch.cuda.synchronize()
+    jobs = []                     # (xyz [B,n,3], features [B,n,C], centres [B,m,3], bands)
+    for li, row in enumerate(arch):
+        radius, nsample, dilated, layer_type = row[2], row[3], row[13], row[11]
+        if layer_type != "SA_Layer" or not radius:
+            continue
+        x_in, f_in = xl[row[0][0]], fl[row[1][0]]
+        ctr = xl[li + 1] if row[14] == -1 else xl[row[14]]
+        bands = [((0.0 if i == 0 or not dilated else float(radius[i - 1])), float(radius[i]), int(nsample[i])) for i in range(len(radius))]
+        jobs.append((x_in.contiguous(), f_in.contiguous(), ctr.contiguous(), bands, dilated))
+
+    by_alg = 0
+    for x_in, f_in, ctr, bands, _d in jobs:          # SURVEY 8d: inputs once + idx/cnt written + grouped tensors written once
+        b, n, m, c = x_in.shape[0], x_in.shape[1], ctr.shape[1], f_in.shape[2]
+        by_alg += b * (n * (3 + c) * 4 + m * 12)
+        for _lo, _hi, ns in bands:
+            by_alg += b * (m * ns * 4 + m * 4 + m * ns * (3 + c) * 4)
+
+    def step():
+        outs = []
+        for x_in, f_in, ctr, bands, dilated in jobs:
+            for lo, hi, ns in bands:
+                idx, cnt = (G.query_ball_point_dilated(lo, hi, ns, x_in, ctr) if dilated else G.query_ball_point(hi, ns, x_in, ctr))
+                outs.append((G.group_point(x_in, idx), G.group_point(f_in, idx)))
+        return outs
+
+    def run(k):
+        return [step() for _ in range(k)]
+
+    t_max, frames_total, host_issue_ms, outs = timed_region(sh, dev, run, args.steps, args.warmup, len(frames))
+    if rank != 0:
+        return None
+    stages = profile_stages(step, max(1, args.profile_iters))
+    ms_step = t_max / args.steps * 1e3
+    grp = [s for s in stages if s["kernel"] == "sa_group_point"]
+    bq = [s for s in stages if s["kernel"].startswith("sa_query_ball")]
+    grp_ms = sum(s["avg_ms"] * s["calls_per_step"] for s in grp)
+    bq_ms = sum(s["avg_ms"] * s["calls_per_step"] for s in bq)
+    gbs = by_alg / (grp_ms + bq_ms) / 1e6 if grp_ms + bq_ms > 0 else 0.0
+    line = {"metric": "frames/sec through ball_query + group_point with materialised grouped tensors (reference op sequence), KITTI 16384-pt",
+            "value": round(frames_total / t_max, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 / int32 copies",
+            "data": "synthetic KITTI-shape frames (seeded, --data %s); layer inputs taken from one backbone forward" % args.data,
+            "config": {"workload": "ball_query + group_point materialised at the shapes of 3dssd.yaml rows 1-3, 6 (one band per call, like the reference), batch=%d per GPU" % args.batch,
+                       "frames_per_step_per_gpu": len(frames), "data": args.data},
+            "timed_window_ms": round(t_max * 1e3, 3), "host_issue_ms_per_step": round(host_issue_ms, 3), "env_knobs": env_knobs()[0],
+            "roofline": {"kernel": "ball_query + group_point, all layers (one stream, HIP events per C-ABI call)", "bound": "hbm",
+                         "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
+                         "traffic": None, "algorithmic_bytes": int(by_alg), "algorithmic_mb_per_frame": round(by_alg / len(frames) / 1e6, 2),
+                         "kernel_ms": round(grp_ms + bq_ms, 5),
+                         "group_point_only": {"ms": round(grp_ms, 5),
+                                              "gbs": round(sum(s["mbytes"] * s["calls_per_step"] for s in grp) / grp_ms, 1) if grp_ms else 0.0,
+                                              "frac": round(sum(s["mbytes"] * s["calls_per_step"] for s in grp) / grp_ms / HBM_PEAK_GBS, 5) if grp_ms else 0.0},
+                         "ball_query_only_ms": round(bq_ms, 5),
+                         "note": "achieved = SURVEY 8d algorithmic bytes (87.4 MB per frame: inputs once, idx / cnt and the "
+                                 "grouped tensors written once) / sum of the kernel times of one step; the host-bound eager "
+                                 "issue (ms_per_step) is not the kernel time"},
+            "stages": stages}
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="configs1", choices=["configs1", "configs2", "configs4"],
-                    help="BASELINE.json configs[1] (default, the metric's configuration), configs[2], configs[4]")
+    ap.add_argument("--workload", default="configs1", choices=["configs1", "configs2", "configs4", "group"],
+                    help="BASELINE.json configs[1] (default, the metric's configuration), configs[2], configs[4]; group: the "
+                         "reference's unfused ball_query + group_point sequence with materialised grouped tensors")
     ap.add_argument("--data", default="default", choices=list(pkg("synthetic").DATA_VARIANTS),
                     help="default: SURVEY 8d generator; dup10: 10 %% duplicated rows (KITTI padding); dense: uniform box, every ball full")
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step")
@@ -682,7 +764,8 @@ def main():
     assert args.gpus >= 1
     defaults = {"configs1": dict(steps=128, warmup=24, batch=8, points=16384, streams=16, pool=160, verify=32),
                 "configs2": dict(steps=4, warmup=1, batch=32, points=16384, streams=1, pool=32, verify=0),
-                "configs4": dict(steps=16, warmup=4, batch=16, points=65536, streams=4, pool=96, verify=8)}[args.workload]
+                "configs4": dict(steps=16, warmup=4, batch=16, points=65536, streams=4, pool=96, verify=8),
+                "group": dict(steps=20, warmup=5, batch=8, points=16384, streams=1, pool=8, verify=0)}[args.workload]
     for k, v in defaults.items():
         if getattr(args, k) is None:
             setattr(args, k, v)
@@ -720,6 +803,8 @@ def main():
     elif args.workload == "configs4":
         # 65536-pt frames: layer-1 FPS is the cooperative multi-workgroup kernel, which cannot be graph-captured
         line = workload_backbone(args, sh, rank, world, dev, args.points, False, "configs[4]")
+    elif args.workload == "group":
+        line = workload_group_materialised(args, sh, rank, world, dev)
     else:
         line = workload_ffps_isolated(args, sh, rank, world, dev)
     if rank == 0:
