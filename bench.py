@@ -302,17 +302,21 @@ def roofline_of(stage, frames, clock_mhz, evaluated_pairs=None):
         while 1024 * (4 if c == 3 else 1) * g < n:
             g *= 2
         wgs, note = frames * g, ("latency-bound serial chain: %d cooperating workgroups of 1024 threads per frame "
-                                 "(csrc/fps_coop.hip), one cross-workgroup arg-max exchange per pick" % g)
+                                 "(csrc/fps_coop.hip), one cross-workgroup arg-max exchange per pick; a cooperative launch "
+                                 "holds 256 workgroups, more frames run as consecutive launches inside the call" % g)
+        launches = -(-wgs // 256)
     else:
         wgs, note = frames, ("latency-bound serial chain: one workgroup (= one CU) per frame, m-1 dependent picks; "
                              "bucket culling evaluates only the pairs near each pick")
+        launches = 1
     r = dict(kernel=label, device_kernel=names[0], bound="latency", achieved=round(tf, 4), peak=VALU_F32_PEAK_TF,
              unit="TFLOP/s", frac=round(tf / VALU_F32_PEAK_TF, 5),
              basis="reference pair evaluations x %d flop / kernel time, against the fp32 VALU peak" % flop_pair,
              traffic=tr, traffic_source=("committed profile %s, not collected in this run" % rel) if tr is not None else None,
              algorithmic_bytes=int(stage["mbytes"] * 1e6), hbm_gbs=a, hbm_frac=round(a / HBM_PEAK_GBS, 7),
-             avg_launch_ms=ms, us_per_pick=round(ms * 1e3 / max(m - 1, 1), 4),
-             cycles_per_pick=round(ms * 1e3 / max(m - 1, 1) * clock_mhz, 1), clock_mhz=clock_mhz,
+             avg_launch_ms=round(ms / launches, 5), sequential_launches_per_call=launches,
+             us_per_pick=round(ms * 1e3 / launches / max(m - 1, 1), 4),
+             cycles_per_pick=round(ms * 1e3 / launches / max(m - 1, 1) * clock_mhz, 1), clock_mhz=clock_mhz,
              workgroups=wgs, cus_used=min(wgs, 256), reference_pair_evaluations=pairs, note=note)
     if evaluated_pairs is not None:
         r["evaluated_pairs"] = int(evaluated_pairs)
