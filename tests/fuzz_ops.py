@@ -128,6 +128,8 @@ def case_mlp(rng):
     b, n, m = int(rng.integers(1, 3)), int(rng.integers(4, 400)), int(rng.integers(1, 120))
     c = int(rng.choice([0, 1, 1, 5, 8, 64, 64, 128, 256]))
     ns = int(rng.choice([1, 3, 8, 16, 20, 32, 48, 64, 70]))
+    if rng.integers(0, 8) == 0:                      # several 4096-ball chunks of the row plan (round 3)
+        b, m, c, ns = 2, int(rng.integers(2100, 6000)), int(rng.choice([1, 8, 64])), int(rng.choice([3, 8, 20]))
     nl = int(rng.integers(1, 4))
     wide = int(rng.choice([16, 32, 64, 128, 256])) if c < 128 else int(rng.choice([128, 256]))
     dims = [int(rng.choice([wide, wide, wide // 2 + 4, wide + 8])) for _ in range(nl)]
@@ -149,14 +151,18 @@ def case_mlp(rng):
     dm = (ctypes.c_int * (nl + 1))(*([c + 3] + dims))
     tx, tn, ti, tc = t(xyz), t(new_xyz), t(idx), t(cnt)
     tf = t(feat) if c else None
-    plan, plan_bytes = N.mlp_plan_ws(b, m, ns, dev)
+    chain = int(rng.integers(0, 2)) * 16             # opt-in GEMM chain (taken only by eligible fp16 scales with the big scratch)
+    plan, plan_bytes = N.mlp_plan_ws(b, m, ns, dev, c, [c + 3] + dims) if chain else N.mlp_plan_ws(b, m, ns, dev)
+    ovf = torch.zeros(1, dtype=torch.int32, device=dev)
     st = N.lib().sa_group_mlp_max(b, n, m, ns, c, tx.data_ptr(), tf.data_ptr() if c else None, tn.data_ptr(), ti.data_ptr(),
                                   tc.data_ptr(), nl, dm, (ctypes.c_void_p * nl)(*[l.w.data_ptr() for l in layers]),
                                   (ctypes.c_void_p * nl)(*[l.bias.data_ptr() for l in layers]), out.data_ptr(), dims[-1], 0,
-                                  plan.data_ptr(), plan_bytes, dense | Wt.scale_flags(layers), None, N.current_stream())
+                                  plan.data_ptr(), plan_bytes, dense | chain | Wt.scale_flags(layers), ovf.data_ptr(), N.current_stream())
     if st != 0:
         return "group_mlp_max status %d %s" % (st, (b, n, m, c, ns, dims))
     torch.cuda.synchronize()
+    if int(ovf.item()) != 0:
+        return "group_mlp_max raised the fp16 range flag on in-range data %s" % ((b, n, m, c, ns, dims),)
     ref = O.group_mlp_max(xyz, feat, new_xyz, idx, cnt, ws, bs)
     got = out.cpu().numpy()
     err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)
@@ -329,11 +335,12 @@ def case_mlp_big(rng):
     nl = 3
     out = torch.empty((b, m, dims[-1]), dtype=torch.float32, device=dev)
     tx, tn, ti, tc, tf = t(xyz), t(new_xyz), t(idx), t(cnt), t(feat)
-    plan, plan_bytes = N.mlp_plan_ws(b, m, ns, dev)
+    chain = 0 if dense else int(rng.integers(0, 2)) * 16
+    plan, plan_bytes = N.mlp_plan_ws(b, m, ns, dev, c, [c + 3] + dims) if chain else N.mlp_plan_ws(b, m, ns, dev)
     st = N.lib().sa_group_mlp_max(b, n, m, ns, c, tx.data_ptr(), tf.data_ptr(), tn.data_ptr(), ti.data_ptr(), tc.data_ptr(), nl,
                                   (ctypes.c_int * 4)(*([c + 3] + dims)), (ctypes.c_void_p * nl)(*[l.w.data_ptr() for l in layers]),
                                   (ctypes.c_void_p * nl)(*[l.bias.data_ptr() for l in layers]), out.data_ptr(), dims[-1], 0,
-                                  plan.data_ptr(), plan_bytes, dense | Wt.scale_flags(layers), None, N.current_stream())
+                                  plan.data_ptr(), plan_bytes, dense | chain | Wt.scale_flags(layers), None, N.current_stream())
     if st != 0:
         return "group_mlp_max(big) status %d" % st
     torch.cuda.synchronize()
