@@ -1202,6 +1202,12 @@ int sa_rowwave_try(int b, int n, int m, int ns, int c, const float *xyz, const f
                    const float *const *bias, float *out, int out_stride, int out_off, const int *plan_hdr,
                    const int *plan_gran, long max_tiles, int fp16, int *overflow, hipStream_t stream, int *st);
 
+// mlp_wide128.hip: the widest fp16 scales on 128-row items (a weight fragment feeds four MFMA tiles)
+int sa_wide128_try(int b, int n, int m, int ns, int c, const float *xyz, const float *feat, const float *new_xyz,
+                   const int *idx, const int *cnt, int nl, const int *dims, const void *const *wpack,
+                   const float *const *bias, float *out, int out_stride, int out_off, const int *plan_hdr,
+                   const int *plan_gran, long max_tiles, int fp16, int force, int *overflow, hipStream_t stream, int *st);
+
 // Upper bound of the plan length: next fit never leaves two consecutive tiles with a combined fill <= 4 granules, so
 // the list is shorter than twice the granules (+ the padding of the last tile).
 static long sa_plan_max_granules(long nballs, int ns) {
@@ -1310,6 +1316,12 @@ extern "C" int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float 
         void *scratch = (char *)ws + plan_bytes_aligned(b, m, ns);
         return sa_mlp_gemm_launch(1, b, n, m, &ns, c, xyz, feat, new_xyz, &idx, &cnt, dims, wpack, bias, out, out_stride,
                                   &out_off, &hdr_c, &gran_c, &max_tiles, &scratch, overflow, stream);
+    }
+    if (fp16 && !(flags & 8) && ((flags & 32) || (long)b * m * ns >= 4096)) {   // the widest scales on 96-row items (mlp_wide128.hip)
+        int st = SA_OK;
+        if (sa_wide128_try(b, n, m, ns, c, xyz, feat, new_xyz, idx, cnt, nl, dims, wpack, bias, out, out_stride, out_off,
+                           hdr, gran, max_tiles, 1, (flags & 32) ? 1 : 0, overflow, stream, &st))
+            return st;
     }
     {
         int st = SA_OK;

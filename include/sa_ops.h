@@ -150,6 +150,9 @@ int sa_query_ball_point_grid(int b, int n, int m, int nbands, const float *rmin,
  * nsample rows of every ball instead (A/B measurements); bit 1: the plan in ws was built by sa_group_mlp_plan;
  * bit 2: wpack[] holds single-plane fp16 fragments and the scale runs one fp16 MFMA pass per k-step (fp32
  * accumulate) instead of the three split-bf16 passes -- chosen per scale by the host (utils/weights.py).
+ * bit 3 (8): keep the 64-row / streamed fused kernels where the 96-row kernel of csrc/mlp_wide128.hip would be taken
+ * (default for the widest fp16 scales: second hidden width x last width >= 512 x 1024); bit 5 (32): take the 96-row kernel
+ * for every shape it supports (A/B measurements, tests: the results are bit-identical either way).
  * overflow (device int, may be NULL; fp16 form only): OR-ed with 1 when an input feature or a hidden activation left
  * the fp16 range (|x| > 65504) -- the result of that call is then unspecified; the word is sticky, the caller zeroes
  * and reads it (3dssd_amd/csrc/mlp_act.h).

@@ -553,7 +553,8 @@ def test_group_mlp_max_operand_precisions(gpu, oracle, c, ns, dims, m):
 
 @pytest.mark.parametrize("c,ns,dims,m,b", [(256, 16, [256, 256, 512], 300, 2), (256, 32, [256, 512, 1024], 300, 2),
                                            (256, 32, [256, 512, 1024], 257, 3), (128, 32, [128, 128, 256], 700, 2),
-                                           (128, 64, [128, 192, 256], 150, 1), (64, 48, [160, 128, 288], 211, 2)])
+                                           (128, 64, [128, 192, 256], 150, 1), (64, 48, [160, 128, 288], 211, 2),
+                                           (256, 40, [256, 384, 544], 97, 2), (8, 16, [256, 128, 512], 301, 1)])
 def test_group_mlp_gemm_chain(gpu, oracle, c, ns, dims, m, b):
     # the wide scales as three large-tile GEMM launches over packed fp16 intermediates (csrc/mlp_gemm.hip; opt-in): within the
     # fp16 bar of the fp32 oracle, and BIT-IDENTICAL to the one-launch fused kernels of the same precision (same
@@ -578,6 +579,11 @@ def test_group_mlp_gemm_chain(gpu, oracle, c, ns, dims, m, b):
     assert (got[cnt == 0] == 0).all()
     fused = _run_group_mlp(gpu, xyz, feat, new_xyz, pidx, cnt, ws, bs, precision="fp16", chain=True)            # default: fused kernels
     assert np.array_equal(got, fused)
+    # flags bit 3: the 64-row / streamed kernels instead of the 96-row kernel of csrc/mlp_wide128.hip (which the default
+    # call takes for the layer4 shapes): bit-identical as well
+    assert np.array_equal(fused, _run_group_mlp(gpu, xyz, feat, new_xyz, pidx, cnt, ws, bs, precision="fp16", flags=8))
+    # ... and bit 5 forces the 96-row kernel for every shape it supports (first hidden width 256)
+    assert np.array_equal(fused, _run_group_mlp(gpu, xyz, feat, new_xyz, pidx, cnt, ws, bs, precision="fp16", flags=32))
     # split bf16 never takes the chain (fp16 only): same call, other precision, still correct
     got3 = _run_group_mlp(gpu, xyz, feat, new_xyz, pidx, cnt, ws, bs, precision="bf16x3", chain=True, flags=16)
     assert np.abs(got3 - ref).max() / np.abs(ref).max() < 5e-5
