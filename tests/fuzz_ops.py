@@ -135,6 +135,8 @@ def case_mlp(rng):
     dims = [int(rng.choice([wide, wide, wide // 2 + 4, wide + 8])) for _ in range(nl)]
     if rng.integers(0, 3) == 0 and nl == 3:
         dims = {1: [16, 16, 32], 64: [64, 64, 128], 128: [128, 192, 256], 256: [256, 256, 512]}.get(c, dims)
+    if rng.integers(0, 6) == 0 and c >= 8:           # shapes of the 96-row kernel: first hidden width 256, ragged others
+        nl, dims = 3, [256, int(rng.choice([128, 160, 256, 384, 512])), int(rng.choice([512, 544, 1024, 800]))]
     xyz = cloud(rng, b, n)
     feat = rng.normal(0, 1, (b, n, c)).astype(np.float32) if c else None
     new_xyz = np.ascontiguousarray(xyz[:, rng.integers(0, n, m)] + rng.normal(0, 0.1, (b, m, 3)), np.float32)
@@ -152,6 +154,7 @@ def case_mlp(rng):
     tx, tn, ti, tc = t(xyz), t(new_xyz), t(idx), t(cnt)
     tf = t(feat) if c else None
     chain = int(rng.integers(0, 2)) * 16             # opt-in GEMM chain (taken only by eligible fp16 scales with the big scratch)
+    chain |= int(rng.integers(0, 2)) * 32            # force the 96-row kernel wherever it supports the shape (csrc/mlp_wide128.hip)
     plan, plan_bytes = N.mlp_plan_ws(b, m, ns, dev, c, [c + 3] + dims) if chain else N.mlp_plan_ws(b, m, ns, dev)
     ovf = torch.zeros(1, dtype=torch.int32, device=dev)
     st = N.lib().sa_group_mlp_max(b, n, m, ns, c, tx.data_ptr(), tf.data_ptr() if c else None, tn.data_ptr(), ti.data_ptr(),
