@@ -37,3 +37,18 @@ def test_world_size_must_match_gpus_flag():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--launch-check"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1 but --gpus 4" in r.stderr
+
+
+def test_bench_refuses_kernel_selection_variables_and_ablation():
+    # ablation / kernel-selection switches must not leak into a benchmark line.  bench.py exits before touching
+    # the GPU when SA_ABLATE is set (always) or when any SA_* / SA3D_* variable is set without --allow-knobs.
+    for var, extra, msg in (("SA_ABLATE", [], "SA_ABLATE is set"), ("SA_ABLATE", ["--allow-knobs"], "SA_ABLATE is set"),
+                            ("SA_MLP_WIDE", [], "refusing to measure"), ("SA3D_LIB", [], "refusing to measure")):
+        env = dict(os.environ)
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        env[var] = "1"
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"] + extra,
+                           capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode != 0 and msg in (r.stderr + r.stdout), (var, extra, r.stderr[-500:])
+        assert not [l for l in r.stdout.splitlines() if l.startswith("{")]          # no line was printed
