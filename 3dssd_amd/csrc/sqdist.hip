@@ -266,6 +266,9 @@ __device__ __forceinline__ void sq_store_tile(float *lds, const float *sA, const
 #pragma unroll
             for (int r = 0; r < 16; ++r) vv[tj][r] = (sa[r] + sb) - 2.0f * acc[ti][tj][r];
         }
+#ifdef SA_SQ_NOSTORE
+        if (vv[0][0] != 12345.678f) continue;
+#endif
         if (full) {
             // ---- direct tile: patch[ir][tj*32 + col], read back as float4 rows
 #pragma unroll
@@ -274,14 +277,22 @@ __device__ __forceinline__ void sq_store_tile(float *lds, const float *sA, const
                 for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * half) * 68 + tj * 32 + col] = vv[tj][r];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
+#ifdef SA_SQ_NODIRECT
+            for (int it = 0; it < (vv[0][0] == 12345.678f ? 8 : 0); ++it) {
+#else
             for (int it = 0; it < 8; ++it) {
+#endif
                 const int pr = it * 4 + (lane >> 4), pc = (lane & 15) * 4;       // 4 rows x 16 lanes x 16 B
                 const float4 q4 = *(const float4 *)(patch + pr * 68 + pc);
                 f32x4v *dst = (f32x4v *)(tile + (unsigned)((wr * 64 + ti * 32 + pr) * m + wc * 64 + pc));
                 const f32x4v qv = {q4.x, q4.y, q4.z, q4.w};
                 if (NT) __builtin_nontemporal_store(qv, dst); else *dst = qv;
             }
+#ifdef SA_SQ_NOMIRROR
+            if (mirror && vv[0][0] == 12345.678f) {
+#else
             if (mirror) {
+#endif
                 // ---- mirrored tile: patch viewed as [64 columns j][34]: patchT[tj*32 + col][ir]
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -578,6 +589,16 @@ __global__ __launch_bounds__(256, 4) void sqdist_mfma3_kernel(int n, int m, int 
     const int wr = w >> 1, wc = w & 1;
     const int half = lane >> 5, col = lane & 31;
     const int S = (c + kKS2 - 1) / kKS2, Ta = npa / kMT, Tb = npb / kMT;
+#ifdef SA_SQ_STAGGER
+    {   // experiment: the workgroups of the first resident round start a fraction of a tile period apart
+        const unsigned L = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        if (L < (unsigned)SA_SQ_STAGGER_WGS) {
+            const unsigned ph = SA_SQ_STAGGER == 1 ? (L >> 8) & 3u : (SA_SQ_STAGGER == 2 ? (L * 2654435761u) >> 30 : (SA_SQ_STAGGER == 4 ? (L >> 8) & 1u : (SA_SQ_STAGGER == 5 ? (L >> 9) & 1u : (L >> 3) & 3u)));
+            const unsigned long long t0 = wall_clock64();
+            while (wall_clock64() - t0 < (unsigned long long)ph * SA_SQ_STAGGER_TICKS) __builtin_amdgcn_s_sleep(16);
+        }
+    }
+#endif
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -598,7 +619,11 @@ __global__ __launch_bounds__(256, 4) void sqdist_mfma3_kernel(int n, int m, int 
     for (int i = 0; i < kCp; ++i) { ra[i] = srcA[i * 256]; rb[i] = srcB[i * 256]; }
     f32x4v *dA = (f32x4v *)&s_pl[0][0][0][0] + tid, *dB = (f32x4v *)&s_pl[1][0][0][0] + tid;
 
+    #ifdef SA_SQ_NOMFMA
+    for (int st = 0; st < 0; ++st) {
+#else
     for (int st = 0; st < S; ++st) {
+#endif
         const int cnt = min(kKS2, c - st * kKS2);
         const int npairs = (cnt + 1) >> 1;
         if (st > 0) __syncthreads();                       // the previous stage is fully consumed
@@ -740,7 +765,11 @@ static int sqdist_split_ws_impl(int b, int n, int m, int c0, int c1, const float
         hipLaunchKernelGGL(sqdist_pack_kernel, dim3(npb / kMT, b), dim3(2 * kMT), pack_lds, stream, m, npb, S, ldc, Bm, packB, normB);
         SA_CHECK_LAUNCH();
     }
+#ifdef SA_SQ_NONT
+    const bool nt = false;
+#else
     const bool nt = (size_t)b * n * m * sizeof(float) > ((size_t)192 << 20);
+#endif
     if (sym) {
         const int T = npa / kMT;
         dim3 grid(T * (T + 1) / 2, 1, b);

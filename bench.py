@@ -453,6 +453,7 @@ def mlp_row_stats(net, batches):
             fl_eval += 2.0 * h[0] * 8 * macs
     k = max(len(batches), 1)
     return dict(nominal=nominal // k, distinct=distinct // k, evaluated=evaluated // k,
+                frames=int(batches[0].shape[0]) if len(batches) else 0,
                 evaluated_frac=round(evaluated / max(nominal, 1), 4), batches_sampled=len(batches),
                 gflop_nominal=round(fl_nom / 1e9 / k, 3), gflop_evaluated=round(fl_eval / 1e9 / k, 3))
 
@@ -473,18 +474,22 @@ def verify_pipeline(pipe, batches, nverify):
         eager.append((xl[-1].clone(), fl[-1].clone()))
     torch.cuda.synchronize()
     equal, first = True, None
-    for r0 in range(0, nverify, pipe.nslots):
-        tickets = [(i, pipe.submit(batches[i], sync_source=False)) for i in range(r0, min(r0 + pipe.nslots, nverify))]
+    per_round = pipe.nslots * pipe.coalesce                     # every slot full: that many batches in flight
+    for r0 in range(0, nverify, per_round):
+        tickets = [(i, pipe.submit(batches[i], sync_source=False)) for i in range(r0, min(r0 + per_round, nverify))]
+        pipe.flush()
         for i, t in tickets:
             x, f = t.result()
             ok = torch.equal(x, eager[i][0]) and torch.equal(f, eager[i][1])
             equal = equal and ok
             if first is None:
                 first = (_sha1(f), _sha1(eager[i][1]))
-    return {"batches": nverify, "slots_in_flight": min(pipe.nslots, nverify), "all_equal_eager": bool(equal),
+    return {"batches": nverify, "slots_in_flight": min(pipe.nslots, -(-nverify // pipe.coalesce)),
+            "batches_per_replay": pipe.coalesce, "all_equal_eager": bool(equal),
             "output_sha1_replay": first[0], "output_sha1_eager": first[1],
-            "note": "sha1 of the [B,256,512] feature output of pool batch 0: through the pipeline (graph replay, all "
-                    "slots busy with other batches) and eager on one stream"}
+            "note": "every batch through the pipeline (graph replay over batches_per_replay batches at once, all slots "
+                    "busy with other batches) against the eager result of THAT batch alone on one stream; sha1 of the "
+                    "[B,256,512] feature output of pool batch 0 both ways"}
 
 
 def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
@@ -494,7 +499,8 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
     use_graphs = bool(args.graphs) and graphs_ok
     pipe = pkg("pipeline").SAPipeline(arch, params, dev, batch=args.batch, points=points, channels=4,
                                       streams=max(1, args.streams), graphs=use_graphs,
-                                      max_translate_range=cfgs.KITTI_MAX_TRANSLATE_RANGE)
+                                      max_translate_range=cfgs.KITTI_MAX_TRANSLATE_RANGE, coalesce=max(1, args.coalesce))
+    C = pipe.coalesce
     net = pipe.net
     # this rank's frame pool: global frame f -> rank f mod world (weak scaling: `batch` frames per GPU per step);
     # `pool` distinct frames per GPU, resident; step i takes pool batch i mod nb
@@ -506,16 +512,21 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
     cursor = [0]
 
     def run(k, marks=None):
+        # k steps = k batches; a slot is launched by the submit that fills it (`coalesce` batches), the last, partly
+        # filled one by flush().  marks: a HIP event before the first copy and after the launch of every replay
         tickets = []
-        for _ in range(k):
+        s_ev = st = None
+        for i in range(k):
             pts = batches[cursor[0] % nb]
             cursor[0] += 1
-            if marks is not None:
+            if marks is not None and pipe._fill == 0:
                 st = pipe.slots[pipe._next].stream
                 s_ev = torch.cuda.Event(enable_timing=True)
                 s_ev.record(st)
             tickets.append(pipe.submit(pts, sync_source=False))
-            if marks is not None:
+            if i == k - 1:
+                pipe.flush()
+            if marks is not None and pipe._fill == 0:
                 e_ev = torch.cuda.Event(enable_timing=True)
                 e_ev.record(st)
                 marks.append((s_ev, e_ev))
@@ -530,15 +541,18 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
     t1 = time.perf_counter()
     for i in range(3):
         pipe.run_alone(batches[i % nb])
-    latency_ms = (time.perf_counter() - t1) / 3 * 1e3
+    latency_ms = (time.perf_counter() - t1) / 3 * 1e3          # one replay (batch x coalesce frames) alone on the device
     verify = verify_pipeline(pipe, batches, args.verify)
     if verify is not None and not verify["all_equal_eager"]:
         sys.exit("bench.py: a pipeline output differs from the eager result of the same batch -- refusing to report")
     if rank != 0:
         return None
     clock_mhz = MAX_CLOCK_MHZ
-    stages = profile_stages(lambda: net(batches[0]), args.profile_iters)
-    rows = mlp_row_stats(net, batches[:min(nb, 4)])
+    # the calls as the pipeline issues them: one replay = `coalesce` batches in one pass
+    launch = [torch.cat([batches[(i * C + j) % nb] for j in range(C)]) for i in range(min(max(nb // C, 1), 4))]
+    stages = profile_stages(lambda: net(launch[0]), args.profile_iters)
+    rows = mlp_row_stats(net, launch)
+    fpl = args.batch * C                                        # frames per launch
     ms_step = t_max / args.steps * 1e3
     window_ms = t_max * 1e3
     line = {
@@ -556,15 +570,21 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
                                % (tag, points, args.batch),
                    "frames_per_step_per_gpu": args.batch, "streams": pipe.nslots, "data": args.data,
                    "pool_frames_per_gpu": nb * args.batch,
-                   "executor": "3dssd_amd.pipeline.SAPipeline: per-slot static input buffer, one block copy + one "
-                               "hipGraph replay per step" if use_graphs else
-                               "3dssd_amd.pipeline.SAPipeline, eager launches on the slots' streams",
+                   "batches_per_replay": C, "frames_per_launch": fpl,
+                   "executor": ("3dssd_amd.pipeline.SAPipeline: per-slot static input buffer, one block copy per step, "
+                                "one hipGraph replay per %d step(s) (coalesce=%d: a slot takes %d consecutive batches of "
+                                "%d frames and runs the backbone over all of them in one pass)" % (C, C, C, args.batch))
+                               if use_graphs else
+                               "3dssd_amd.pipeline.SAPipeline, eager launches on the slots' streams (coalesce=%d)" % C,
                    "sharding": "frame f -> rank f mod N, no data-path collective"},
         "timed_window_ms": round(window_ms, 3),
         "single_stream_batch_latency_ms": round(latency_ms, 3),
+        "latency_note": "one batch submitted alone and waited for: its slot is launched at once, i.e. one pass over "
+                        "frames_per_launch frames (the other parts of the slot hold stale frames)",
         "ramp_dominated": bool(window_ms < 20.0 * latency_ms),
-        "ramp_note": "a run shorter than ~20 single-batch latencies mostly measures filling and draining the %d slots "
-                     "(every chain starts with the ~3 ms layer-1 D-FPS); the steady-state rate needs --steps >= 100" % pipe.nslots,
+        "ramp_note": "a run shorter than ~20 single-replay latencies mostly measures filling and draining the %d slots "
+                     "(every chain starts with the ~3 ms layer-1 D-FPS); the steady-state rate needs --steps >= %d"
+                     % (pipe.nslots, 100 * C),
         "host_issue_ms_per_step": round(host_issue_ms, 3),
         "hip_graphs": use_graphs,
         "env_knobs": env_knobs()[0],
@@ -590,14 +610,15 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
         evaluated = None
         if dom["kernel"] in ("sa_fps_ex", "sa_fps_ex2") and " c=3" in dom["label"]:
             m1 = int(dom["label"].split("->")[1].split()[0])
-            evaluated = fps_bucket_evaluated(batches[0][:, :, :3].contiguous(), m1)
-        line["roofline"] = roofline_of(dom, args.batch, clock_mhz, evaluated)
+            evaluated = fps_bucket_evaluated(launch[0][:, :, :3].contiguous(), m1)
+        line["roofline"] = roofline_of(dom, fpl, clock_mhz, evaluated)
         line["whole_step"] = {
             "mlp_gflop_algorithmic": round(gflop_step, 2),
-            "mfma_tflops": round(gflop_step / ms_step, 2), "mfma_frac_of_bf16_peak": round(gflop_step / ms_step / MFMA_BF16_PEAK_TF, 5),
-            "algorithmic_mbytes": round(mb_step, 2), "hbm_gbs": round(mb_step / ms_step, 2),
-            "hbm_frac": round(mb_step / ms_step / HBM_PEAK_GBS, 5),
-            "note": "algorithmic work of one step (SURVEY 8d) / ms_per_step of the overlapped multi-stream run"}
+            "mfma_tflops": round(gflop_step / (ms_step * C), 2), "mfma_frac_of_bf16_peak": round(gflop_step / (ms_step * C) / MFMA_BF16_PEAK_TF, 5),
+            "algorithmic_mbytes": round(mb_step, 2), "hbm_gbs": round(mb_step / (ms_step * C), 2),
+            "hbm_frac": round(mb_step / (ms_step * C) / HBM_PEAK_GBS, 5),
+            "note": "algorithmic work of one replay = %d step(s) (SURVEY 8d) / (%d x ms_per_step) of the overlapped "
+                    "multi-stream run" % (C, C)}
         ev_tf = rows["gflop_evaluated"] / mlp_ms if mlp_ms else 0.0
         line["roofline_grouped_mlp"] = {
             "bound": "mfma", "achieved": round(ev_tf, 3), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
@@ -618,6 +639,9 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
                                            "the grid ball query moves 19 MB per launch and is latency-bound, not "
                                            "bandwidth-bound"}
         line["stages"] = stages
+        line["stages_note"] = ("stages, mlp_rows_per_step and the roofline objects describe the calls as the pipeline issues "
+                               "them: ONE pass over frames_per_launch = %d frames (%d step(s)); calls_per_step counts calls per "
+                               "such pass" % (fpl, C))
     if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only (the contract)
         line["cpu_baseline"] = cpu_baseline(arch, params, min(args.batch, 8), points, args.data)
     return line
@@ -756,6 +780,7 @@ def main():
     ap.add_argument("--points", type=int, default=None)
     ap.add_argument("--pool", type=int, default=None, help="distinct frames per GPU the steps cycle through")
     ap.add_argument("--streams", type=int, default=None, help="pipeline slots (HIP streams) the steps are issued on")
+    ap.add_argument("--coalesce", type=int, default=None, help="batches a pipeline slot takes before it is launched (frames per replay = batch x coalesce)")
     ap.add_argument("--verify", type=int, default=None, help="batches re-run through the pipeline and compared with eager (0: skip)")
     ap.add_argument("--profile-iters", type=int, default=3)
     ap.add_argument("--graphs", type=int, default=1, help="1 (default): one captured hipGraph per slot; 0: eager launches")
@@ -766,10 +791,10 @@ def main():
     ap.add_argument("--launch-check", action="store_true", help="exercise only the launch path (works without a GPU)")
     args = ap.parse_args()
     assert args.gpus >= 1
-    defaults = {"configs1": dict(steps=128, warmup=24, batch=8, points=16384, streams=16, pool=160, verify=32),
-                "configs2": dict(steps=4, warmup=1, batch=32, points=16384, streams=1, pool=32, verify=0),
-                "configs4": dict(steps=16, warmup=4, batch=16, points=65536, streams=4, pool=96, verify=8),
-                "group": dict(steps=20, warmup=5, batch=8, points=16384, streams=1, pool=8, verify=0)}[args.workload]
+    defaults = {"configs1": dict(steps=512, warmup=64, batch=8, points=16384, streams=16, pool=256, verify=64, coalesce=4),
+                "configs2": dict(steps=4, warmup=1, batch=32, points=16384, streams=1, pool=32, verify=0, coalesce=1),
+                "configs4": dict(steps=16, warmup=4, batch=16, points=65536, streams=4, pool=96, verify=8, coalesce=1),
+                "group": dict(steps=20, warmup=5, batch=8, points=16384, streams=1, pool=8, verify=0, coalesce=1)}[args.workload]
     for k, v in defaults.items():
         if getattr(args, k) is None:
             setattr(args, k, v)

@@ -93,3 +93,46 @@ def test_eager_pipeline_mode_for_uncapturable_frames(gpu):
     tickets = [pipe.submit(t, out=o) for t, o in zip(dev, outs)]
     for i, tk in enumerate(tickets):
         assert torch.equal(tk.result()[1], eager[i])
+
+
+def test_coalescing_slots_give_every_batch_its_own_eager_result(gpu):
+    # coalesce=3: a slot takes three consecutive batches and runs the backbone over all six frames in one pass.  Frames
+    # never interact, so every batch must come out exactly as it does alone (eager, its own two frames) -- whichever
+    # batches it shared a replay with, and also from a slot that was launched only partly filled.
+    cfgs, syn = pkg("configs"), pkg("synthetic")
+    arch = cfgs.KITTI_3DSSD_ARCH
+    pipe = pkg("pipeline").SAPipeline(arch, syn.random_backbone_params(arch), gpu, batch=2, points=16384, streams=3,
+                                      coalesce=3, max_translate_range=cfgs.KITTI_MAX_TRANSLATE_RANGE)
+    dev = [torch.from_numpy(h).to(gpu) for h in _batches("default", 20, 2, first=700)]
+    eager = []
+    for t in dev:
+        xl, fl, il = pipe.forward_eager(t)
+        eager.append((xl[-1].clone(), fl[-1].clone(), [None if v is None else v.clone() for v in il]))
+    torch.cuda.synchronize()
+    # 20 batches = 6 full replays + one slot holding 2 of 3: result() launches it
+    tickets = [pipe.submit(t) for t in dev[:9]]
+    assert all(tk.done() or True for tk in tickets)
+    for i, tk in enumerate(tickets):
+        x, f = tk.result()
+        assert x.shape == (2, 256, 3) and f.shape == (2, 256, 512)
+        assert torch.equal(x, eager[i][0]) and torch.equal(f, eager[i][1]), "batch %d" % i
+    outs = [(torch.empty_like(e[0]), torch.empty_like(e[1])) for e in eager]
+    tickets = [pipe.submit(t, out=o) for t, o in zip(dev, outs)]
+    assert not tickets[-1].done()                    # batches 18, 19 sit in a slot that still waits for a third
+    x, f = tickets[-1].result()                      # ... and is launched by the first result() on it
+    assert torch.equal(f, eager[19][1])
+    for i, tk in enumerate(tickets):
+        x, f = tk.result()
+        assert torch.equal(x, eager[i][0]) and torch.equal(f, eager[i][1]), "batch %d (out=)" % i
+    # per-batch views of every list the backbone returns
+    tk = pipe.submit(dev[5])
+    xl, fl, il = tk.all_outputs()
+    assert torch.equal(fl[-1], eager[5][1]) and xl[1].shape[0] == 2
+    for a, b in zip(il, eager[5][2]):
+        assert (a is None and b is None) or torch.equal(a, b)
+    # a stale ticket refuses: its slot has started a later round
+    later = [pipe.submit(t) for t in dev[:9]]
+    with pytest.raises(RuntimeError, match="reused"):
+        tk.result()
+    pipe.drain()
+    assert torch.equal(later[8].result()[1], eager[8][1])
