@@ -1047,15 +1047,20 @@ __device__ __forceinline__ PlanFn plan_wave_scan(PlanFn incl, int lane) {
 }
 
 // A scale's balls are cut into chunks of 4096; workgroup (chunk, scale) packs ITS chunk.  The packing state in front of
-// the chunk (granules placed so far, fill of the open tile) is a function of all earlier balls: every workgroup
-// recomputes it with one summary pass over them -- a thread folds a contiguous run of balls into a phase -> (phase,
-// advance) function, a wave scan and a 8-entry serial composition give the total -- instead of waiting for its
-// predecessors (no atomics, no flags to reset between calls, the same plan on every run).  Until round 3 one workgroup
-// per scale walked its chunks one after the other: 61 us for layer1's 3 x 32 768 balls on three workgroups.
+// the chunk (granules placed so far, fill of the open tile) is a function of all earlier balls.  Two launches, no
+// atomics, no flags to reset between calls, the same plan on every run:
+//   mlp_plan_summary_kernel   workgroup (chunk, scale) folds its 4096 balls into ONE phase -> (phase, advance) function
+//                             (+ distinct rows, split balls) and stores the six words in the scale's scratch;
+//   mlp_plan_kernel           composes the summaries of the chunks in front of it (a thread folds a run of them, a
+//                             wave scan and an 8-entry serial composition give the total) and packs its chunk.
+// History: until round 3 one workgroup per scale walked its chunks one after the other (61 us for layer1's 3 x 32 768
+// balls); then every workgroup re-folded all BALLS in front of it -- quadratic, 22 us per call at 8 frames but 50 us at
+// the 32 frames of a coalesced replay (pipeline.py), 0.2 ms of plans per replay.
 constexpr int kPlanMaxScales = 4;
+constexpr int kPlanSumInts = 8;      // per chunk: t[0..3] (advance << 2 | end phase for start phase p), rows, split balls
 struct PlanJob {
     const int *cnt;
-    int *hdr, *gran;
+    int *hdr, *gran, *sum;
     int ns, out_off, N;
 };
 struct PlanJobs {
@@ -1063,6 +1068,59 @@ struct PlanJobs {
     int nballs, dense, out_stride;
     float *out;
 };
+
+// this thread's 8 balls of the chunk: granules, distinct rows, and their fold for the four start phases
+__device__ __forceinline__ PlanFn plan_fold_thread(const PlanJob &job, int ball0, int nballs, int dense,
+                                                   int (&g)[kPlanBallsPerThread], int &rows, int &nsp) {
+#pragma unroll
+    for (int k = 0; k < kPlanBallsPerThread; ++k) {
+        g[k] = plan_granules_of(job.cnt, ball0 + k, nballs, job.ns, dense, rows);
+        nsp += g[k] > 4;
+    }
+    PlanFn f;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        int ph = p, adv = 0;
+#pragma unroll
+        for (int k = 0; k < kPlanBallsPerThread; ++k)
+            if (g[k] > 0) { adv += plan_place(g[k], ph); adv += g[k]; }
+        f.t[p] = (adv << 2) | ph;
+    }
+    return f;
+}
+
+__global__ __launch_bounds__(kPlanThreads) void mlp_plan_summary_kernel(PlanJobs J) {
+    constexpr int NWV = kPlanThreads / 64;
+    __shared__ int wfn[NWV][4];
+    __shared__ int wsum[NWV][2];
+    const PlanJob job = J.j[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int chunk0 = blockIdx.x * kPlanChunk;
+    if (chunk0 + kPlanChunk >= J.nballs) return;              // nobody reads the last chunk's summary
+    int g[kPlanBallsPerThread], rows = 0, nsp = 0;
+    const PlanFn f = plan_fold_thread(job, chunk0 + tid * kPlanBallsPerThread, J.nballs, J.dense, g, rows, nsp);
+    const PlanFn incl = plan_wave_scan(f, lane);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { rows += __shfl_xor(rows, d); nsp += __shfl_xor(nsp, d); }
+    if (lane == 63) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) wfn[w][p] = incl.t[p];
+    }
+    if (lane == 0) { wsum[w][0] = rows; wsum[w][1] = nsp; }
+    __syncthreads();
+    if (tid < 4) {                                           // thread p: the chunk's function at start phase p
+        int st = tid, r = 0, n = 0;
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            const int y = wfn[i][st & 3];
+            st = (((st >> 2) + (y >> 2)) << 2) | (y & 3);
+            r += wsum[i][0]; n += wsum[i][1];
+        }
+        int *o = job.sum + (size_t)blockIdx.x * kPlanSumInts;
+        o[tid] = st - 0;                                     // advance << 2 | end phase (the start phase's 2 bits carry no advance)
+        if (tid == 0) { o[4] = r; o[5] = n; }
+    }
+}
 
 __global__ __launch_bounds__(kPlanThreads) void mlp_plan_kernel(PlanJobs J) {
     constexpr int NWV = kPlanThreads / 64;
@@ -1072,38 +1130,31 @@ __global__ __launch_bounds__(kPlanThreads) void mlp_plan_kernel(PlanJobs J) {
     __shared__ int split_ball[kPlanChunk];
     const PlanJob job = J.j[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int nballs = J.nballs, ns = job.ns;
+    const int nballs = J.nballs;
     const int chunk0 = blockIdx.x * kPlanChunk;
     if (chunk0 >= nballs) return;
     const bool last_chunk = chunk0 + kPlanChunk >= nballs;
     if (tid == 0) nsplit_s = 0;
 
-    // ---- summary of the balls in front of this chunk: packing state `base`, distinct rows and split balls so far
+    // ---- the chunks in front of this one: packing state `base`, distinct rows and split balls so far, from their
+    //      summaries (mlp_plan_summary_kernel, earlier on the stream)
     int base = 0, rows_before = 0, nsplit_before = 0;
-    if (chunk0 > 0) {
-        const int per = (chunk0 + kPlanThreads - 1) / kPlanThreads;
-        const int b0 = tid * per, b1 = min(b0 + per, chunk0);
+    if (blockIdx.x > 0) {
+        const int nprev = blockIdx.x;
+        const int per = (nprev + kPlanThreads - 1) / kPlanThreads;
+        const int c0 = tid * per, c1 = min(c0 + per, nprev);
         PlanFn f;
         int rows = 0, nsp = 0;
 #pragma unroll
         for (int p = 0; p < 4; ++p) f.t[p] = p;
-        for (int ball = b0; ball < b1; ball += 8) {     // 8 counts requested together, then folded (a load per ball in the
-            int g8[8];                                  // fold loop waited ~400 cycles for each of the up to 56 balls)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) g8[k] = ball + k < b1 ? plan_granules_of(job.cnt, ball + k, nballs, ns, J.dense, rows) : 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int g = g8[k];
-                nsp += g > 4;
-                if (g > 0) {
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) {
-                        int ph = f.t[p] & 3, adv = f.t[p] >> 2;
-                        adv += plan_place(g, ph) + g;
-                        f.t[p] = (adv << 2) | ph;
-                    }
-                }
-            }
+        for (int c = c0; c < c1; ++c) {
+            const int *o = job.sum + (size_t)c * kPlanSumInts;
+            const int4 t4 = *(const int4 *)o;
+            const int2 r2 = *(const int2 *)(o + 4);
+            PlanFn h;
+            h.t[0] = t4.x; h.t[1] = t4.y; h.t[2] = t4.z; h.t[3] = t4.w;
+            f = plan_fn_compose(f, h);
+            rows += r2.x; nsp += r2.y;
         }
         const PlanFn incl = plan_wave_scan(f, lane);
 #pragma unroll
@@ -1126,18 +1177,8 @@ __global__ __launch_bounds__(kPlanThreads) void mlp_plan_kernel(PlanJobs J) {
 
     // ---- this chunk
     const int ball0 = chunk0 + tid * kPlanBallsPerThread;
-    int g[kPlanBallsPerThread], rows = 0;
-#pragma unroll
-    for (int k = 0; k < kPlanBallsPerThread; ++k) g[k] = plan_granules_of(job.cnt, ball0 + k, nballs, ns, J.dense, rows);
-    PlanFn f;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        int ph = p, adv = 0;
-#pragma unroll
-        for (int k = 0; k < kPlanBallsPerThread; ++k)
-            if (g[k] > 0) { adv += plan_place(g[k], ph); adv += g[k]; }
-        f.t[p] = (adv << 2) | ph;
-    }
+    int g[kPlanBallsPerThread], rows = 0, nsp_unused = 0;
+    const PlanFn f = plan_fold_thread(job, ball0, nballs, J.dense, g, rows, nsp_unused);
     const PlanFn incl = plan_wave_scan(f, lane);
     int rsum = rows;
 #pragma unroll
@@ -1215,11 +1256,24 @@ static long sa_plan_max_granules(long nballs, int ns) {
     return (ns <= 8 ? g : 2 * g) + 8;
 }
 
+// ints in front of the chunk summaries of a scale's scratch: header + one int per granule of the densest plan, 16-byte
+// aligned
+static size_t sa_plan_sum_offset_ints(long nballs, int ns) {
+    return ((size_t)sa::kPlanHeaderInts + (size_t)sa_plan_max_granules(nballs, ns) + 8 + 3) & ~(size_t)3;
+}
 // Bytes of caller-owned scratch sa_group_mlp_max needs for the row plan of one scale (header + one int per granule
-// of the densest plan).
+// of the densest plan + the summaries of its 4096-ball chunks).
 extern "C" size_t sa_group_mlp_max_ws_bytes(int b, int m, int ns) {
     if (b <= 0 || m <= 0 || ns <= 0) return 0;
-    return (size_t)sa::kPlanHeaderInts * sizeof(int) + ((size_t)sa_plan_max_granules((long)b * m, ns) + 8) * sizeof(int);
+    const long nballs = (long)b * m;
+    const size_t chunks = (size_t)((nballs + kPlanChunk - 1) / kPlanChunk);
+    return (sa_plan_sum_offset_ints(nballs, ns) + chunks * kPlanSumInts) * sizeof(int);
+}
+// the two launches of a layer's (or a scale's) row plans
+static void launch_plan(const PlanJobs &J, int nscale, hipStream_t stream) {
+    const unsigned chunks = (unsigned)((J.nballs + kPlanChunk - 1) / kPlanChunk);
+    if (chunks > 1) hipLaunchKernelGGL(mlp_plan_summary_kernel, dim3(chunks - 1, nscale), dim3(kPlanThreads), 0, stream, J);
+    hipLaunchKernelGGL(mlp_plan_kernel, dim3(chunks, nscale), dim3(kPlanThreads), 0, stream, J);
 }
 
 // mlp_gemm.hip: the wide scales as a chain of three large-tile GEMMs over packed fp16 intermediates
@@ -1251,7 +1305,7 @@ static bool use_gemm_chain(int b, int m, int ns, int c, int nl, const int *dims,
     return ws_bytes >= sa_group_mlp_gemm_ws_bytes(b, m, ns, c, nl, dims);
 }
 
-// Row plans of ALL scales of an SA layer in one launch (one workgroup per scale).  cnt[i]: pts_cnt of scale i
+// Row plans of ALL scales of an SA layer (two launches: chunk summaries, then the packing; workgroups = chunks x scales).  cnt[i]: pts_cnt of scale i
 // [b, m]; ws[i]: scratch of sa_group_mlp_max_ws_bytes(b, m, ns[i]) bytes; out / out_stride / out_off[i] / nout[i]:
 // where scale i's pooled channels go (rows of balls with more than 32 distinct rows are zeroed here).  The
 // sa_group_mlp_max calls of the layer then pass the same ws[i] and flags | 2.
@@ -1267,10 +1321,11 @@ extern "C" int sa_group_mlp_plan(int b, int m, int nscale, const int *ns, const 
         if (ns[i] <= 0 || !cnt[i] || !ws[i] || nout[i] <= 0) return SA_ERR_INVALID;
         if (ns[i] > 8 * sa::kPlanMaxOrd) return SA_ERR_UNSUPPORTED;
         J.j[i].cnt = cnt[i]; J.j[i].hdr = (int *)ws[i]; J.j[i].gran = (int *)ws[i] + sa::kPlanHeaderInts;
+        J.j[i].sum = (int *)ws[i] + sa_plan_sum_offset_ints(nballs, ns[i]);
         J.j[i].ns = ns[i]; J.j[i].out_off = out_off[i]; J.j[i].N = nout[i];
     }
     J.nballs = (int)nballs; J.dense = flags & 1; J.out_stride = out_stride; J.out = out;
-    hipLaunchKernelGGL(mlp_plan_kernel, dim3((unsigned)((nballs + kPlanChunk - 1) / kPlanChunk), nscale), dim3(kPlanThreads), 0, stream, J);
+    launch_plan(J, nscale, stream);
     SA_CHECK_LAUNCH();
     return SA_OK;
 }
@@ -1306,8 +1361,9 @@ extern "C" int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float 
     if (!(flags & 2)) {
         PlanJobs J{};
         J.j[0].cnt = cnt; J.j[0].hdr = hdr; J.j[0].gran = gran; J.j[0].ns = ns; J.j[0].out_off = out_off; J.j[0].N = dims[nl];
+        J.j[0].sum = hdr + sa_plan_sum_offset_ints(nballs, ns);
         J.nballs = (int)nballs; J.dense = flags & 1; J.out_stride = out_stride; J.out = out;
-        hipLaunchKernelGGL(mlp_plan_kernel, dim3((unsigned)((nballs + kPlanChunk - 1) / kPlanChunk), 1), dim3(kPlanThreads), 0, stream, J);
+        launch_plan(J, 1, stream);
         SA_CHECK_LAUNCH();
     }
     const bool fp16 = (flags & 4) != 0;

@@ -38,7 +38,10 @@ class SkipProxy:
         return wrapped if name.startswith("sa_") and not name.endswith("_ws_bytes") else fn
 
 
-def run(skip, steps=128, warmup=24):
+COALESCE = int(os.environ.get("ABLATE_COALESCE", "4"))
+
+
+def run(skip, steps=512, warmup=64):
     native = pkg("utils._native")
     real = native.lib()
     native._LIB = SkipProxy(real, set(skip))
@@ -46,7 +49,7 @@ def run(skip, steps=128, warmup=24):
         cfgs, syn = pkg("configs"), pkg("synthetic")
         arch = cfgs.KITTI_3DSSD_ARCH
         pipe = pkg("pipeline").SAPipeline(arch, syn.random_backbone_params(arch), "cuda:0", batch=8, points=16384, streams=16,
-                                          check_overflow=False)
+                                          check_overflow=False, coalesce=COALESCE)
     finally:
         native._LIB = real            # the graphs are captured: replays no longer go through ctypes
     batches = [torch.from_numpy(syn.kitti_like_batch(8, first_frame=8 * i)).cuda() for i in range(20)]
@@ -62,7 +65,7 @@ def run(skip, steps=128, warmup=24):
 
 
 if __name__ == "__main__":
-    allmlp = ["mlp:layer1", "mlp:layer2", "mlp:layer3", "mlp:layer4"]
-    for skip in ([], ["mlp:layer4"], ["mlp:layer3"], ["mlp:layer2"], ["mlp:layer1"], ["dense"], ["sqdist"], allmlp,
-                 allmlp + ["dense", "sqdist", "plan"]):
+    # one process per configuration (a pipeline's graphs keep their memory pools): argv = comma-separated classes, or "none"
+    for a in sys.argv[1:] or ["none"]:
+        skip = [] if a == "none" else a.split(",")
         print("%-70s ms/step %.4f" % (",".join(skip) or "none", run(skip)), flush=True)
