@@ -393,11 +393,15 @@ __global__ __launch_bounds__(NW * 64, WPE) void mlp_rw_kernel(RwParams P) {
 // wave of the SIMD fills the gaps; that halves the register budget (256), hence one accumulator chain and the
 // next tile's loads issued after the tile instead of under its last layer.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector: plain loads / stores, no memcpy
+#ifndef SA_RS_LA
+#define SA_RS_LA 4
+#endif
+constexpr int kRsLA16 = SA_RS_LA;     // fp16 form: weight fragments requested from LDS ahead of the MFMA that uses them
 struct RsCtx {
     uint4 *ring;          // 2 slots x PC x 64 uint4
     int w, lane;
     int abase;            // uint4 index of this lane's fragment slot in the current chunk
-    u32x4 qh[4], ql[4];   // weight fragments (hi, lo plane) of the next LA k-step tiles, already requested from LDS
+    u32x4 qh[kRsLA16 > 4 ? kRsLA16 : 4], ql[kRsLA16 > 4 ? kRsLA16 : 4];   // weight fragments (hi, lo plane) of the next LA k-step tiles, already requested from LDS
 };
 
 // The stream of a pass is cut into CPP chunks of G = TOT/CPP k-step tiles (PC = NP*G pieces of 1 KiB, NP = planes per
@@ -447,7 +451,7 @@ __device__ __forceinline__ void rs_tile_mma(const RwParams &P, RsCtx &X, u32x4 (
                                             const uint4 (&ih)[KS], const uint4 (&il)[KS], int base,
                                             f32x16 &acc) {
     constexpr int NP = PR == 3 ? 2 : 1;
-    constexpr int LA = PR == 3 ? 1 : 4;
+    constexpr int LA = PR == 3 ? 1 : kRsLA16;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         const int p = base + ks, pc = p % G;
@@ -839,7 +843,15 @@ int sa_rowwave_try(int b, int n, int m, int ns, int c, const float *xyz, const f
     SA_RS(9, 4, 8, 4, 8, 8, 8, 2, 1, 2, 1, 12, 1)       // layer3 scale 0
     SA_RS(9, 4, 8, 6, 12, 8, 8, 2, 1, 2, 1, 12, 1)      // layer3 scale 1
     SA_RS(9, 4, 8, 8, 16, 8, 8, 2, 1, 2, 1, 12, 1)      // layer3 scale 2
-    SA_RS(17, 8, 16, 8, 16, 16, 4, 1, 1, 2, 1, 26, 0)   // 259 -> 256 -> 256 -> 512   (layer4 scale 0): 520 tiles, 20 per chunk
+    // 259 -> 256 -> 256 -> 512 (layer4 scale 0): 520 tiles, 20 per chunk.  Up to one tile per wave of the 4-wave form
+    // (1024 tiles on 256 CUs: batch 8) four waves of 512 registers; from two tiles per wave on, eight waves of 256
+    // registers (two per SIMD: one wave's gather / conversions / barrier waits run under the other's MFMAs -- the
+    // single wave of a SIMD spends 2.5-3x the MFMA time in its layers, tools/rw_phase_prof.py): 125 / 237 / 455 us for the
+    // layer4 call at 8 / 16 / 32 frames with four waves, 131 / 217 / 411 with eight
+    if ((long)b * m * ns / 32 >= 2048) {
+        SA_RS(17, 8, 16, 8, 16, 16, 8, 2, 1, 2, 1, 26, 0)
+    }
+    SA_RS(17, 8, 16, 8, 16, 16, 4, 1, 1, 2, 1, 26, 0)
 #undef SA_RS
     return 0;
 }

@@ -986,3 +986,30 @@ def test_grid_ball_query_overflow_falls_back_to_full_scan(gpu, oracle):
     for i, (a, r, s) in enumerate([(0.0, 0.1, 64), (0.1, 0.5, 32)]):
         ridx, rcnt = oracle.query_ball_point_dilated(a, r, s, xyz1, xyz2)
         _check_ball(idx[i], cnt[i], ridx, rcnt)
+
+
+def test_group_mlp_layer4_scale0_eight_wave_form_matches_the_four_wave_form(gpu, oracle):
+    # 259 -> 256 -> 256 -> 512 in fp16: from 2048 nominal 32-row tiles on (b * m * ns / 32) the streamed-weight kernel of
+    # csrc/mlp_rowwave.hip runs eight waves per workgroup instead of four.  16 frames take the eight-wave form, each
+    # half of them alone (8 frames: 1024 tiles) the four-wave form: same rows, same arithmetic -> identical bits; and
+    # both within the bar of the fp32 oracle.
+    rng = np.random.default_rng(4160)
+    b, n, m, ns, c = 16, 512, 256, 16, 256
+    xyz = _cloud(rng, b, n, scale=6.0)
+    feat = rng.normal(0, 1, (b, n, c)).astype(np.float32)
+    new_xyz = xyz[:, :m] + rng.normal(0, 0.1, (b, m, 3)).astype(np.float32)
+    idx = rng.integers(0, n, (b, m, ns)).astype(np.int32)
+    cnt = rng.integers(0, ns + 1, (b, m)).astype(np.int32)
+    cnt[:, ::9] = 0
+    pidx = _pad_like_ball_query(idx, cnt)
+    ws, bs = _rand_layers(rng, [c + 3, 256, 256, 512])
+    assert b * m * ns // 32 >= 2048 > (b // 2) * m * ns // 32
+    both = _run_group_mlp(gpu, xyz, feat, new_xyz, pidx, cnt, ws, bs, precision="fp16")
+    for h in range(2):
+        s = slice(h * 8, h * 8 + 8)
+        half = _run_group_mlp(gpu, xyz[s], feat[s], new_xyz[s], pidx[s], cnt[s], ws, bs, precision="fp16")
+        assert np.array_equal(both[s], half), "frames %d.. differ between the 8-wave and the 4-wave form" % (h * 8)
+    ref = oracle.group_mlp_max(xyz[:4], feat[:4], new_xyz[:4], pidx[:4], cnt[:4], ws, bs)
+    err = np.abs(both[:4] - ref).max() / np.abs(ref).max()
+    assert err < MLP_TOL, "relative error %g" % err
+    assert (both[cnt == 0] == 0).all()

@@ -14,6 +14,19 @@ buf = (ctypes.c_ulonglong * 9)()
 class Proxy:
     def __getattr__(self, name):
         fn = getattr(real, name)
+        if name == "sa_group_mlp_max_layer":
+            def wrapped_layer(*a):
+                torch.cuda.synchronize(); raw.sa_debug_rw_prof(None, 1)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record(); st = fn(*a); e.record(); torch.cuda.synchronize()
+                raw.sa_debug_rw_prof(buf, 0)
+                v = list(buf)
+                waves, tiles = max(v[8], 1), max(v[7], 1)
+                print("layer call b=%d m=%d: %.3f ms | instrumented waves %d tiles/wave %.2f | per wave: prologue %d | per tile: [1] %d [2] %d [3] %d [4] %d [5] %d [6] %d | total/wave %d cycles" % (
+                    a[1], a[3], s.elapsed_time(e), waves, tiles / waves, v[0] // waves, v[1] // tiles, v[2] // tiles, v[3] // tiles,
+                    v[4] // tiles, v[5] // tiles, v[6] // tiles, sum(v[:7]) // waves))
+                return st
+            return wrapped_layer
         if name != "sa_group_mlp_max":
             return fn
         def wrapped(*a):
@@ -39,7 +52,7 @@ native._LIB = Proxy()
 dev = torch.device("cuda:0")
 arch = cfgs.KITTI_3DSSD_ARCH
 net = importlib.import_module("3dssd_amd.backbone").SABackbone(arch, syn.random_backbone_params(arch), dev)
-pts = torch.from_numpy(syn.kitti_like_batch(8)).to(dev)
+pts = torch.from_numpy(syn.kitti_like_batch(int(sys.argv[1]) if len(sys.argv) > 1 else 8)).to(dev)
 for rep in range(2):
     print("--- rep", rep)
     net(pts)
