@@ -266,9 +266,6 @@ __device__ __forceinline__ void sq_store_tile(float *lds, const float *sA, const
 #pragma unroll
             for (int r = 0; r < 16; ++r) vv[tj][r] = (sa[r] + sb) - 2.0f * acc[ti][tj][r];
         }
-#ifdef SA_SQ_NOSTORE
-        if (vv[0][0] != 12345.678f) continue;
-#endif
         if (full) {
             // ---- direct tile: patch[ir][tj*32 + col], read back as float4 rows
 #pragma unroll
@@ -277,22 +274,14 @@ __device__ __forceinline__ void sq_store_tile(float *lds, const float *sA, const
                 for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * half) * 68 + tj * 32 + col] = vv[tj][r];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-#ifdef SA_SQ_NODIRECT
-            for (int it = 0; it < (vv[0][0] == 12345.678f ? 8 : 0); ++it) {
-#else
             for (int it = 0; it < 8; ++it) {
-#endif
                 const int pr = it * 4 + (lane >> 4), pc = (lane & 15) * 4;       // 4 rows x 16 lanes x 16 B
                 const float4 q4 = *(const float4 *)(patch + pr * 68 + pc);
                 f32x4v *dst = (f32x4v *)(tile + (unsigned)((wr * 64 + ti * 32 + pr) * m + wc * 64 + pc));
                 const f32x4v qv = {q4.x, q4.y, q4.z, q4.w};
                 if (NT) __builtin_nontemporal_store(qv, dst); else *dst = qv;
             }
-#ifdef SA_SQ_NOMIRROR
-            if (mirror && vv[0][0] == 12345.678f) {
-#else
             if (mirror) {
-#endif
                 // ---- mirrored tile: patch viewed as [64 columns j][34]: patchT[tj*32 + col][ir]
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -336,6 +325,79 @@ __device__ __forceinline__ void sq_store_tile(float *lds, const float *sA, const
             }
         }
     }
+}
+
+// Full tiles of the packed-operand kernel: the same values as sq_store_tile, with the MIRRORED tile written in 256-byte
+// row pieces too.  sq_store_tile transposes a (ti) strip of 32 rows x 64 columns, whose image is 64 rows of 32 floats:
+// 8 rows x 128 B per store instruction, 4.7 TB/s with nothing else running against 5.4 for the direct tile (store-only
+// builds of this kernel).  Here the distances replace the accumulators in place, the direct tile leaves per (ti) strip as
+// before and the mirrored tile per (tj) strip of 64 rows x 32 columns, whose image is 32 rows x 64 floats: 4 rows x 256 B
+// per instruction like the direct one, and the patch is filled with 16-byte LDS writes (a lane's four consecutive
+// accumulator registers are four consecutive rows i = one 16-byte piece of a transposed row).
+template <bool SYM, bool NT>
+__device__ __forceinline__ void sq_store_full(float *lds, const float *sA, const float *sB, f32x16 (&acc)[2][2], int b, int n,
+                                              int m, int i0, int j0, bool mirror, int w, int lane, float *__restrict__ out) {
+    const int wr = w >> 1, wc = w & 1;
+    const int half = lane >> 5, col = lane & 31;
+    float *patch = lds + w * (32 * 68);                                          // 32 x 68 floats
+    float *tile = out + ((size_t)b * n + i0) * m + j0;
+    float *tileT = SYM ? out + ((size_t)b * n + j0) * n + i0 : nullptr;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        float sa[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *(const float4 *)(sA + wr * 64 + ti * 32 + 8 * q + 4 * half);
+            sa[4 * q + 0] = v.x; sa[4 * q + 1] = v.y; sa[4 * q + 2] = v.z; sa[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            const float sb = sB[wc * 64 + tj * 32 + col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ti][tj][r] = (sa[r] + sb) - 2.0f * acc[ti][tj][r];
+        }
+    }
+    const int pr0 = lane >> 4, pc = (lane & 15) * 4;                             // read-back: 4 rows x 16 lanes x 16 B
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {                                             // direct tile: strip of 32 rows i x 64 columns j
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * half) * 68 + tj * 32 + col] = acc[ti][tj][r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int pr = it * 4 + pr0;
+            const float4 q4 = *(const float4 *)(patch + pr * 68 + pc);
+            f32x4v *dst = (f32x4v *)(tile + (unsigned)((wr * 64 + ti * 32 + pr) * m + wc * 64 + pc));
+            const f32x4v qv = {q4.x, q4.y, q4.z, q4.w};
+            if (NT) __builtin_nontemporal_store(qv, dst); else *dst = qv;
+        }
+    }
+    if (SYM && mirror) {
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {                                         // mirrored tile: strip of 64 rows i x 32 columns j
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4v v4 = {acc[ti][tj][4 * q], acc[ti][tj][4 * q + 1], acc[ti][tj][4 * q + 2], acc[ti][tj][4 * q + 3]};
+                    *(f32x4v *)(patch + col * 68 + ti * 32 + 8 * q + 4 * half) = v4;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int pr = it * 4 + pr0;                                     // row j of the strip, 64 floats i
+                const float4 q4 = *(const float4 *)(patch + pr * 68 + pc);
+                f32x4v *dst = (f32x4v *)(tileT + (unsigned)((wc * 64 + tj * 32 + pr) * n + wr * 64 + pc));
+                const f32x4v qv = {q4.x, q4.y, q4.z, q4.w};
+                if (NT) __builtin_nontemporal_store(qv, dst); else *dst = qv;
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
 // NT: non-temporal stores -- a matrix far larger than L2 + Infinity Cache (537 MB at the layer-2 shape, of which
@@ -589,16 +651,6 @@ __global__ __launch_bounds__(256, 4) void sqdist_mfma3_kernel(int n, int m, int 
     const int wr = w >> 1, wc = w & 1;
     const int half = lane >> 5, col = lane & 31;
     const int S = (c + kKS2 - 1) / kKS2, Ta = npa / kMT, Tb = npb / kMT;
-#ifdef SA_SQ_STAGGER
-    {   // experiment: the workgroups of the first resident round start a fraction of a tile period apart
-        const unsigned L = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        if (L < (unsigned)SA_SQ_STAGGER_WGS) {
-            const unsigned ph = SA_SQ_STAGGER == 1 ? (L >> 8) & 3u : (SA_SQ_STAGGER == 2 ? (L * 2654435761u) >> 30 : (SA_SQ_STAGGER == 4 ? (L >> 8) & 1u : (SA_SQ_STAGGER == 5 ? (L >> 9) & 1u : (L >> 3) & 3u)));
-            const unsigned long long t0 = wall_clock64();
-            while (wall_clock64() - t0 < (unsigned long long)ph * SA_SQ_STAGGER_TICKS) __builtin_amdgcn_s_sleep(16);
-        }
-    }
-#endif
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -619,11 +671,7 @@ __global__ __launch_bounds__(256, 4) void sqdist_mfma3_kernel(int n, int m, int 
     for (int i = 0; i < kCp; ++i) { ra[i] = srcA[i * 256]; rb[i] = srcB[i * 256]; }
     f32x4v *dA = (f32x4v *)&s_pl[0][0][0][0] + tid, *dB = (f32x4v *)&s_pl[1][0][0][0] + tid;
 
-    #ifdef SA_SQ_NOMFMA
-    for (int st = 0; st < 0; ++st) {
-#else
     for (int st = 0; st < S; ++st) {
-#endif
         const int cnt = min(kKS2, c - st * kKS2);
         const int npairs = (cnt + 1) >> 1;
         if (st > 0) __syncthreads();                       // the previous stage is fully consumed
@@ -657,7 +705,10 @@ __global__ __launch_bounds__(256, 4) void sqdist_mfma3_kernel(int n, int m, int 
     __syncthreads();                               // operand planes dead -> norms and transpose patches
     if (tid < kMT) sA[tid] = nrm; else sB[tid - kMT] = nrm;
     __syncthreads();
-    sq_store_tile<SYM, NT>(&s_pl[0][0][0][0], sA, sB, acc, b, n, m, i0, j0, SYM && bi != bj, w, lane, out);
+    // full tiles (wave-uniform): both images in 256-byte row pieces; edge tiles: the scalar path of sq_store_tile
+    const bool full = i0 + kMT <= n && j0 + kMT <= m && (m & 3) == 0 && (!SYM || (n & 3) == 0);
+    if (full) sq_store_full<SYM, NT>(&s_pl[0][0][0][0], sA, sB, acc, b, n, m, i0, j0, SYM && bi != bj, w, lane, out);
+    else sq_store_tile<SYM, NT>(&s_pl[0][0][0][0], sA, sB, acc, b, n, m, i0, j0, SYM && bi != bj, w, lane, out);
 }
 
 #ifdef SA_SQ_TIMING
@@ -765,11 +816,7 @@ static int sqdist_split_ws_impl(int b, int n, int m, int c0, int c1, const float
         hipLaunchKernelGGL(sqdist_pack_kernel, dim3(npb / kMT, b), dim3(2 * kMT), pack_lds, stream, m, npb, S, ldc, Bm, packB, normB);
         SA_CHECK_LAUNCH();
     }
-#ifdef SA_SQ_NONT
-    const bool nt = false;
-#else
     const bool nt = (size_t)b * n * m * sizeof(float) > ((size_t)192 << 20);
-#endif
     if (sym) {
         const int T = npa / kMT;
         dim3 grid(T * (T + 1) / 2, 1, b);
