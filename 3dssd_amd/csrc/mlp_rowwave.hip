@@ -104,8 +104,14 @@ struct RowRef { int pt, ball, cnt, ent; };   // source point (flat index), ball,
 // pair) + 32-bit lane offset: no 64-bit address arithmetic on the VALU.
 // tile, row of the tile -> plan entry (granule row>>3 of the tile) -> ball, sample -> source point; the index and
 // count loads issue together.  Granules past the end of the plan (ent < 0) read ball 0 and are never written.
-__device__ __forceinline__ RowRef load_row_ref(const RwParams &P, int ngran, int tile, int row) {
-    const int ent = sa::plan_entry(P.gran, ngran, tile * 4 + (row >> 3));
+// The chain is TWO dependent round trips (plan entry -> index / count).  In the tile loops the plan entry is therefore
+// requested one tile earlier than the index (load_plan_ent, then row_ref_of on the next iteration): requested together,
+// the index load waited a full memory round trip for the entry at every tile -- 20-40 % of a wave's time in the narrow
+// scales (tools/rw_phase_prof.py).
+__device__ __forceinline__ int load_plan_ent(const RwParams &P, int ngran, int tile, int row) {
+    return sa::plan_entry(P.gran, ngran, tile * 4 + (row >> 3));
+}
+__device__ __forceinline__ RowRef row_ref_of(const RwParams &P, int ent, int row) {
     const int ball = ent >= 0 ? sa::plan_ball(ent) : 0;
     const int s = sa::plan_sample(ent, row & 7, P.ns);
     const int a_raw = P.idx[(unsigned)(ball * P.ns + s)];
@@ -123,6 +129,9 @@ __device__ __forceinline__ RowRef load_row_ref(const RwParams &P, int ngran, int
     r.ball = ball;
     r.pt = frame * P.n + (c > 0 ? a_raw : 0);               // layers_util.py:157-159
     return r;
+}
+__device__ __forceinline__ RowRef load_row_ref(const RwParams &P, int ngran, int tile, int row) {
+    return row_ref_of(P, load_plan_ent(P, ngran, tile, row), row);
 }
 
 // Relative coordinates (and, for C == 1, the single feature channel) of this lane's row.
@@ -292,6 +301,8 @@ __device__ __forceinline__ void rw_body(const RwParams &P) {
     advance(tf);
     int ti = tf;
     advance(ti);
+    int te = ti;                                         // plan entries: three ahead
+    advance(te);
 
     float raw[KS0][8];
     RowRef cur = load_row_ref(P, ngran, tc, row);
@@ -301,6 +312,7 @@ __device__ __forceinline__ void rw_body(const RwParams &P) {
         for (int ks = 0; ks < KS0; ++ks) load_group(P, cur, tl, 2 * ks + half, raw[ks]);
     }
     RowRef nxt = load_row_ref(P, ngran, tf, row);
+    int ent_i = load_plan_ent(P, ngran, ti, row);
 
     for (bool more = true; more;) {
         more = tc + nwaves < ntiles;
@@ -324,10 +336,12 @@ __device__ __forceinline__ void rw_body(const RwParams &P) {
 #pragma unroll
             for (int ks = 0; ks < KS0; ++ks) load_group(P, cur, tl, 2 * ks + half, raw[ks]);
         }
-        nxt = load_row_ref(P, ngran, ti, row);
+        nxt = row_ref_of(P, ent_i, row);                 // tile ti: its entry arrived during the previous tile
+        ent_i = load_plan_ent(P, ngran, te, row);
         advance(tc);
         advance(tf);
         advance(ti);
+        advance(te);
         __builtin_amdgcn_sched_barrier(0);
         RW_TICK(2)
 
@@ -547,6 +561,7 @@ __device__ __forceinline__ void rs_body(const RwParams &P) {
         for (int ks = 0; ks < KS0; ++ks) load_group(P, cur, tl, 2 * ks + half, raw[ks]);
     }
     RowRef nxt = load_row_ref(P, ngran, tf, row);
+    int ent_f = load_plan_ent(P, ngran, tf + nwaves, row);      // the entry of the tile after `nxt`: one tile ahead of its index
     sa::f16_guard_t det = 0;                 // fp16 range guard (mlp_act.h), scalar registers
 
     RW_TICK(0)
@@ -611,7 +626,8 @@ __device__ __forceinline__ void rs_body(const RwParams &P) {
 #pragma unroll
             for (int ks = 0; ks < KS0; ++ks) load_group(P, cur, tl, 2 * ks + half, raw[ks]);
         }
-        nxt = load_row_ref(P, ngran, tf, row);
+        nxt = row_ref_of(P, ent_f, row);
+        ent_f = load_plan_ent(P, ngran, tf + nwaves, row);
         RW_TICK(5)
     }
     if (PR == 1) sa::f16_overflow_report(det, P.ovf, lane);
