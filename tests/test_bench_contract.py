@@ -1,7 +1,8 @@
 """The bench lines committed under profiles/ (outputs of `python bench.py` on the GPU box, round 3) carry every field
 of the driver's contract, the round-3 additions (distinct frames, verification against eager, recorded environment,
-latency-bound roofline for FPS, executed-flop MFMA fraction), and their algorithmic work model reproduces SURVEY.md 8d:
-30.93 GFLOP of MLP per frame."""
+latency-bound roofline for FPS, executed-flop MFMA fraction, batches coalesced per replay), and their algorithmic work
+model reproduces SURVEY.md 8d: 30.93 GFLOP of MLP per frame.  Stages / rooflines describe the calls as the pipeline
+issues them: one pass over config.frames_per_launch frames."""
 import json
 import os
 
@@ -26,6 +27,7 @@ def test_bench_line_has_the_contract_fields(name):
     assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"] and "configs[1]" in d["config"]["workload"]
     assert "SAPipeline" in d["config"]["executor"] and d["config"]["pool_frames_per_gpu"] >= 128
+    assert d["config"]["frames_per_launch"] == d["config"]["frames_per_step_per_gpu"] * d["config"]["batches_per_replay"]
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
@@ -37,6 +39,7 @@ def test_bench_line_has_the_contract_fields(name):
     # every pipeline output of the verification pass equalled the eager result of the same batch
     v = d["verify"]
     assert v["all_equal_eager"] is True and v["output_sha1_replay"] == v["output_sha1_eager"] and v["batches"] >= 16
+    assert v["batches_per_replay"] == d["config"]["batches_per_replay"]
     assert not [k for k in d["env_knobs"] if k.startswith("SA_")]
 
 
@@ -51,19 +54,21 @@ def test_default_line_cpu_baseline_and_ramp_flag():
 
 
 def test_fps_roofline_is_latency_bound_with_evaluated_pairs():
-    r = _line()["roofline"]
+    d = _line()
+    r, fpl = d["roofline"], d["config"]["frames_per_launch"]
     assert r["bound"] == "latency" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
     assert r["device_kernel"].startswith("fps3_wave_bucket_kernel")
-    assert r["reference_pair_evaluations"] == 8 * 4095 * 16384
+    assert r["reference_pair_evaluations"] == fpl * 4095 * 16384
     assert 0 < r["evaluated_pairs"] < r["reference_pair_evaluations"] and abs(r["evaluated_frac"] - r["evaluated_pairs"] / r["reference_pair_evaluations"]) < 1e-4
     assert abs(r["achieved"] - r["reference_pair_evaluations"] * 11 / (r["avg_launch_ms"] * 1e9)) < 0.01
-    assert abs(r["cycles_per_pick"] - r["us_per_pick"] * r["clock_mhz"]) < 1.0 and r["cus_used"] == 8
-    assert abs(r["algorithmic_bytes"] / 8 / 1e6 - 0.213) < 0.001     # 213 KB algorithmic per frame for layer-1 FPS
+    assert abs(r["cycles_per_pick"] - r["us_per_pick"] * r["clock_mhz"]) < 1.0 and r["cus_used"] == fpl   # one CU per frame
+    assert abs(r["algorithmic_bytes"] / fpl / 1e6 - 0.213) < 0.001   # 213 KB algorithmic per frame for layer-1 FPS
+    assert r["traffic"] is not None and r["traffic"] < 2 * r["algorithmic_bytes"]      # counter traffic of the same launch shape
 
 
 def test_algorithmic_mlp_work_matches_survey_8d():
     d = _line()
-    frames = d["config"]["frames_per_step_per_gpu"]
+    frames = d["config"]["frames_per_launch"]              # the stages are the calls of one replay
     mlp = sum(s["gflop"] * s["calls_per_step"] for s in d["stages"] if s["kernel"] in MLP_CALLS + ("sa_dense", "sa_vote_tail"))
     assert abs(mlp / frames - 30.93) < 0.01            # 30.93 GFLOP per frame through the backbone
     fps = [s for s in d["stages"] if s["label"].startswith("fps n=16384")]
@@ -74,6 +79,10 @@ def test_algorithmic_mlp_work_matches_survey_8d():
     ms = g["kernel_ms"] + g["plan_ms"]
     assert abs(g["achieved"] - rows["gflop_evaluated"] / ms) < 0.5 and abs(g["frac"] - g["achieved"] / g["peak"]) < 1e-4
     assert abs(g["nominal_tflops"] - rows["gflop_nominal"] / ms) < 1.0 and g["nominal_frac"] > g["frac"]
+    assert rows["frames"] == frames
+    # the north star's ">= 30 % MFMA utilisation on the grouped MLP": the hardware counter over the MLP kernels of the
+    # committed PMC pass (same launch shape), not the flop model
+    assert g["pmc"]["mfma_util"] >= 0.30 and "r03_traffic.json" in g["pmc"]["source"]
 
 
 def test_data_variants_move_the_data_dependent_counters():

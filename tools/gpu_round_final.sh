@@ -41,4 +41,6 @@ print(open("$OUT/ops_rocprof_summary.txt").read()[:1500])
 P
 find $OUT/ops_trace -name "*kernel_trace.csv" -size +10M -delete
 echo "== rocprof single stream"; bash tools/gpu_prof.sh $TAG/prof > $OUT/prof.log 2>&1; tail -5 $OUT/prof.log
+echo "== slots x batches per replay"; bash tools/gpu_sweep_coalesce.sh 16:1 16:2 16:4 16:8 12:4 8:4 > $OUT/sweep_coalesce.txt 2>&1; cat $OUT/sweep_coalesce.txt
+echo "== marginal cost of the kernel classes"; bash tools/ablate.sh > $OUT/ablation.txt 2>&1; cat $OUT/ablation.txt
 echo "== done"
