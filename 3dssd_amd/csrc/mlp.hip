@@ -919,6 +919,140 @@ __global__ __launch_bounds__(kDThreads) void dense_kernel(DenseParams P) {
     dense_body<TG>(P, smem, lane, w, tid);
 }
 
+// ---- dense layer on 128-ROW blocks for the wide aggregation layers of a coalesced replay (32 frames: 8192 x 1536 -> 512,
+//      16384 x 768 -> 256, 32768 x 384 -> 128).  dense_kernel streams ALL weights of its column tiles for every 32 rows
+//      with one L2 round trip per couple of k-steps: 805 MB of weight fragments and 48 dependent round trips per
+//      workgroup at 8192 x 1536 -> 512 (75 us, MFMA busy 0.20).  Here a workgroup owns 128 rows x 128 columns: NW = 4 or 8
+//      waves, wave = (column tile, row part), a weight fragment feeds 4 / 2 row tiles; the contraction runs in chunks of
+//      64 channels through a double-buffered LDS image of the rows (one LDS-only barrier per chunk), and both streams --
+//      the fp32 rows and the weight fragments -- are requested kD128PD chunks ahead into register rings (branch-free
+//      blocks, prologue values laundered: see mlp_wide128.hip).  Same arithmetic as dense_kernel (bias in the
+//      accumulator, k ascending, the three split-bf16 passes in the same order, D^T form): bit-identical output.
+constexpr int kD128KC = 64, kD128PD = 3;
+constexpr int kD128Stride = kD128KC * 4 + 16;                 // bytes of a row in one LDS buffer (hi / lo planes, padded)
+constexpr size_t kD128Lds = (size_t)2 * 128 * kD128Stride;
+typedef unsigned d128_u32x4 __attribute__((ext_vector_type(4)));
+typedef float d128_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void dense128_kernel(DenseParams P) {
+    constexpr int RT = 16 / NW;                               // row tiles per wave: 4 (four waves) or 2 (eight)
+    constexpr int NI = 1024 / (NW * 64);                      // (row, 8-channel group) items a thread stages per chunk
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, col = lane & 31;
+    const LayerDesc &L = P.L;
+    const int ct = blockIdx.y * 4 + (w & 3);                  // this wave's column tile (host: NT % 4 == 0)
+    const int rt0 = (w >> 2) * RT;                            // ... and its first row tile of the block
+    const long r0 = (long)blockIdx.x * 128;
+    const int nch = L.K / kD128KC;                            // host: K % (64 * kD128PD) == 0
+
+    // this thread's (row, 8-channel group) items of a chunk: rows past the end read the last row, never stored
+    const float *sp[NI];
+    int soff[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int item = tid + NW * 64 * j, row = item >> 3, g = item & 7;
+        long r = r0 + row;
+        if (r >= P.rows) r = P.rows - 1;
+        sp[j] = P.x + r * L.K + g * 8;
+        soff[j] = row * kD128Stride + g * 32;
+    }
+    f32x16 acc[RT];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 bv = *(const float4 *)(L.bias + ct * 32 + 8 * q + 4 * half);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            acc[rt][4 * q + 0] = bv.x; acc[rt][4 * q + 1] = bv.y; acc[rt][4 * q + 2] = bv.z; acc[rt][4 * q + 3] = bv.w;
+        }
+    }
+    const d128_u32x4 *wb = (const d128_u32x4 *)L.w + (size_t)ct * L.KS * 128 + lane;
+    d128_f32x4 xa[kD128PD][NI][2];
+    d128_u32x4 wq[kD128PD][4][2];
+#pragma unroll
+    for (int d = 0; d < kD128PD; ++d) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            xa[d][j][0] = *(const d128_f32x4 *)(sp[j] + d * kD128KC);
+            xa[d][j][1] = *(const d128_f32x4 *)(sp[j] + d * kD128KC + 4);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            wq[d][ks][0] = wb[(d * 4 + ks) * 128];
+            wq[d][ks][1] = wb[(d * 4 + ks) * 128 + 64];
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < kD128PD; ++d) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) asm volatile("" : "+v"(xa[d][j][0]), "+v"(xa[d][j][1]));
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(wq[d][ks][0]), "+v"(wq[d][ks][1]));
+    }
+    for (int c0 = 0; c0 < nch; c0 += kD128PD) {
+#pragma unroll
+        for (int d = 0; d < kD128PD; ++d) {
+            const int c = c0 + d;
+            unsigned char *buf = smem + (c & 1) * (128 * kD128Stride);
+            // rows of chunk c: fp32 -> split bf16 planes -> LDS
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const float v[8] = {xa[d][j][0][0], xa[d][j][0][1], xa[d][j][0][2], xa[d][j][0][3],
+                                    xa[d][j][1][0], xa[d][j][1][1], xa[d][j][1][2], xa[d][j][1][3]};
+                uint4 hi, lo;
+                split8(v, hi, lo);
+                *(uint4 *)(buf + soff[j]) = hi;
+                *(uint4 *)(buf + soff[j] + 16) = lo;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // LDS-only barrier: the rings stay in flight
+            // the chunk's weight fragments out of the ring, both rings refilled kD128PD chunks ahead (clamped at the end)
+            d128_u32x4 wc[4][2];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { wc[ks][0] = wq[d][ks][0]; wc[ks][1] = wq[d][ks][1]; }
+            const int cn = c + kD128PD < nch ? c + kD128PD : nch - 1;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                xa[d][j][0] = *(const d128_f32x4 *)(sp[j] + cn * kD128KC);
+                xa[d][j][1] = *(const d128_f32x4 *)(sp[j] + cn * kD128KC + 4);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                wq[d][ks][0] = wb[(cn * 4 + ks) * 128];
+                wq[d][ks][1] = wb[(cn * 4 + ks) * 128 + 64];
+            }
+            const unsigned char *arow = buf + (rt0 * 32 + col) * kD128Stride + half * 32;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const uint4 wh = __builtin_bit_cast(uint4, wc[ks][0]), wl = __builtin_bit_cast(uint4, wc[ks][1]);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const uint4 ah = *(const uint4 *)(arow + rt * 32 * kD128Stride + ks * 64);
+                    const uint4 al = *(const uint4 *)(arow + rt * 32 * kD128Stride + ks * 64 + 16);
+                    acc[rt] = mfma_bf16(wh, ah, acc[rt]);
+                    acc[rt] = mfma_bf16(wl, ah, acc[rt]);
+                    acc[rt] = mfma_bf16(wh, al, acc[rt]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const long r = r0 + (rt0 + rt) * 32 + col;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = acc[rt][4 * q + e];
+                if (P.relu) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
+            }
+            if (r < P.rows) *(float4 *)(P.y + r * L.N + ct * 32 + 8 * q + 4 * half) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
 // ---- vote_layer tail in ONE launch (layers_util.py:17-23): the last hidden conv1d (K -> H <= 128, BN folded, ReLU),
 //      the offset conv1d (H -> 3, no activation) and out = xyz + clip(offsets) -- three launches before.  A workgroup
 //      owns 32 rows: its four waves produce the 32 x H hidden tile exactly as dense_kernel<1> does (and write it, it is
@@ -1549,6 +1683,18 @@ extern "C" int sa_dense(long rows, int K, int N, const float *x, const void *wpa
     P.L.w = (const uint4 *)wpack; P.L.bias = bias; P.L.K = K; P.L.N = N;
     P.L.KS = roundup(K, 16) / 16;
     P.L.NT = roundup(N, 32) / 32;
+    // wide layers with enough rows to give every CU a 128 x 128 block: the 128-row kernel (same bits)
+    if (K % (kD128KC * kD128PD) == 0 && N % 128 == 0 && ((rows + 127) / 128) * (N / 128) >= 192 && rows < (1l << 31)) {
+#ifndef SA_D128_NW
+#define SA_D128_NW 8
+#endif
+        auto kern = dense128_kernel<SA_D128_NW>;
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kD128Lds);
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(kern, dim3((unsigned)((rows + 127) / 128), N / 128), dim3(SA_D128_NW * 64), kD128Lds, stream, P);
+        SA_CHECK_LAUNCH();
+        return SA_OK;
+    }
     P.KC = P.L.KS * 16 < 256 ? P.L.KS * 16 : 256;
     P.stride = P.KC * 4 + 16;
     const size_t lds = (size_t)kRows * P.stride;

@@ -1013,3 +1013,35 @@ def test_group_mlp_layer4_scale0_eight_wave_form_matches_the_four_wave_form(gpu,
     err = np.abs(both[:4] - ref).max() / np.abs(ref).max()
     assert err < MLP_TOL, "relative error %g" % err
     assert (both[cnt == 0] == 0).all()
+
+
+@pytest.mark.parametrize("rows,K,N,relu", [(25000, 384, 128, True), (12300, 768, 256, True), (6200, 1536, 512, False)])
+def test_dense_128_row_blocks_equal_the_32_row_kernel(gpu, oracle, rows, K, N, relu):
+    # sa_dense takes 128-row x 128-column blocks (csrc/mlp.hip dense128_kernel) when K is a multiple of 192, N of 128 and
+    # there are >= 192 blocks -- the aggregation layers of a 32-frame replay.  Same arithmetic as the 32-row kernel: the
+    # same rows in pieces too small for the block form (< 192 blocks) must give the same bits; rows is not a multiple of
+    # 128 (ragged last block) and the output is checked against the oracle on a sample.
+    N_ = pkg("utils._native")
+    Wt = pkg("utils.weights")
+    assert K % 192 == 0 and N % 128 == 0 and -(-rows // 128) * (N // 128) >= 192
+    rng = np.random.default_rng(rows + K)
+    x = rng.normal(0, 1, (rows, K)).astype(np.float32)
+    w = rng.normal(0, 1 / np.sqrt(K), (K, N)).astype(np.float32)
+    bias = rng.normal(0, 0.2, N).astype(np.float32)
+    L = Wt.PackedLayer(w, bias, gpu)
+    tx = _t(x, gpu)
+    lib, st = N_.lib(), N_.current_stream()
+    y = torch.full((rows + 1, N), -5.0, dtype=torch.float32, device=gpu)       # one guard row behind the output
+    assert lib.sa_dense(rows, K, N, tx.data_ptr(), L.w.data_ptr(), L.bias.data_ptr(), int(relu), y.data_ptr(), st) == 0
+    piece = (191 // (N // 128)) * 128                                          # at most 191 blocks: the 32-row kernel
+    y2 = torch.full((rows + 1, N), -5.0, dtype=torch.float32, device=gpu)
+    for a in range(0, rows, piece):
+        n = min(piece, rows - a)
+        assert lib.sa_dense(n, K, N, tx.data_ptr() + 4 * K * a, L.w.data_ptr(), L.bias.data_ptr(), int(relu),
+                            y2.data_ptr() + 4 * N * a, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2) and bool((y[rows] == -5.0).all())
+    sample = np.r_[0:300, rows - 300:rows]
+    ref = oracle.dense(x[sample], w, bias, relu)
+    err = np.abs(y.cpu().numpy()[sample] - ref).max() / np.abs(ref).max()
+    assert err < MLP_TOL, "relative error %g" % err
