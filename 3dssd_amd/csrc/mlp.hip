@@ -922,13 +922,24 @@ __global__ __launch_bounds__(kDThreads) void dense_kernel(DenseParams P) {
 // ---- dense layer on 128-ROW blocks for the wide aggregation layers of a coalesced replay (32 frames: 8192 x 1536 -> 512,
 //      16384 x 768 -> 256, 32768 x 384 -> 128).  dense_kernel streams ALL weights of its column tiles for every 32 rows
 //      with one L2 round trip per couple of k-steps: 805 MB of weight fragments and 48 dependent round trips per
-//      workgroup at 8192 x 1536 -> 512 (75 us, MFMA busy 0.20).  Here a workgroup owns 128 rows x 128 columns: NW = 4 or 8
-//      waves, wave = (column tile, row part), a weight fragment feeds 4 / 2 row tiles; the contraction runs in chunks of
-//      64 channels through a double-buffered LDS image of the rows (one LDS-only barrier per chunk), and both streams --
-//      the fp32 rows and the weight fragments -- are requested kD128PD chunks ahead into register rings (branch-free
-//      blocks, prologue values laundered: see mlp_wide128.hip).  Same arithmetic as dense_kernel (bias in the
-//      accumulator, k ascending, the three split-bf16 passes in the same order, D^T form): bit-identical output.
-constexpr int kD128KC = 64, kD128PD = 3;
+//      workgroup at 8192 x 1536 -> 512 (75 us, MFMA busy 0.20).  Here a workgroup owns 128 rows x 128 columns: eight
+//      waves, wave = (column tile, row half), a weight fragment feeds two row tiles; the contraction runs in chunks of
+//      64 channels through a double-buffered LDS image of the rows (chunk c + 1 staged in front of the matrix work on
+//      chunk c, one LDS-only barrier per chunk), and both streams -- the fp32 rows and the weight fragments -- are
+//      requested kD128PD chunks ahead into register rings (branch-free blocks, prologue values laundered: see
+//      mlp_wide128.hip; a ring slot is refilled AFTER its MFMAs so that no fragment is copied).  Same arithmetic as
+//      dense_kernel (bias in the accumulator, k ascending, the three split-bf16 passes in the same order, D^T form):
+//      bit-identical output.  75 / 47 / 32 us -> 54 / 35 / 24 us for the three layers above.  What bounds it now: the
+//      workgroups draw 604 MB from the L2s per call at 8192 x 1536 -> 512 (rows 786 KB + weights 2 x 786 KB per
+//      workgroup: both row halves fetch the fragments) = 11 TB/s, the L2 -> CU rate every streaming kernel of this
+//      library tops out at; the four-wave form (each fragment fetched once, RT = 4) has one wave per SIMD and nobody to
+//      overlap its LDS round trips with: 58 us.  Measured on the way: removing the MFMAs saves 11 us, either stream
+//      12 us; hipcc left alone reuses one register pair for the LDS operand fragments (a round trip in front of every
+//      three MFMAs) -- the sched_group_barrier pipeline below fixes the ISA but not the time, the L2 does.
+#ifndef SA_D128_PD
+#define SA_D128_PD 3
+#endif
+constexpr int kD128KC = 64, kD128PD = SA_D128_PD;
 constexpr int kD128Stride = kD128KC * 4 + 16;                 // bytes of a row in one LDS buffer (hi / lo planes, padded)
 constexpr size_t kD128Lds = (size_t)2 * 128 * kD128Stride;
 typedef unsigned d128_u32x4 __attribute__((ext_vector_type(4)));
@@ -991,50 +1002,76 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void dense128_kernel(DenseParams P
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(wq[d][ks][0]), "+v"(wq[d][ks][1]));
     }
+    // stage(slot, chunk to refill with, buffer): the ring slot's fp32 rows -> split bf16 planes -> LDS, then the slot is
+    // requested again kD128PD chunks ahead (clamped at the end: harmless re-reads)
+    auto stage = [&](d128_f32x4 (&xs)[NI][2], int refill, unsigned char *dst) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const float v[8] = {xs[j][0][0], xs[j][0][1], xs[j][0][2], xs[j][0][3], xs[j][1][0], xs[j][1][1], xs[j][1][2], xs[j][1][3]};
+            uint4 hi, lo;
+            split8(v, hi, lo);
+            *(uint4 *)(dst + soff[j]) = hi;
+            *(uint4 *)(dst + soff[j] + 16) = lo;
+        }
+        const int cn = refill < nch ? refill : nch - 1;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            xs[j][0] = *(const d128_f32x4 *)(sp[j] + cn * kD128KC);
+            xs[j][1] = *(const d128_f32x4 *)(sp[j] + cn * kD128KC + 4);
+        }
+    };
+    stage(xa[0], kD128PD, smem);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");              // LDS-only barrier: the rings stay in flight
+    // Chunk c + 1 is staged into the other buffer in front of the matrix work on chunk c: one barrier per chunk.
     for (int c0 = 0; c0 < nch; c0 += kD128PD) {
 #pragma unroll
         for (int d = 0; d < kD128PD; ++d) {
             const int c = c0 + d;
-            unsigned char *buf = smem + (c & 1) * (128 * kD128Stride);
-            // rows of chunk c: fp32 -> split bf16 planes -> LDS
+            const int dn = (d + 1) % kD128PD;                 // ring slot of chunk c + 1
+            const unsigned char *buf = smem + (c & 1) * (128 * kD128Stride);
+            unsigned char *bufn = smem + ((c + 1) & 1) * (128 * kD128Stride);
+            stage(xa[dn], c + 1 + kD128PD, bufn);
+            // The matrix work of the chunk as its own scheduling region with an explicit pipeline: left alone, hipcc reuses
+            // ONE pair of registers for the operand fragments (ds_read x2 -> wait -> 3 MFMA -> ds_read x2 ...: an LDS round
+            // trip in front of every three MFMAs, ~2 000 cycles per chunk against 770 of matrix issue); here the fragments
+            // of group g + 1 are requested before the MFMAs of group g.
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const unsigned char *arow = buf + (rt0 * 32 + col) * kD128Stride + half * 32;
+                uint4 ah[4 * RT], al[4 * RT];
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const float v[8] = {xa[d][j][0][0], xa[d][j][0][1], xa[d][j][0][2], xa[d][j][0][3],
-                                    xa[d][j][1][0], xa[d][j][1][1], xa[d][j][1][2], xa[d][j][1][3]};
-                uint4 hi, lo;
-                split8(v, hi, lo);
-                *(uint4 *)(buf + soff[j]) = hi;
-                *(uint4 *)(buf + soff[j] + 16) = lo;
+                for (int g = 0; g < 4 * RT; ++g) {
+                    ah[g] = *(const uint4 *)(arow + (g % RT) * 32 * kD128Stride + (g / RT) * 64);
+                    al[g] = *(const uint4 *)(arow + (g % RT) * 32 * kD128Stride + (g / RT) * 64 + 16);
+                }
+#pragma unroll
+                for (int g = 0; g < 4 * RT; ++g) {
+                    const int ks = g / RT, rt = g % RT;
+                    const uint4 wh = __builtin_bit_cast(uint4, wq[d][ks][0]), wl = __builtin_bit_cast(uint4, wq[d][ks][1]);
+                    acc[rt] = mfma_bf16(wh, ah[g], acc[rt]);
+                    acc[rt] = mfma_bf16(wl, ah[g], acc[rt]);
+                    acc[rt] = mfma_bf16(wh, al[g], acc[rt]);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);            // DS reads of groups 0, 1
+#pragma unroll
+                for (int g = 0; g + 2 < 4 * RT; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);        // MFMAs of group g
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);        // DS reads of group g + 2
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // LDS-only barrier: the rings stay in flight
-            // the chunk's weight fragments out of the ring, both rings refilled kD128PD chunks ahead (clamped at the end)
-            d128_u32x4 wc[4][2];
+            __builtin_amdgcn_sched_barrier(0);
+            // the ring slot of the weight fragments is requested again (kD128PD chunks ahead, clamped) once its MFMAs are
+            // issued: no copy of the fragments, and the loads of a slot are consumed in the order they were issued
+            {
+                const int cn = c + kD128PD < nch ? c + kD128PD : nch - 1;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) { wc[ks][0] = wq[d][ks][0]; wc[ks][1] = wq[d][ks][1]; }
-            const int cn = c + kD128PD < nch ? c + kD128PD : nch - 1;
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                xa[d][j][0] = *(const d128_f32x4 *)(sp[j] + cn * kD128KC);
-                xa[d][j][1] = *(const d128_f32x4 *)(sp[j] + cn * kD128KC + 4);
-            }
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                wq[d][ks][0] = wb[(cn * 4 + ks) * 128];
-                wq[d][ks][1] = wb[(cn * 4 + ks) * 128 + 64];
-            }
-            const unsigned char *arow = buf + (rt0 * 32 + col) * kD128Stride + half * 32;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const uint4 wh = __builtin_bit_cast(uint4, wc[ks][0]), wl = __builtin_bit_cast(uint4, wc[ks][1]);
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-                    const uint4 ah = *(const uint4 *)(arow + rt * 32 * kD128Stride + ks * 64);
-                    const uint4 al = *(const uint4 *)(arow + rt * 32 * kD128Stride + ks * 64 + 16);
-                    acc[rt] = mfma_bf16(wh, ah, acc[rt]);
-                    acc[rt] = mfma_bf16(wl, ah, acc[rt]);
-                    acc[rt] = mfma_bf16(wh, al, acc[rt]);
+                for (int ks = 0; ks < 4; ++ks) {
+                    wq[d][ks][0] = wb[(cn * 4 + ks) * 128];
+                    wq[d][ks][1] = wb[(cn * 4 + ks) * 128 + 64];
                 }
             }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
     }
 #pragma unroll
@@ -1686,7 +1723,7 @@ extern "C" int sa_dense(long rows, int K, int N, const float *x, const void *wpa
     // wide layers with enough rows to give every CU a 128 x 128 block: the 128-row kernel (same bits)
     if (K % (kD128KC * kD128PD) == 0 && N % 128 == 0 && ((rows + 127) / 128) * (N / 128) >= 192 && rows < (1l << 31)) {
 #ifndef SA_D128_NW
-#define SA_D128_NW 8
+#define SA_D128_NW 8                     // 4: one wave per (column tile), four row tiles per fragment
 #endif
         auto kern = dense128_kernel<SA_D128_NW>;
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kD128Lds);
