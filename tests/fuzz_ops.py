@@ -355,7 +355,84 @@ def case_mlp_big(rng):
     return None
 
 
-BIG = [case_fps_big, case_ball_multi, case_sqdist_big, case_mlp_big]
+def case_dense_blocks(rng):
+    """sa_dense on the 128-row block kernel (K a multiple of 192, N of 128, >= 192 blocks) against the 32-row kernel on
+    pieces of the same rows (identical bits) and against the oracle on a sample of rows"""
+    K, N_ = [(384, 128), (768, 256), (1536, 512), (192, 128), (576, 384)][int(rng.integers(0, 5))]
+    blocks = int(rng.integers(192, 260)) // (N_ // 128) + 1
+    rows = blocks * 128 - int(rng.integers(0, 128))
+    relu = int(rng.integers(0, 2))
+    x = rng.normal(0, 1, (rows, K)).astype(np.float32)
+    w = rng.normal(0, 1 / np.sqrt(K), (K, N_)).astype(np.float32)
+    bias = rng.normal(0, 0.2, N_).astype(np.float32)
+    L = Wt.PackedLayer(w, bias, dev)
+    tx = t(x)
+    lib, st = N.lib(), N.current_stream()
+    y = torch.full((rows + 1, N_), -5.0, dtype=torch.float32, device=dev)
+    y2 = torch.full((rows + 1, N_), -5.0, dtype=torch.float32, device=dev)
+    ok = lib.sa_dense(rows, K, N_, tx.data_ptr(), L.w.data_ptr(), L.bias.data_ptr(), relu, y.data_ptr(), st) == 0
+    piece = (191 // (N_ // 128)) * 128
+    for a in range(0, rows, piece):
+        n = min(piece, rows - a)
+        ok = ok and lib.sa_dense(n, K, N_, tx.data_ptr() + 4 * K * a, L.w.data_ptr(), L.bias.data_ptr(), relu,
+                                 y2.data_ptr() + 4 * N_ * a, st) == 0
+    torch.cuda.synchronize()
+    if not ok:
+        return "dense blocks: status"
+    if not torch.equal(y, y2) or not bool((y[rows] == -5.0).all()):
+        return "dense blocks: 128-row kernel differs from the 32-row kernel %s" % ((rows, K, N_, relu),)
+    sample = np.unique(np.r_[rng.integers(0, rows, 200), rows - 1, 0])
+    ref = O.dense(x[sample], w, bias, bool(relu))
+    err = np.abs(y.cpu().numpy()[sample] - ref).max() / max(np.abs(ref).max(), 1e-30)
+    return None if err < 1e-3 else "dense blocks: rel err %.3g %s" % (err, (rows, K, N_))
+
+
+def case_mlp_replay(rng):
+    """shapes of a coalesced replay: plans of several 4096-ball chunks (two-launch plan), the eight-wave streamed kernel of
+    259-256-256-512 (b * m * ns / 32 >= 2048); the whole call against the same frames in two halves (identical bits),
+    two frames against the oracle"""
+    c, ns, dims, m = [(256, 16, [256, 256, 512], 256), (1, 32, [16, 16, 32], 2048), (64, 32, [64, 64, 128], 1024),
+                      (128, 32, [128, 192, 256], 512), (256, 32, [256, 512, 1024], 256)][int(rng.integers(0, 5))]
+    b, n = 2 * int(rng.integers(4, 11)), int(rng.integers(400, 900))
+    xyz = cloud(rng, b, n)
+    feat = rng.normal(0, 1, (b, n, c)).astype(np.float32)
+    new_xyz = np.ascontiguousarray(xyz[:, rng.integers(0, n, m)], np.float32)
+    idx = rng.integers(0, n, (b, m, ns)).astype(np.int32)
+    cnt = rng.integers(0, ns + 1, (b, m)).astype(np.int32)
+    idx = np.where(np.arange(ns)[None, None, :] >= np.maximum(cnt, 1)[:, :, None], idx[:, :, :1], idx)
+    cin = [c + 3] + dims[:-1]
+    ws = [rng.normal(0, 1.0 / np.sqrt(k), (k, o)).astype(np.float32) for k, o in zip(cin, dims)]
+    bs = [rng.normal(0, 0.1, o).astype(np.float32) for o in dims]
+    layers = Wt.pack_scale(ws, bs, dev)
+
+    def run(sl):
+        bb = sl.stop - sl.start
+        out = torch.empty((bb, m, dims[-1]), dtype=torch.float32, device=dev)
+        tx, tn, ti, tc, tf = t(xyz[sl]), t(new_xyz[sl]), t(idx[sl]), t(cnt[sl]), t(feat[sl])
+        plan, plan_bytes = N.mlp_plan_ws(bb, m, ns, dev)
+        st = N.lib().sa_group_mlp_max(bb, n, m, ns, c, tx.data_ptr(), tf.data_ptr(), tn.data_ptr(), ti.data_ptr(), tc.data_ptr(), 3,
+                                      (ctypes.c_int * 4)(*([c + 3] + dims)), (ctypes.c_void_p * 3)(*[l.w.data_ptr() for l in layers]),
+                                      (ctypes.c_void_p * 3)(*[l.bias.data_ptr() for l in layers]), out.data_ptr(), dims[-1], 0,
+                                      plan.data_ptr(), plan_bytes, Wt.scale_flags(layers), None, N.current_stream())
+        torch.cuda.synchronize()
+        return st, out
+
+    st, whole = run(slice(0, b))
+    st1, lo = run(slice(0, b // 2))
+    st2, hi = run(slice(b // 2, b))
+    if st or st1 or st2:
+        return "mlp replay: status %d %d %d" % (st, st1, st2)
+    if not torch.equal(whole[:b // 2], lo) or not torch.equal(whole[b // 2:], hi):
+        return "mlp replay: %d frames at once differ from the two halves %s" % (b, (c, ns, dims, m, n))
+    ref = O.group_mlp_max(xyz[:2], feat[:2], new_xyz[:2], idx[:2], cnt[:2], ws, bs)
+    got = whole[:2].cpu().numpy()
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    if not np.isfinite(got).all() or err > 1e-3 or (got[cnt[:2] == 0] != 0).any():
+        return "mlp replay: rel err %.3g %s" % (err, (b, n, m, c, ns, dims))
+    return None
+
+
+BIG = [case_fps_big, case_ball_multi, case_sqdist_big, case_mlp_big, case_dense_blocks, case_mlp_replay, case_mlp_replay]
 
 def case_pooling(rng):
     P = pkg("utils.tf_ops.points_pooling.points_pooling")
