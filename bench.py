@@ -545,6 +545,27 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
     verify = verify_pipeline(pipe, batches, args.verify)
     if verify is not None and not verify["all_equal_eager"]:
         sys.exit("bench.py: a pipeline output differs from the eager result of the same batch -- refusing to report")
+    uncoalesced = None
+    if C > 1 and use_graphs and not args.no_uncoalesced and world == 1:
+        # the same executor with one batch per replay, reported beside the headline so that the effect of coalescing is
+        # in the line itself.  A process of its own: a second pipeline in THIS process would share the 16 hardware
+        # queues with the first one's 16 idle streams (measured: 8.5 k instead of 10.7 k frames/s).
+        torch.cuda.synchronize()
+        k1, w1 = max(min(args.steps, 128), 1), max(min(args.warmup, 24), 1)
+        cmd = [sys.executable, os.path.abspath(__file__), "--coalesce", "1", "--steps", str(k1), "--warmup", str(w1),
+               "--batch", str(args.batch), "--points", str(points), "--streams", str(args.streams), "--pool", str(args.pool),
+               "--data", args.data, "--no-cpu-baseline", "--no-uncoalesced", "--profile-iters", "0", "--verify", "0"]
+        if args.allow_knobs:
+            cmd.append("--allow-knobs")
+        try:
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=300).stdout.strip().splitlines()
+            d1 = json.loads(out[-1])
+            uncoalesced = {"value": d1["value"], "unit": d1["unit"], "steps": d1["steps"], "warmup": d1["warmup"],
+                           "ms_per_step": d1["ms_per_step"], "single_stream_batch_latency_ms": d1["single_stream_batch_latency_ms"],
+                           "note": "`bench.py --coalesce 1` in a process of its own right after the headline run: same pipeline "
+                                   "class, same kernels, one batch of %d frames per graph replay" % args.batch}
+        except Exception as e:  # noqa: BLE001 -- the secondary figure must not take the headline down
+            uncoalesced = {"error": repr(e)}
     if rank != 0:
         return None
     clock_mhz = MAX_CLOCK_MHZ
@@ -589,6 +610,7 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
         "hip_graphs": use_graphs,
         "env_knobs": env_knobs()[0],
         "verify": verify,
+        "uncoalesced": uncoalesced,
         "mlp_rows_per_step": rows,
         "overlap": overlap,
     }
@@ -785,6 +807,7 @@ def main():
     ap.add_argument("--profile-iters", type=int, default=3)
     ap.add_argument("--graphs", type=int, default=1, help="1 (default): one captured hipGraph per slot; 0: eager launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-uncoalesced", action="store_true", help="skip the secondary coalesce=1 measurement of the backbone workload")
     ap.add_argument("--allow-knobs", action="store_true", help="run although SA_* / SA3D_* environment variables are set (recorded in the line)")
     ap.add_argument("--allow-shared-device", action="store_true",
                     help="--gpus N with fewer than N GPUs visible: ranks share devices (functional check of the multi-rank path)")

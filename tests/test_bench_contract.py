@@ -43,6 +43,13 @@ def test_bench_line_has_the_contract_fields(name):
     assert not [k for k in d["env_knobs"] if k.startswith("SA_")]
 
 
+def test_default_line_reports_the_uncoalesced_executor_beside_the_headline():
+    d = _line()
+    u = d["uncoalesced"]
+    assert u["unit"] == d["unit"] and u["steps"] >= 100 and 0 < u["value"] < d["value"]     # coalescing is what it says
+    assert abs(u["value"] - d["config"]["frames_per_step_per_gpu"] / (u["ms_per_step"] * 1e-3)) / u["value"] < 1e-3
+
+
 def test_default_line_cpu_baseline_and_ramp_flag():
     d = _line()
     c = d["cpu_baseline"]

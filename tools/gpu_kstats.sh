@@ -2,7 +2,7 @@
 # per-kernel average durations of one single-stream bench run (rocprofv3 --kernel-trace --stats); $1 = tag, $2 = grep filter
 TAG=${1:-ks}; OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp PYTHONUNBUFFERED=1
-CMD="python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --streams 1 --no-cpu-baseline --profile-iters 1 --verify 0 ${BENCH_EXTRA}"
+CMD="python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --streams 1 --no-cpu-baseline --no-uncoalesced --profile-iters 1 --verify 0 ${BENCH_EXTRA}"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $CMD > $OUT/trace.log 2>&1
 cd $GRAFT_REPO_ROOT

@@ -4,7 +4,7 @@
 TAG=$1; FILT=$2; shift 2
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp PYTHONUNBUFFERED=1
-CMD="python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --streams 1 --no-cpu-baseline --profile-iters 0 --verify 0 ${BENCH_EXTRA}"
+CMD="python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --streams 1 --no-cpu-baseline --no-uncoalesced --profile-iters 0 --verify 0 ${BENCH_EXTRA}"
 cd /tmp
 i=0
 for pass in "$@"; do

@@ -20,7 +20,7 @@ except Exception as e:
 P
 }
 echo "== bench default"; timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; show default
-for i in 2 3; do timeout 300 python bench.py --no-cpu-baseline --profile-iters 0 --verify 0 | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('default again', d['value'], d['ms_per_step'])"; done
+for i in 2 3; do timeout 300 python bench.py --no-cpu-baseline --no-uncoalesced --profile-iters 0 --verify 0 | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('default again', d['value'], d['ms_per_step'])"; done
 echo "== bench 20 steps"; timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_20steps.json 2> $OUT/bench_20steps.err; show 20steps
 for v in dup10 dense; do timeout 600 python bench.py --data $v --no-cpu-baseline > $OUT/bench_$v.json 2> $OUT/bench_$v.err; show $v; done
 timeout 600 python bench.py --gpus 2 --allow-shared-device --steps 64 --warmup 16 --no-cpu-baseline > $OUT/bench_2ranks_shared.json 2> $OUT/bench_2ranks_shared.err; show 2ranks_shared

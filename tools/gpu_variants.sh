@@ -4,7 +4,7 @@ TAG=$1; shift; OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp PYTHONUNBUFFERED=1
 for v in "$@"; do
   if [ "$v" = "base" ]; then unset SA3D_LIB; K=""; else export SA3D_LIB=$GRAFT_REPO_ROOT/3dssd_amd/csrc/variants/lib_$v.so; K="--allow-knobs"; fi
-  timeout 300 python bench.py --steps 8 --warmup 2 --streams 1 --no-cpu-baseline --profile-iters 5 --verify 2 $K ${BENCH_EXTRA} > $OUT/$v.json 2> $OUT/$v.err
+  timeout 300 python bench.py --steps 8 --warmup 2 --streams 1 --no-cpu-baseline --no-uncoalesced --profile-iters 5 --verify 2 $K ${BENCH_EXTRA} > $OUT/$v.json 2> $OUT/$v.err
   python - <<P
 import json
 try:
