@@ -146,7 +146,8 @@ int sa_query_ball_point_grid(int b, int n, int m, int nbands, const float *rmin,
  * Only the DISTINCT rows of a ball are evaluated: the ball query pads a ball of cnt < nsample points with copies of
  * its first hit (tf_grouping_g.cu:245-248), those rows give identical outputs and the max ignores them -- same
  * result bit for bit, a fraction of the work on KITTI-like clouds (3dssd_amd/csrc/mlp_plan.h).  ws: caller-owned
- * device scratch of sa_group_mlp_max_ws_bytes(b, m, ns) bytes (the per-call row plan).  flags bit 0: evaluate all
+ * device scratch of sa_group_mlp_max_ws_bytes(b, m, ns) bytes (the per-call row plan: header, one entry per 8-row
+ * granule of the densest plan, one summary per 4096 balls).  flags bit 0: evaluate all
  * nsample rows of every ball instead (A/B measurements); bit 1: the plan in ws was built by sa_group_mlp_plan;
  * bit 2: wpack[] holds single-plane fp16 fragments and the scale runs one fp16 MFMA pass per k-step (fp32
  * accumulate) instead of the three split-bf16 passes -- chosen per scale by the host (utils/weights.py).
@@ -188,7 +189,8 @@ int sa_group_mlp_max_layer(int nscale, int b, int n, int m, const int *ns, int c
                            const int *out_off, void *const *ws, const unsigned long *ws_bytes, const int *flags,
                            int *overflow, sa_stream_t stream);
 
-/* y[rows,N] = act(x[rows,K] W + b): tf_util.conv1d 1x1 + folded BN (tf_util.py:51-124). */
+/* y[rows,N] = act(x[rows,K] W + b): tf_util.conv1d 1x1 + folded BN (tf_util.py:51-124).  Two kernels, the same bits:
+ * 32-row workgroups, and 128-row x 128-column blocks when K % 192 == 0, N % 128 == 0 and there are >= 192 blocks. */
 int sa_dense(long rows, int K, int N, const float *x, const void *wpack, const float *bias, int relu,
              float *y, sa_stream_t stream);
 
