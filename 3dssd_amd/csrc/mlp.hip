@@ -1721,7 +1721,8 @@ extern "C" int sa_dense(long rows, int K, int N, const float *x, const void *wpa
     P.L.KS = roundup(K, 16) / 16;
     P.L.NT = roundup(N, 32) / 32;
     // wide layers with enough rows to give every CU a 128 x 128 block: the 128-row kernel (same bits)
-    if (K % (kD128KC * kD128PD) == 0 && N % 128 == 0 && ((rows + 127) / 128) * (N / 128) >= 192 && rows < (1l << 31)) {
+    if (K % (kD128KC * kD128PD) == 0 && N % 128 == 0 && ((rows + 127) / 128) * (N / 128) >= 192 && rows < (1l << 31) &&
+        (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {          // 16-byte row pieces in and out
 #ifndef SA_D128_NW
 #define SA_D128_NW 8                     // 4: one wave per (column tile), four row tiles per fragment
 #endif
