@@ -926,7 +926,7 @@ __global__ __launch_bounds__(kDThreads) void dense_kernel(DenseParams P) {
 //      waves, wave = (column tile, row half), a weight fragment feeds two row tiles; the contraction runs in chunks of
 //      64 channels through a double-buffered LDS image of the rows (chunk c + 1 staged in front of the matrix work on
 //      chunk c, one LDS-only barrier per chunk), and both streams -- the fp32 rows and the weight fragments -- are
-//      requested kD128PD chunks ahead into register rings (branch-free blocks, prologue values laundered: see
+//      requested PD chunks ahead into register rings (branch-free blocks, prologue values laundered: see
 //      mlp_wide128.hip; a ring slot is refilled AFTER its MFMAs so that no fragment is copied).  Same arithmetic as
 //      dense_kernel (bias in the accumulator, k ascending, the three split-bf16 passes in the same order, D^T form):
 //      bit-identical output.  75 / 47 / 32 us -> 54 / 35 / 24 us for the three layers above.  What bounds it now: the
@@ -936,28 +936,27 @@ __global__ __launch_bounds__(kDThreads) void dense_kernel(DenseParams P) {
 //      overlap its LDS round trips with: 58 us.  Measured on the way: removing the MFMAs saves 11 us, either stream
 //      12 us; hipcc left alone reuses one register pair for the LDS operand fragments (a round trip in front of every
 //      three MFMAs) -- the sched_group_barrier pipeline below fixes the ISA but not the time, the L2 does.
-#ifndef SA_D128_PD
-#define SA_D128_PD 3
-#endif
-constexpr int kD128KC = 64, kD128PD = SA_D128_PD;
+constexpr int kD128KC = 64;
 constexpr int kD128Stride = kD128KC * 4 + 16;                 // bytes of a row in one LDS buffer (hi / lo planes, padded)
 constexpr size_t kD128Lds = (size_t)2 * 128 * kD128Stride;
 typedef unsigned d128_u32x4 __attribute__((ext_vector_type(4)));
 typedef float d128_f32x4 __attribute__((ext_vector_type(4)));
 
-template <int NW>
+// NW waves, CT column tiles per workgroup (4: 128 columns, 2: 64), PD chunks of lookahead (K % (64 * PD) == 0)
+template <int NW, int CT, int PD>
 __global__ __launch_bounds__(NW * 64, NW / 4) void dense128_kernel(DenseParams P) {
-    constexpr int RT = 16 / NW;                               // row tiles per wave: 4 (four waves) or 2 (eight)
+    constexpr int RT = 4 * CT / NW;                           // row tiles per wave
+    static_assert(RT >= 1 && RT * NW == 4 * CT, "waves = column tiles x row parts");
     constexpr int NI = 1024 / (NW * 64);                      // (row, 8-channel group) items a thread stages per chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, col = lane & 31;
     const LayerDesc &L = P.L;
-    const int ct = blockIdx.y * 4 + (w & 3);                  // this wave's column tile (host: NT % 4 == 0)
-    const int rt0 = (w >> 2) * RT;                            // ... and its first row tile of the block
+    const int ct = blockIdx.y * CT + (w % CT);                // this wave's column tile (host: NT % CT == 0)
+    const int rt0 = (w / CT) * RT;                            // ... and its first row tile of the block
     const long r0 = (long)blockIdx.x * 128;
-    const int nch = L.K / kD128KC;                            // host: K % (64 * kD128PD) == 0
+    const int nch = L.K / kD128KC;                            // host: K % (64 * PD) == 0
 
     // this thread's (row, 8-channel group) items of a chunk: rows past the end read the last row, never stored
     const float *sp[NI];
@@ -980,10 +979,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void dense128_kernel(DenseParams P
         }
     }
     const d128_u32x4 *wb = (const d128_u32x4 *)L.w + (size_t)ct * L.KS * 128 + lane;
-    d128_f32x4 xa[kD128PD][NI][2];
-    d128_u32x4 wq[kD128PD][4][2];
+    d128_f32x4 xa[PD][NI][2];
+    d128_u32x4 wq[PD][4][2];
 #pragma unroll
-    for (int d = 0; d < kD128PD; ++d) {
+    for (int d = 0; d < PD; ++d) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             xa[d][j][0] = *(const d128_f32x4 *)(sp[j] + d * kD128KC);
@@ -996,14 +995,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void dense128_kernel(DenseParams P
         }
     }
 #pragma unroll
-    for (int d = 0; d < kD128PD; ++d) {
+    for (int d = 0; d < PD; ++d) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) asm volatile("" : "+v"(xa[d][j][0]), "+v"(xa[d][j][1]));
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(wq[d][ks][0]), "+v"(wq[d][ks][1]));
     }
     // stage(slot, chunk to refill with, buffer): the ring slot's fp32 rows -> split bf16 planes -> LDS, then the slot is
-    // requested again kD128PD chunks ahead (clamped at the end: harmless re-reads)
+    // requested again PD chunks ahead (clamped at the end: harmless re-reads)
     auto stage = [&](d128_f32x4 (&xs)[NI][2], int refill, unsigned char *dst) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
@@ -1020,17 +1019,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void dense128_kernel(DenseParams P
             xs[j][1] = *(const d128_f32x4 *)(sp[j] + cn * kD128KC + 4);
         }
     };
-    stage(xa[0], kD128PD, smem);
+    stage(xa[0], PD, smem);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");              // LDS-only barrier: the rings stay in flight
     // Chunk c + 1 is staged into the other buffer in front of the matrix work on chunk c: one barrier per chunk.
-    for (int c0 = 0; c0 < nch; c0 += kD128PD) {
+    for (int c0 = 0; c0 < nch; c0 += PD) {
 #pragma unroll
-        for (int d = 0; d < kD128PD; ++d) {
+        for (int d = 0; d < PD; ++d) {
             const int c = c0 + d;
-            const int dn = (d + 1) % kD128PD;                 // ring slot of chunk c + 1
+            const int dn = (d + 1) % PD;                 // ring slot of chunk c + 1
             const unsigned char *buf = smem + (c & 1) * (128 * kD128Stride);
             unsigned char *bufn = smem + ((c + 1) & 1) * (128 * kD128Stride);
-            stage(xa[dn], c + 1 + kD128PD, bufn);
+            stage(xa[dn], c + 1 + PD, bufn);
             // The matrix work of the chunk as its own scheduling region with an explicit pipeline: left alone, hipcc reuses
             // ONE pair of registers for the operand fragments (ds_read x2 -> wait -> 3 MFMA -> ds_read x2 ...: an LDS round
             // trip in front of every three MFMAs, ~2 000 cycles per chunk against 770 of matrix issue); here the fragments
@@ -1061,10 +1060,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void dense128_kernel(DenseParams P
                 __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            // the ring slot of the weight fragments is requested again (kD128PD chunks ahead, clamped) once its MFMAs are
+            // the ring slot of the weight fragments is requested again (PD chunks ahead, clamped) once its MFMAs are
             // issued: no copy of the fragments, and the loads of a slot are consumed in the order they were issued
             {
-                const int cn = c + kD128PD < nch ? c + kD128PD : nch - 1;
+                const int cn = c + PD < nch ? c + PD : nch - 1;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     wq[d][ks][0] = wb[(cn * 4 + ks) * 128];
@@ -1720,18 +1719,26 @@ extern "C" int sa_dense(long rows, int K, int N, const float *x, const void *wpa
     P.L.w = (const uint4 *)wpack; P.L.bias = bias; P.L.K = K; P.L.N = N;
     P.L.KS = roundup(K, 16) / 16;
     P.L.NT = roundup(N, 32) / 32;
-    // wide layers with enough rows to give every CU a 128 x 128 block: the 128-row kernel (same bits)
-    if (K % (kD128KC * kD128PD) == 0 && N % 128 == 0 && ((rows + 127) / 128) * (N / 128) >= 192 && rows < (1l << 31) &&
-        (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {          // 16-byte row pieces in and out
-#ifndef SA_D128_NW
-#define SA_D128_NW 8                     // 4: one wave per (column tile), four row tiles per fragment
-#endif
-        auto kern = dense128_kernel<SA_D128_NW>;
-        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kD128Lds);
-        (void)hipGetLastError();
-        hipLaunchKernelGGL(kern, dim3((unsigned)((rows + 127) / 128), N / 128), dim3(SA_D128_NW * 64), kD128Lds, stream, P);
-        SA_CHECK_LAUNCH();
-        return SA_OK;
+    // layers with enough rows to give every CU a 128-row block: the 128-row kernel (same bits).  128-column blocks with
+    // three chunks of lookahead where the shape allows, 64-column blocks with two for the narrow 128 -> 64 layer
+    if (rows < (1l << 31) && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {      // 16-byte row pieces in and out
+        const long blocks = (rows + 127) / 128;
+        if (K % (kD128KC * 3) == 0 && N % 128 == 0 && blocks * (N / 128) >= 192) {
+            auto kern = dense128_kernel<8, 4, 3>;
+            (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kD128Lds);
+            (void)hipGetLastError();
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks, N / 128), dim3(512), kD128Lds, stream, P);
+            SA_CHECK_LAUNCH();
+            return SA_OK;
+        }
+        if (K % (kD128KC * 2) == 0 && N % 64 == 0 && N % 128 != 0 && blocks * (N / 64) >= 512) {
+            auto kern = dense128_kernel<8, 2, 2>;
+            (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kD128Lds);
+            (void)hipGetLastError();
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks, N / 64), dim3(512), kD128Lds, stream, P);
+            SA_CHECK_LAUNCH();
+            return SA_OK;
+        }
     }
     P.KC = P.L.KS * 16 < 256 ? P.L.KS * 16 : 256;
     P.stride = P.KC * 4 + 16;

@@ -358,8 +358,9 @@ def case_mlp_big(rng):
 def case_dense_blocks(rng):
     """sa_dense on the 128-row block kernel (K a multiple of 192, N of 128, >= 192 blocks) against the 32-row kernel on
     pieces of the same rows (identical bits) and against the oracle on a sample of rows"""
-    K, N_ = [(384, 128), (768, 256), (1536, 512), (192, 128), (576, 384)][int(rng.integers(0, 5))]
-    blocks = int(rng.integers(192, 260)) // (N_ // 128) + 1
+    K, N_ = [(384, 128), (768, 256), (1536, 512), (192, 128), (576, 384), (128, 64), (256, 192)][int(rng.integers(0, 7))]
+    wide = N_ % 128 == 0
+    blocks = (int(rng.integers(192, 260)) // (N_ // 128) + 1) if wide else (int(rng.integers(512, 600)) // (N_ // 64) + 1)
     rows = blocks * 128 - int(rng.integers(0, 128))
     relu = int(rng.integers(0, 2))
     x = rng.normal(0, 1, (rows, K)).astype(np.float32)
@@ -371,7 +372,7 @@ def case_dense_blocks(rng):
     y = torch.full((rows + 1, N_), -5.0, dtype=torch.float32, device=dev)
     y2 = torch.full((rows + 1, N_), -5.0, dtype=torch.float32, device=dev)
     ok = lib.sa_dense(rows, K, N_, tx.data_ptr(), L.w.data_ptr(), L.bias.data_ptr(), relu, y.data_ptr(), st) == 0
-    piece = (191 // (N_ // 128)) * 128
+    piece = (191 // (N_ // 128)) * 128 if wide else (511 // (N_ // 64)) * 128
     for a in range(0, rows, piece):
         n = min(piece, rows - a)
         ok = ok and lib.sa_dense(n, K, N_, tx.data_ptr() + 4 * K * a, L.w.data_ptr(), L.bias.data_ptr(), relu,

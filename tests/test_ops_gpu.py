@@ -1015,7 +1015,8 @@ def test_group_mlp_layer4_scale0_eight_wave_form_matches_the_four_wave_form(gpu,
     assert (both[cnt == 0] == 0).all()
 
 
-@pytest.mark.parametrize("rows,K,N,relu", [(25000, 384, 128, True), (12300, 768, 256, True), (6200, 1536, 512, False)])
+@pytest.mark.parametrize("rows,K,N,relu", [(25000, 384, 128, True), (12300, 768, 256, True), (6200, 1536, 512, False),
+                                           (66000, 128, 64, True)])
 def test_dense_128_row_blocks_equal_the_32_row_kernel(gpu, oracle, rows, K, N, relu):
     # sa_dense takes 128-row x 128-column blocks (csrc/mlp.hip dense128_kernel) when K is a multiple of 192, N of 128 and
     # there are >= 192 blocks -- the aggregation layers of a 32-frame replay.  Same arithmetic as the 32-row kernel: the
@@ -1023,7 +1024,9 @@ def test_dense_128_row_blocks_equal_the_32_row_kernel(gpu, oracle, rows, K, N, r
     # 128 (ragged last block) and the output is checked against the oracle on a sample.
     N_ = pkg("utils._native")
     Wt = pkg("utils.weights")
-    assert K % 192 == 0 and N % 128 == 0 and -(-rows // 128) * (N // 128) >= 192
+    # (the narrow 128 -> 64 aggregation layer takes 128-row x 64-column blocks from 512 blocks on)
+    wide = N % 128 == 0
+    assert (K % 192 == 0 and -(-rows // 128) * (N // 128) >= 192) if wide else (K % 128 == 0 and N % 64 == 0 and -(-rows // 128) * (N // 64) >= 512)
     rng = np.random.default_rng(rows + K)
     x = rng.normal(0, 1, (rows, K)).astype(np.float32)
     w = rng.normal(0, 1 / np.sqrt(K), (K, N)).astype(np.float32)
@@ -1033,7 +1036,7 @@ def test_dense_128_row_blocks_equal_the_32_row_kernel(gpu, oracle, rows, K, N, r
     lib, st = N_.lib(), N_.current_stream()
     y = torch.full((rows + 1, N), -5.0, dtype=torch.float32, device=gpu)       # one guard row behind the output
     assert lib.sa_dense(rows, K, N, tx.data_ptr(), L.w.data_ptr(), L.bias.data_ptr(), int(relu), y.data_ptr(), st) == 0
-    piece = (191 // (N // 128)) * 128                                          # at most 191 blocks: the 32-row kernel
+    piece = (191 // (N // 128)) * 128 if wide else (511 // (N // 64)) * 128    # too few blocks: the 32-row kernel
     y2 = torch.full((rows + 1, N), -5.0, dtype=torch.float32, device=gpu)
     for a in range(0, rows, piece):
         n = min(piece, rows - a)
