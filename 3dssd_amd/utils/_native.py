@@ -63,15 +63,20 @@ SIGNATURES = {
     "sa_farthest_point_sample_with_preidx": [_c_int] * 5 + [_vp, _vp, _vp, _vp, _vp],
     "sa_three_interpolate_grad": [_c_int] * 4 + [_vp, _vp, _vp, _vp, _vp],
     "sa_k_interpolate_grad": [_c_int] * 5 + [_vp, _vp, _vp, _vp, _vp],
+}
+
+# lib3dssd_extra.so (include/sa_extra.h): the reference's operators outside the set-abstraction path, frozen
+EXTRA_LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "lib3dssd_extra.so")
+EXTRA_SIGNATURES = {
     "sa_points_pooling": [_c_int] * 8 + [_vp] * 8,
-    "sa_prob_sample": [_c_int] * 3 + [_vp] * 5,
+    "sa_points_pooling_grad": [_c_int] * 8 + [_vp] * 5,
     "sa_calc_iou": [_c_int] * 3 + [_vp] * 5,
     "sa_calc_iou_match": [_c_int] + [_vp] * 5,
-    "sa_points_pooling_grad": [_c_int] * 8 + [_vp] * 5,
 }
 
 _ERRORS = {-1: "invalid argument", -2: "kernel launch failed (hipGetLastError)", -3: "unsupported size"}
 _LIB = None
+_EXTRA = None
 
 
 class NativeLibraryError(RuntimeError):
@@ -107,6 +112,23 @@ def lib():
         h.sa_host_crc32c.restype = ctypes.c_uint32
         _LIB = h
     return _LIB
+
+
+def lib_extra():
+    """Load lib3dssd_extra.so (`make extra`): points pooling and the evaluation IoU, not part of the hot path."""
+    global _EXTRA
+    if _EXTRA is None:
+        if not os.path.exists(EXTRA_LIB_PATH):
+            raise NativeLibraryError("HIP extension not built: %s is missing (make -C 3dssd_amd/csrc extra). "
+                                     "There is no CPU fallback." % EXTRA_LIB_PATH)
+        import torch  # noqa: F401  (same reason as in lib())
+        h = ctypes.CDLL(EXTRA_LIB_PATH)
+        for name, argtypes in EXTRA_SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.argtypes = argtypes
+            fn.restype = _c_int
+        _EXTRA = h
+    return _EXTRA
 
 
 def check(status, what):

@@ -19,7 +19,7 @@ def calc_iou(detections, groundtruths):
     gn = groundtruths.shape[1]
     bev = torch.empty((bs, dn, gn), dtype=torch.float32, device=detections.device)
     i3d = torch.empty((bs, dn, gn), dtype=torch.float32, device=detections.device)
-    N.check(N.lib().sa_calc_iou(bs, dn, gn, detections.data_ptr(), groundtruths.data_ptr(), bev.data_ptr(), i3d.data_ptr(),
+    N.check(N.lib_extra().sa_calc_iou(bs, dn, gn, detections.data_ptr(), groundtruths.data_ptr(), bev.data_ptr(), i3d.data_ptr(),
                                 N.current_stream()), "calc_iou")
     return bev, i3d
 
@@ -32,7 +32,7 @@ def calc_iou_match(detections, groundtruths):
     T.require(tuple(groundtruths.shape) == (n, 7), "Calculate IoU expects (-1, 7) gt shape")
     bev = torch.empty((n,), dtype=torch.float32, device=detections.device)
     i3d = torch.empty((n,), dtype=torch.float32, device=detections.device)
-    N.check(N.lib().sa_calc_iou_match(n, detections.data_ptr(), groundtruths.data_ptr(), bev.data_ptr(), i3d.data_ptr(),
+    N.check(N.lib_extra().sa_calc_iou_match(n, detections.data_ptr(), groundtruths.data_ptr(), bev.data_ptr(), i3d.data_ptr(),
                                       N.current_stream()), "calc_iou_match")
     return bev, i3d
 

@@ -27,7 +27,7 @@ def points_pooling(pc, box_3d, pc_loc, l=7, h=7, w=7, sample_num=35):
     idx = torch.empty((bs, pn, l, h, w, sample_num), dtype=torch.int32, device=dev)
     num = torch.empty((bs, pn, l, h, w), dtype=torch.int32, device=dev)
     pillars = torch.empty((bs, pn, l, h, w, 3), dtype=torch.float32, device=dev)
-    N.check(N.lib().sa_points_pooling(bs, pn, pts, c, l, h, w, sample_num, pc.data_ptr(), box_3d.data_ptr(), pc_loc.data_ptr(),
+    N.check(N.lib_extra().sa_points_pooling(bs, pn, pts, c, l, h, w, sample_num, pc.data_ptr(), box_3d.data_ptr(), pc_loc.data_ptr(),
                                       feats.data_ptr(), idx.data_ptr(), num.data_ptr(), pillars.data_ptr(),
                                       N.current_stream()), "points_pooling")
     return feats, idx, num, pillars
@@ -46,6 +46,6 @@ def points_pooling_grad(pc, out_idx, sampled_num_lists, features_grad):
     T.require(tuple(features_grad.shape) == (bs, pn, l, h, w, sample_num, c),
               "PointsPoolingGrad expects (bs, proposal_num, l, h, w, sample_num, channel) features_grad shape")
     out = torch.empty((bs, pn, pts, c), dtype=torch.float32, device=pc.device)
-    N.check(N.lib().sa_points_pooling_grad(bs, pn, pts, c, l, h, w, sample_num, out_idx.data_ptr(), sampled_num_lists.data_ptr(),
+    N.check(N.lib_extra().sa_points_pooling_grad(bs, pn, pts, c, l, h, w, sample_num, out_idx.data_ptr(), sampled_num_lists.data_ptr(),
                                            features_grad.data_ptr(), out.data_ptr(), N.current_stream()), "points_pooling_grad")
     return out

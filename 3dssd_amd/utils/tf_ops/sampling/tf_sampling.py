@@ -107,19 +107,3 @@ def farthest_point_sample_with_preidx(npoint, inp, preidx):
                                                          preidx.data_ptr(), temp.data_ptr(), out.data_ptr(),
                                                          N.current_stream()), "farthest_point_sample_with_preidx")
     return out
-
-
-def prob_sample(inp, inpr):
-    """Inverse-CDF sampling: inp [b,n] non-negative weights, inpr [b,m] uniform numbers in [0,1) -> int32 [b,m], the
-    first position whose cumulative weight reaches inpr * total (the reference's blocked cumulative sum, float for
-    float).   tf_sampling.py:8-17"""
-    inp, inpr = T.f32_cuda(inp, "inp"), T.f32_cuda(inpr, "inpr")
-    T.require(inp.dim() == 2, "ProbSample expects (batch_size,num_choices) inp shape")
-    b, n = inp.shape
-    T.require(inpr.dim() == 2 and inpr.shape[0] == b, "ProbSample expects (batch_size,num_points) inpr shape")
-    m = inpr.shape[1]
-    out = torch.empty((b, m), dtype=torch.int32, device=inp.device)
-    temp = torch.empty((b, n), dtype=torch.float32, device=inp.device)
-    N.check(N.lib().sa_prob_sample(b, n, m, inp.data_ptr(), inpr.data_ptr(), temp.data_ptr(), out.data_ptr(),
-                                   N.current_stream()), "prob_sample")
-    return out

@@ -651,69 +651,6 @@ void orc_points_pooling_grad(int bs, int proposal_num, int point_num, int c, int
             }
 }
 
-/* ==== prob_sample: tf_sampling_g.cu:24-121 (cumsumKernel + binarysearchKernel), serial emulation of the same tree ===== */
-#define PS_BLOCK 2048
-#define PS_PAD 5
-void orc_prob_sample(int b, int n, int m, const float *inp_p, const float *inp_r, float *temp, int *out) {
-    static float buffer4[PS_BLOCK * 4], buffer[PS_BLOCK + (PS_BLOCK >> PS_PAD)];
-    for (int i = 0; i < b; ++i) {
-        const float *row = inp_p + (size_t)i * n;
-        float *orow = temp + (size_t)i * n;
-        float runningsum = 0.0f, runningsum2 = 0.0f;
-        for (int j = 0; j < n; j += PS_BLOCK * 4) {
-            int n24_i = n - j < PS_BLOCK * 4 ? n - j : PS_BLOCK * 4;
-            int n24 = (n24_i + 3) & ~3, n2 = n24 >> 2;
-            for (int k = 0; k < n24_i; k += 4) {
-                if (k + 3 < n24_i) {                                   /* :33-47 */
-                    float v1 = row[j + k], v2 = row[j + k + 1];
-                    v2 += v1;
-                    float v3 = row[j + k + 2], v4 = row[j + k + 3];
-                    v4 += v3; v3 += v2; v4 += v2;
-                    buffer4[k] = v1; buffer4[k + 1] = v2; buffer4[k + 2] = v3; buffer4[k + 3] = v4;
-                    buffer[(k >> 2) + (k >> (2 + PS_PAD))] = v4;
-                } else {                                               /* :48-58 */
-                    float v = 0.0f;
-                    for (int k2 = k; k2 < n24_i; ++k2) { v += row[j + k2]; buffer4[k2] = v; }
-                    for (int k2 = n24_i; k2 < n24; ++k2) buffer4[k2] = v;
-                    buffer[(k >> 2) + (k >> (2 + PS_PAD))] = v;
-                }
-            }
-            int u = 0;
-            for (; (2 << u) <= n2; ++u)                                /* :60-70 */
-                for (int k = 0; k < (n2 >> (u + 1)); ++k) {
-                    int i1 = (((k << 1) + 2) << u) - 1, i2 = (((k << 1) + 1) << u) - 1;
-                    i1 += i1 >> PS_PAD; i2 += i2 >> PS_PAD;
-                    buffer[i1] += buffer[i2];
-                }
-            --u;
-            for (; u >= 0; --u)                                        /* :71-81 */
-                for (int k = 0; k < ((n2 - (1 << u)) >> (u + 1)); ++k) {
-                    int i1 = (((k << 1) + 3) << u) - 1, i2 = (((k << 1) + 2) << u) - 1;
-                    i1 += i1 >> PS_PAD; i2 += i2 >> PS_PAD;
-                    buffer[i1] += buffer[i2];
-                }
-            for (int k = 4; k < n24; k += 4) {                         /* :83-91 */
-                int k2 = ((k >> 2) - 1) + (((k >> 2) - 1) >> PS_PAD);
-                buffer4[k] += buffer[k2]; buffer4[k + 1] += buffer[k2]; buffer4[k + 2] += buffer[k2]; buffer4[k + 3] += buffer[k2];
-            }
-            for (int k = 0; k < n24_i; ++k) orow[j + k] = buffer4[k] + runningsum;      /* :93-95 */
-            float t = buffer[(n2 - 1) + ((n2 - 1) >> PS_PAD)] + runningsum2;            /* :96-99 */
-            float r2 = runningsum + t;
-            runningsum2 = t - (r2 - runningsum);
-            runningsum = r2;
-        }
-        int base = 1;
-        while (base < n) base <<= 1;
-        for (int j = 0; j < m; ++j) {                                  /* :105-121 */
-            float q = inp_r[(size_t)i * m + j] * orow[n - 1];
-            int r = n - 1;
-            for (int k = base; k >= 1; k >>= 1)
-                if (r >= k && orow[r - k] >= q) r -= k;
-            out[(size_t)i * m + j] = r;
-        }
-    }
-}
-
 /* ==== calc_iou / calc_iou_match: lib/utils/tf_ops/evaluation/evaluate.cpp:461-537,1161-1227 ====================== */
 /* The reference intersects boost::geometry polygons (not available here).  This restatement builds the
  * intersection polygon a different way than the HIP kernel (which clips edge by edge): the vertices of each rectangle

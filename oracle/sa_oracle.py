@@ -299,18 +299,6 @@ def points_pooling_grad(pc, out_idx, sampled_num_lists, features_grad):
     return out
 
 
-def prob_sample(inp, inpr, return_cumsum=False):
-    """tf_sampling.py:8-17 -> tf_sampling_g.cu:24-121."""
-    inp, pi = _f(inp)
-    inpr, pr = _f(inpr)
-    b, n = inp.shape
-    m = inpr.shape[1]
-    temp = np.empty((b, n), np.float32)
-    out = np.empty((b, m), np.int32)
-    lib().orc_prob_sample(b, n, m, pi, pr, temp.ctypes.data_as(_f32p), out.ctypes.data_as(_i32p))
-    return (out, temp) if return_cumsum else out
-
-
 def calc_iou(detections, groundtruths):
     """tf_evaluate.py:26-33 -> evaluate.cpp:1161-1194.  -> (iou_bev, iou_3d) [bs, det_num, gt_num]."""
     detections, pd = _f(detections)

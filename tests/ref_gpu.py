@@ -29,7 +29,6 @@ _SYMS = {
     "gatherpointLauncher": ("_Z19gatherpointLauncheriiiiPKfPKiPf", [_i] * 4 + [_p] * 3),
     "scatteraddpointLauncher": ("_Z23scatteraddpointLauncheriiiiPKfPKiPf", [_i] * 4 + [_p] * 3),
     "GatherByMaskLauncher": ("_Z20GatherByMaskLauncheriiiiPKfS0_Pf", [_i] * 4 + [_p] * 3),
-    "probsampleLauncher": ("_Z18probsampleLauncheriiiPKfS0_PfPi", [_i] * 3 + [_p] * 4),
     "queryBallPointLauncher": ("_Z22queryBallPointLauncheriiifiPKfS0_PiS1_", [_i] * 3 + [_f, _i] + [_p] * 4),
     "queryBallPointDilatedLauncher": ("_Z29queryBallPointDilatedLauncheriiiffiPKfS0_PiS1_",
                                       [_i] * 3 + [_f, _f, _i] + [_p] * 4),
@@ -136,15 +135,6 @@ class RefOps:
         out = torch.zeros((b, proposal_num, c), dtype=torch.float32, device=inp.device)
         self._run("GatherByMaskLauncher", b, n, c, proposal_num, inp, mask, out)
         return out
-
-    def prob_sample(self, inp, inpr):
-        inp, inpr = self._f32(inp), self._f32(inpr)
-        b, n = inp.shape
-        m = inpr.shape[1]
-        temp = torch.zeros((b, n), dtype=torch.float32, device=inp.device)
-        out = torch.zeros((b, m), dtype=torch.int32, device=inp.device)
-        self._run("probsampleLauncher", b, n, m, inp, inpr, temp, out)
-        return out, temp
 
     # -- grouping (tf_grouping.py)
     def query_ball_point(self, radius, nsample, xyz1, xyz2):

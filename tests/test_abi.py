@@ -12,8 +12,8 @@ import pytest
 from conftest import ROOT, pkg
 
 
-def _header_functions():
-    src = open(os.path.join(ROOT, "include", "sa_ops.h")).read()
+def _header_functions(name="sa_ops.h"):
+    src = open(os.path.join(ROOT, "include", name)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return re.findall(r"\b(?:int|unsigned long)\s+(sa_\w+)\s*\(", src)
 
@@ -26,6 +26,19 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 15
     for n in names:
         assert hasattr(h, n), "lib3dssd_sa.so does not export %s" % n
+
+
+def test_extra_library_is_separate_and_complete():
+    """The reference's out-of-scope operators (points pooling, evaluation IoU) live in lib3dssd_extra.so /
+    include/sa_extra.h; the product library exports none of them."""
+    native = pkg("utils._native")
+    assert os.path.exists(native.EXTRA_LIB_PATH), "lib3dssd_extra.so not built (make -C 3dssd_amd/csrc extra)"
+    h, product = ctypes.CDLL(native.EXTRA_LIB_PATH), ctypes.CDLL(native.LIB_PATH)
+    names = _header_functions("sa_extra.h")
+    assert sorted(names) == sorted(native.EXTRA_SIGNATURES)
+    for n in names:
+        assert hasattr(h, n) and not hasattr(product, n), n
+    native.lib_extra()
 
 
 def test_ctypes_table_matches_header():

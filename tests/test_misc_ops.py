@@ -168,43 +168,6 @@ def test_interpolate_grads_exact_on_dyadic_data_and_adjoint(gpu, oracle):
         I.three_interpolate_grad(_t(pts, gpu), _t(idx[:, :, :3], gpu), _t(w[:, :, :3], gpu), _t(gout[:, :-1], gpu))
 
 
-def test_oracle_prob_sample_known_answers(oracle):
-    w = np.array([[1, 2, 3, 4, 0, 0, 5, 1]], np.float32)             # cumsum 1 3 6 10 10 10 15 16
-    r = np.array([[0.0, 0.0624, 0.0626, 0.5, 0.62, 0.63, 0.9375, 0.99]], np.float32)
-    out, cs = oracle.prob_sample(w, r, return_cumsum=True)
-    assert cs.tolist() == [[1, 3, 6, 10, 10, 10, 15, 16]]
-    # q = r * 16: 0 -> 0 ; 0.9984 -> 0 ; 1.0016 -> 1 ; 8 -> 3 ; 9.92 -> 3 ; 10.08 -> 6 (zero-weight entries are skipped) ;
-    # 15 -> 6 ; 15.84 -> 7
-    assert out.tolist() == [[0, 0, 1, 3, 3, 6, 6, 7]]
-    # integer weights: every partial sum is exact, so the blocked tree equals numpy's cumsum, across several chunks
-    rng = np.random.default_rng(3)
-    big = rng.integers(0, 4, (2, 20000)).astype(np.float32)
-    _, cs = oracle.prob_sample(big, np.zeros((2, 1), np.float32), return_cumsum=True)
-    assert np.array_equal(cs, np.cumsum(big.astype(np.float64), -1).astype(np.float32))
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("b,n,m", [(2, 8, 8), (3, 1000, 300), (2, 8192, 1000), (2, 8193, 500), (1, 30001, 2000), (2, 3, 5), (1, 1, 4)])
-def test_prob_sample_matches_oracle(gpu, oracle, b, n, m):
-    S = pkg("utils.tf_ops.sampling.tf_sampling")
-    rng = np.random.default_rng(n + m)
-    w = rng.uniform(0, 1, (b, n)).astype(np.float32)                  # inexact sums: the summation order matters
-    w[:, rng.integers(0, n, max(1, n // 10))] = 0.0
-    r = rng.uniform(0, 1, (b, m)).astype(np.float32)
-    r[:, 0] = 0.0
-    got = S.prob_sample(_t(w, gpu), _t(r, gpu)).cpu().numpy()
-    ref = oracle.prob_sample(w, r)
-    assert got.dtype == np.int32 and np.array_equal(got, ref)
-    assert ref.min() >= 0 and ref.max() < n
-    # the cumulative sums themselves (the op's scratch), bit for bit
-    N = pkg("utils._native")
-    tw, tr = _t(w, gpu), _t(r, gpu)
-    temp = torch.empty((b, n), dtype=torch.float32, device=gpu)
-    out = torch.empty((b, m), dtype=torch.int32, device=gpu)
-    assert N.lib().sa_prob_sample(b, n, m, tw.data_ptr(), tr.data_ptr(), temp.data_ptr(), out.data_ptr(), N.current_stream()) == 0
-    assert np.array_equal(temp.cpu().numpy(), oracle.prob_sample(w, r, return_cumsum=True)[1])
-
-
 @pytest.mark.gpu
 def test_copy_blocks_matches_slicing(gpu):
     # sa_copy_blocks: up to four strided block copies in one launch == torch slicing + contiguous()
