@@ -4,7 +4,6 @@ the detection head (out of scope)."""
 import torch
 
 from .builder.layer_builder import LayerBuilder
-from .utils import layers_util
 from .utils import _native as N
 from .utils.tf_ops import _tensor as T
 from .utils.weights import VariableStore
@@ -17,9 +16,11 @@ class SABackbone:
         "bf16x3" = split bf16 everywhere (~1e-5 of fp32, no range limit), "fp16" = one pass wherever the weights fit."""
         self.device = torch.device(device)
         self.variables = params if isinstance(params, VariableStore) else VariableStore(params, self.device, precision)
-        layers_util.AGGREGATION_SA_FEATURE = bool(aggregation_sa_feature)
-        layers_util.MAX_TRANSLATE_RANGE = tuple(max_translate_range)
-        self.layers = [LayerBuilder(i, False, arch, variables=self.variables) for i in range(len(arch))]
+        # per instance (round 3 wrote them into layers_util's module attributes: two backbones shared the last value)
+        self.settings = {"aggregation_sa_feature": bool(aggregation_sa_feature),
+                         "max_translate_range": tuple(float(v) for v in max_translate_range)}
+        self.layers = [LayerBuilder(i, False, arch, variables=self.variables, settings=self.settings)
+                       for i in range(len(arch))]
 
     def split_input(self, point_cloud):
         """The two tf.slice of single_stage_detector.py:117-118 in one launch: [B,n,3+C] -> xyz [B,n,3], features [B,n,C]."""
@@ -46,6 +47,21 @@ class SABackbone:
         return xyz_list, feature_list, fps_idx_list
 
     __call__ = forward
+
+    def forward_staged(self, point_cloud):
+        """forward() as a generator with ONE yield, between the sampling half of the first row (input split + layer-1
+        D-FPS + centres: a latency-bound chain on one CU per frame) and everything else: the staged executor
+        (pipeline.py) enqueues / captures the two halves on different streams.  The generator's return value
+        (StopIteration.value) is forward()'s result; the kernels and their order are exactly forward()'s."""
+        l0_xyz, l0_points = self.split_input(point_cloud)
+        xyz_list, feature_list, fps_idx_list = [l0_xyz], [l0_points], [None]
+        pre = self.layers[0].sample(xyz_list, feature_list, fps_idx_list)
+        yield
+        out = {}
+        for i, layer in enumerate(self.layers):
+            xyz_list, feature_list, fps_idx_list = layer.build_layer(xyz_list, feature_list, fps_idx_list, None, out,
+                                                                     presampled=pre if i == 0 else None)
+        return xyz_list, feature_list, fps_idx_list
 
     def raise_if_overflow(self):
         """The fp16 scales guard their operand range (csrc/mlp_act.h); forward() does not synchronise, so the check is

@@ -4,33 +4,35 @@ overlap of batches at all, lib/core/evaluator.py:94-135).
 
 Why it exists: the layer-1 D-FPS is a 4 095-step dependent chain that keeps ONE compute unit per frame busy for
 ~3 ms, so one batch of 8 frames alone uses 8 of the 256 CUs most of the time.  Throughput comes from overlapping
-the chains of different batches: N HIP streams, each with its own captured hipGraph of the whole backbone, its own
-STATIC input buffer and its own intermediate / output buffers.  `submit(batch)` copies the batch into the next
-slot's input buffer (one `sa_copy_blocks` launch on the slot's stream) and replays that slot's graph; it returns
-a `Ticket` whose `result()` waits for that batch only.
+the sampler chains of some frames with the chip-filling kernels (ball queries, grouped MLPs, distance matrices) of
+others.  A PACKAGE is `coalesce` consecutive batches in one static input buffer, run through the backbone in one
+pass (frames never interact: every kernel indexes its frame only).  Two ways to overlap packages:
+
+  mode="staged" (default)  three HIP streams, software-pipelined inside the executor.  A package is TWO captured
+      hipGraphs: stage A = input split + layer-1 D-FPS + centres (SABackbone.forward_staged up to its yield) on the
+      sampler stream S; stage B = everything else on one of two main streams M0 / M1, behind an event.  S runs
+      stage A of package k+1 / k+2 while M0 / M1 run stage B of packages k / k+1.  Needs 3 hardware queues (+ the
+      in-graph helper branch of the F-FPS ‖ D-FPS launch): ROCm's DEFAULT of 4 is enough, no environment variable.
+  mode="slots"  `streams` slots, each a HIP stream with one captured hipGraph of the whole backbone (rounds 2-3).
+      Needs as many hardware queues as slots (`request_hw_queues(16)` BEFORE the HIP runtime starts), and collapses
+      when it does not get them (measured: profiles/r04_sweep_queues.txt).
 
     pipe = SAPipeline(arch, params, "cuda:0", batch=8, points=16384)
-    t = [pipe.submit(b) for b in batches]          # up to `streams` batches run concurrently
-    xyz, feat = t[0].result(copy=True)             # [B,256,3], [B,256,512]
+    t = [pipe.submit(b) for b in batches]          # returns at once; packages launch as they fill
+    xyz, feat = t[0].result(copy=True)             # [B,256,3], [B,256,512]; launches a partly filled package first
 
 Slots are reused round-robin: the tensors a ticket hands out are the slot's static output buffers and stay valid
-until `streams` further submits (use copy=True, or pass out=(xyz, feat) to `submit`, to keep them longer);
-`result()` raises if the slot was already reused.  Nothing here is a collective: on a multi-GPU node every rank
-owns one pipeline and its share of the frames (sharding.py).
-
-`coalesce=C` (default 1): a slot takes C consecutive batches before it is launched -- its input buffer holds C x B
-frames and its graph is the backbone over all of them, so C x B sampler chains (one CU each) share one trip through the
-slot's hardware queue.  The 16 hardware queues bound the number of chains in flight, not the kernels: at B = 8 the
-steady rate goes 10.7 -> 13.2 (C = 2) -> 14.9 k frames/s (C = 4) while a replay alone takes 4.4 -> 4.8 -> 5.7 ms
-(DESIGN.md section 5).  Frames never interact (every kernel indexes its frame only), so a batch's result does not
-depend on which batches it shares a replay with; a slot that is only partly filled is launched by `flush()`,
-`drain()` or the first `result()` / `wait()` on one of its tickets, its unfilled parts computing on stale frames.
+until the slot's next round starts (`nslots x coalesce` further submits; use copy=True, or pass out=(xyz, feat) to
+`submit`, to keep them longer); `result()` raises if the slot was already reused.  A package that is only partly
+filled is launched by `flush()`, `drain()` or the first `result()` / `wait()` on one of its tickets; its unfilled
+parts are zeroed first.  Lifetime rule for inputs: `submit` copies the batch on an executor stream; a CUDA batch is
+`record_stream`-ed there, so the caller may drop it right after `submit`.  fp16 range guard (csrc/mlp_act.h): every
+round of a slot has its own flag word, zeroed on the slot's stream before the round and copied to pinned host memory
+after it -- a ticket raises for ITS package only.  Nothing here is a collective: on a multi-GPU node every rank owns
+one pipeline and its share of the frames (sharding.py).
 """
 import os
-
-# The slots live on different HIP streams; the ROCm default of 4 hardware queues would serialise them (measured:
-# 16 queues = 1.6x the throughput of 4).  Only effective when set before the HIP runtime starts, hence at import.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+import warnings
 
 import torch
 
@@ -38,91 +40,141 @@ from .backbone import SABackbone
 from .utils import _native as N
 from .utils.tf_ops import _tensor as T
 
-DEFAULT_STREAMS = 16
+DEFAULT_STREAMS = 16          # mode="slots"
+DEFAULT_PACKAGES = 4          # mode="staged": packages in the ring (>= main streams + 1 so that stage A runs ahead)
+MAIN_STREAMS = 2              # mode="staged"
+_FLAG_RING = 4096
+
+
+def request_hw_queues(n):
+    """mode="slots" wants one hardware queue per slot; ROCm's default is 4.  GPU_MAX_HW_QUEUES is read when the HIP
+    runtime starts, so this must run before the first CUDA call of the process (bench.py calls it first thing; a
+    server sets the variable in its launcher).  Returns True when the setting can still take effect."""
+    if torch.cuda.is_initialized():
+        if os.environ.get("GPU_MAX_HW_QUEUES") != str(n):
+            warnings.warn("GPU_MAX_HW_QUEUES=%s cannot take effect: the HIP runtime is already initialised (%s hardware "
+                          "queues); streams beyond that share queues" % (n, os.environ.get("GPU_MAX_HW_QUEUES", "4")))
+            return False
+        return True
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(n))
+    return os.environ["GPU_MAX_HW_QUEUES"] == str(n)
+
+
+def hw_queues():
+    """Hardware queues this process's HIP runtime was started with (what GPU_MAX_HW_QUEUES said then; 4 if unset)."""
+    try:
+        return int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    except ValueError:
+        return 4
+
+
+class _Round:
+    """One use of a slot: the package of up to `coalesce` batches that is launched together."""
+    __slots__ = ("slot", "fill", "launched", "event", "flag", "outs", "marks")
+
+    def __init__(self, slot, flag):
+        self.slot, self.fill, self.launched, self.event, self.flag, self.outs, self.marks = slot, 0, False, None, flag, [], None
 
 
 class Ticket:
-    """One submitted batch.  `result()` blocks the host until THIS batch is complete (and launches its slot first
-    when the slot is still waiting for further batches to coalesce)."""
-    __slots__ = ("_slot", "_seq", "_part", "_out")
+    """One submitted batch.  `result()` blocks the host until THIS batch's package is complete (and launches the
+    package first when it is still waiting for further batches)."""
+    __slots__ = ("_round", "_part", "_out")
 
-    def __init__(self, slot, seq, part, out):
-        self._slot, self._seq, self._part, self._out = slot, seq, part, out
-
-    def _launched(self):
-        s = self._slot
-        return s.seq > self._seq or (s.seq == self._seq and s.launched)
+    def __init__(self, rnd, part, out):
+        self._round, self._part, self._out = rnd, part, out
 
     def done(self):
-        return self._launched() and (self._slot.seq > self._seq or self._slot.event.query())
+        r = self._round
+        return bool(r.launched and r.event.query())
 
     def wait(self):
-        s = self._slot
-        if s.seq == self._seq and not s.launched:
-            s.pipe._launch(s)
-        s.event.synchronize()        # (a slot that was reused since: its newer event is later on the same stream)
+        r = self._round
+        if not r.launched:
+            r.slot.pipe._launch(r.slot)
+        r.event.synchronize()
         return self
 
+    def _stale(self):
+        return self._round.slot.round is not self._round
+
     def _views(self):
-        s, B = self._slot, self._slot.pipe.batch
+        s, B = self._round.slot, self._round.slot.pipe.batch
         return s.out_xyz[self._part * B:(self._part + 1) * B], s.out_feat[self._part * B:(self._part + 1) * B]
 
     def result(self, copy=False):
         """(new_xyz [B,m,3], features [B,m,C]) of the backbone's last row.  With `out=` given at submit time those
         tensors are returned; otherwise this batch's part of the slot's static buffers (copy=True: clones)."""
         self.wait()
-        pipe = self._slot.pipe
-        if pipe.check_overflow:
-            # fp16 scales guard their operand range (csrc/mlp_act.h): one 4-byte read per batch, after completion
-            pipe.net.raise_if_overflow()
+        r = self._round
+        pipe = r.slot.pipe
+        if pipe.check_overflow and int(pipe._flags[r.flag]) != 0:
+            # fp16 scales guard their operand range (csrc/mlp_act.h): this round's own word, already on the host
+            raise FloatingPointError(
+                "SA backbone: an activation left the fp16 range (|x| > 65504, inf or NaN) in a scale evaluated in fp16 in "
+                "the package this batch ran in -- its results are invalid.  Use precision='bf16x3' for these weights.")
         if self._out is not None:
             return self._out
-        if self._slot.seq != self._seq:
+        if self._stale():
             raise RuntimeError("this ticket's slot has been reused by a later submit (%d batches in flight at most): "
                                "call result() earlier, or submit(..., out=...) / result(copy=True)"
-                               % (self._slot.pipe.nslots * self._slot.pipe.coalesce))
+                               % (pipe.nslots * pipe.coalesce))
         xyz, feat = self._views()
         if copy:
-            with torch.cuda.stream(self._slot.stream):
+            st = r.slot.stream_b
+            with torch.cuda.stream(st):
                 xyz, feat = xyz.clone(), feat.clone()
-            self._slot.stream.synchronize()
+            st.synchronize()
         return xyz, feat
 
     def all_outputs(self):
         """(xyz_list, feature_list, fps_idx_list) of this batch, as SABackbone.forward returns them (views of the slot's
         static buffers)."""
         self.wait()
-        if self._slot.seq != self._seq:
+        if self._stale():
             raise RuntimeError("this ticket's slot has been reused by a later submit")
-        B, p = self._slot.pipe.batch, self._part
+        B, p = self._round.slot.pipe.batch, self._part
         cut = lambda t: None if t is None else t[p * B:(p + 1) * B]
-        return tuple([cut(t) for t in lst] for lst in self._slot.lists)
+        return tuple([cut(t) for t in lst] for lst in self._round.slot.lists)
 
 
 class _Slot:
-    __slots__ = ("pipe", "stream", "inp", "graph", "out_xyz", "out_feat", "lists", "seq", "event", "launched", "outs")
+    __slots__ = ("pipe", "index", "stream_a", "stream_b", "inp", "overflow", "graph_a", "graph_b", "out_xyz", "out_feat",
+                 "lists", "round", "last_event")
 
 
 class SAPipeline:
-    def __init__(self, arch, params, device="cuda:0", batch=8, points=16384, channels=4, streams=DEFAULT_STREAMS,
+    def __init__(self, arch, params, device="cuda:0", batch=8, points=16384, channels=4, streams=None,
                  graphs=True, max_translate_range=(-3.0, -2.0, -3.0), aggregation_sa_feature=True, net=None,
-                 precision=None, check_overflow=True, coalesce=1):
-        """arch / params as for SABackbone.  `streams` slots, each a HIP stream + (graphs=True) a captured hipGraph of
-        net(slot input); a slot's input holds `coalesce` batches (module docstring).  graphs=False launches eagerly on the slot's stream (frames whose layer-1 sampler is the
-        cooperative multi-workgroup kernel -- n > 16384 -- cannot be captured)."""
+                 precision=None, check_overflow=True, coalesce=1, mode="staged", timeline=False):
+        """arch / params as for SABackbone.  mode / coalesce: module docstring.  `streams`: the number of slots --
+        packages in the ring for mode="staged" (default 4), slots = HIP streams for mode="slots" (default 16).
+        graphs=False launches eagerly on the same streams (frames whose layer-1 sampler cannot be captured).
+        timeline=True records HIP timing events around every package (`timeline()`)."""
         self.device = torch.device(device)
         T.require(self.device.type == "cuda", "SAPipeline needs a GPU: the HIP path has no CPU fallback")
+        T.require(mode in ("staged", "slots"), "SAPipeline mode must be 'staged' or 'slots'")
         N.lib()
         self.net = net if net is not None else SABackbone(arch, params, self.device, max_translate_range,
                                                            aggregation_sa_feature, precision)
         self.check_overflow = bool(check_overflow)
+        self.mode = mode
         self.batch, self.points, self.channels = int(batch), int(points), int(channels)
+        if streams is None:
+            streams = DEFAULT_PACKAGES if mode == "staged" else DEFAULT_STREAMS
         self.nslots = max(1, int(streams))
         self.coalesce = max(1, int(coalesce))
-        self._fill = 0
         self.graphs = bool(graphs)
+        self.record_timeline = bool(timeline)
+        self._timeline = []
         self._next = 0
         self.submitted = 0
+        self._flags = torch.zeros(_FLAG_RING, dtype=torch.int32).pin_memory()
+        self._flag_next = 0
+        if mode == "slots" and self.nslots > hw_queues():
+            warnings.warn("SAPipeline(mode='slots') with %d slots on %d hardware queues: slots beyond the queue count "
+                          "serialise (call pipeline.request_hw_queues(%d) before the first CUDA call, or use "
+                          "mode='staged')" % (self.nslots, hw_queues(), self.nslots))
         with torch.cuda.device(self.device):
             self._build()
 
@@ -130,14 +182,21 @@ class SAPipeline:
     def _build(self):
         dev = self.device
         shape = (self.batch * self.coalesce, self.points, self.channels)
+        if self.mode == "staged":
+            self.sampler_stream = torch.cuda.Stream(device=dev)
+            self.main_streams = [torch.cuda.Stream(device=dev) for _ in range(MAIN_STREAMS)]
         self.slots = []
-        for _ in range(self.nslots):
+        for i in range(self.nslots):
             s = _Slot()
-            s.pipe, s.stream, s.seq, s.graph = self, torch.cuda.Stream(device=dev), -1, None
+            s.pipe, s.index, s.graph_a, s.graph_b = self, i, None, None
+            if self.mode == "staged":
+                s.stream_a, s.stream_b = self.sampler_stream, self.main_streams[i % MAIN_STREAMS]
+            else:
+                s.stream_a = s.stream_b = torch.cuda.Stream(device=dev)
             s.inp = torch.zeros(shape, dtype=torch.float32, device=dev)
-            s.event = torch.cuda.Event()
+            s.overflow = torch.zeros(1, dtype=torch.int32, device=dev)
             s.out_xyz = s.out_feat = s.lists = None
-            s.launched, s.outs = True, []
+            s.round, s.last_event = None, None
             self.slots.append(s)
         if not self.graphs:
             return
@@ -152,91 +211,190 @@ class SAPipeline:
             s.inp.copy_(warm)
         torch.cuda.synchronize(dev)
         for s in self.slots:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=s.stream):
-                xl, fl, il = self.net(s.inp)
-            s.graph, s.lists = g, (xl, fl, il)
+            with self._flag_word(s):
+                if self.mode == "staged":
+                    gen = self.net.forward_staged(s.inp)
+                    ga = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(ga, stream=s.stream_a):
+                        next(gen)
+                    gb = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gb, stream=s.stream_b, pool=ga.pool()):
+                        try:
+                            next(gen)
+                            raise RuntimeError("forward_staged yielded twice")
+                        except StopIteration as e:
+                            xl, fl, il = e.value
+                    s.graph_a, s.graph_b = ga, gb
+                else:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=s.stream_b):
+                        xl, fl, il = self.net(s.inp)
+                    s.graph_b = g
+            s.lists = (xl, fl, il)
             s.out_xyz, s.out_feat = xl[-1], fl[-1]
         torch.cuda.synchronize(dev)
-        # every graph replayed once as part of the set-up (first replay uploads the executable graph)
+        # every graph replayed once as part of the set-up (the first replay uploads the executable graph)
         for s in self.slots:
-            with torch.cuda.stream(s.stream):
-                s.graph.replay()
-        torch.cuda.synchronize(dev)
+            if s.graph_a is not None:
+                with torch.cuda.stream(s.stream_a):
+                    s.graph_a.replay()
+                torch.cuda.synchronize(dev)
+            with torch.cuda.stream(s.stream_b):
+                s.graph_b.replay()
+            torch.cuda.synchronize(dev)
+
+    class _flag_word:
+        """While a slot's kernels are enqueued / captured, the network's fp16 range flag IS the slot's own word."""
+
+        def __init__(self, slot):
+            self.v, self.slot = slot.pipe.net.variables, slot
+
+        def __enter__(self):
+            self.saved, self.v.overflow = self.v.overflow, self.slot.overflow
+
+        def __exit__(self, *exc):
+            self.v.overflow = self.saved
 
     # ------------------------------------------------------------------------------------------------ use
     def submit(self, batch, out=None, sync_source=True):
         """Enqueue one batch [B, points, channels] fp32 (device tensor; a pinned host tensor is copied
-        asynchronously).  Returns immediately.  sync_source=False skips the event that orders the slot's stream
-        behind the stream that produced `batch` (for inputs known to be complete, e.g. a resident pool).
+        asynchronously).  Returns immediately.  sync_source=False skips the event that orders the copy behind the
+        stream that produced `batch` (for inputs known to be complete, e.g. a resident pool).
         out = (xyz [B,m,3], feat [B,m,C]): the results are additionally copied there on the slot's stream.
-        With coalesce > 1 the slot is launched by the submit that fills it (or by flush / drain / result)."""
+        With coalesce > 1 the package is launched by the submit that fills it (or by flush / drain / result)."""
         T.require(isinstance(batch, torch.Tensor) and tuple(batch.shape) == (self.batch, self.points, self.channels),
                   "SAPipeline.submit expects a [%d,%d,%d] tensor" % (self.batch, self.points, self.channels))
         T.require(batch.dtype == torch.float32, "SAPipeline.submit expects fp32 (got %s)" % batch.dtype)
         s = self.slots[self._next]
-        part = self._fill
-        if part == 0:                       # a new round of this slot: earlier tickets of the slot are now stale
-            s.seq, s.launched, s.outs = self.submitted, False, []
+        r = s.round
+        if r is None or r.launched:          # a new round of this slot: earlier tickets of the slot are now stale
+            r = s.round = _Round(s, self._flag_next)
+            self._flag_next = (self._flag_next + 1) % _FLAG_RING
+        part = r.fill
         dst = s.inp[part * self.batch:(part + 1) * self.batch]
+        st = s.stream_a
         with torch.cuda.device(self.device):
             if batch.is_cuda:
                 T.require(batch.device == self.device, "batch lives on %s, the pipeline on %s" % (batch.device, self.device))
                 if sync_source:
                     ev = torch.cuda.Event()
                     ev.record(torch.cuda.current_stream(self.device))
-                    s.stream.wait_event(ev)
-            with torch.cuda.stream(s.stream):
+                    st.wait_event(ev)
+                batch.record_stream(st)       # the caller may drop `batch` now: its block is not reused before the copy ran
+            with torch.cuda.stream(st):
                 if batch.is_cuda and batch.stride(2) == 1:
                     N.copy_blocks([(batch, dst, self.batch, self.points, self.channels)])
                 else:
                     dst.copy_(batch, non_blocking=True)
         if out is not None:
-            s.outs.append((part, out))
-        t = Ticket(s, s.seq, part, out)
+            for o in out:
+                if o.is_cuda:
+                    o.record_stream(s.stream_b)
+            r.outs.append((part, out))
+        t = Ticket(r, part, out)
         self.submitted += 1
-        self._fill += 1
-        if self._fill == self.coalesce:
+        r.fill += 1
+        if r.fill == self.coalesce:
             self._launch(s)
         return t
 
     def _launch(self, s):
-        """Replay (or run eagerly) slot `s` over whatever its input buffer holds; the slot the next submit fills is
+        """Run slot `s` over what its input buffer holds (unfilled parts zeroed); the slot the next submit fills is
         the one after it."""
-        if s.launched:
+        r = s.round
+        if r is None or r.launched:
             return
-        with torch.cuda.device(self.device), torch.cuda.stream(s.stream):
-            if s.graph is not None:
-                s.graph.replay()
-            else:
-                xl, fl, il = self.net(s.inp)
-                s.lists, s.out_xyz, s.out_feat = (xl, fl, il), xl[-1], fl[-1]
-            B = self.batch
-            for part, (ox, of) in s.outs:
-                N.copy_blocks([(s.out_xyz[part * B:(part + 1) * B], ox, B, s.out_xyz.shape[1], 3),
-                               (s.out_feat[part * B:(part + 1) * B], of, B, s.out_feat.shape[1], s.out_feat.shape[2])])
-            s.event = torch.cuda.Event()
-            s.event.record(s.stream)
-        s.launched = True
+        B = self.batch
+        tl = self.record_timeline
+        with torch.cuda.device(self.device):
+            a, b = s.stream_a, s.stream_b
+            marks = []
+            with torch.cuda.stream(a):
+                if tl:
+                    marks.append(self._mark(a))
+                if r.fill < self.coalesce:
+                    s.inp[r.fill * B:].zero_()            # no stale frames (their range flags would re-raise)
+            staged = self.mode == "staged"
+            gen = None
+            if staged:
+                if s.last_event is not None:
+                    a.wait_event(s.last_event)            # stage B of the slot's previous round still reads stage A's outputs
+                with torch.cuda.stream(a):
+                    if s.graph_a is not None:
+                        s.graph_a.replay()
+                    else:
+                        gen = self.net.forward_staged(s.inp)
+                        next(gen)
+                    ev = torch.cuda.Event(enable_timing=tl)
+                    ev.record(a)
+                    if tl:
+                        marks.append(ev)
+                b.wait_event(ev)
+            with torch.cuda.stream(b):
+                s.overflow.zero_()
+                if s.graph_b is not None:
+                    s.graph_b.replay()
+                else:
+                    with self._flag_word(s):
+                        if gen is not None:
+                            try:
+                                next(gen)
+                                raise RuntimeError("forward_staged yielded twice")
+                            except StopIteration as e:
+                                xl, fl, il = e.value
+                        else:
+                            xl, fl, il = self.net(s.inp)
+                    s.lists, s.out_xyz, s.out_feat = (xl, fl, il), xl[-1], fl[-1]
+                for part, (ox, of) in r.outs:
+                    N.copy_blocks([(s.out_xyz[part * B:(part + 1) * B], ox, B, s.out_xyz.shape[1], 3),
+                                   (s.out_feat[part * B:(part + 1) * B], of, B, s.out_feat.shape[1], s.out_feat.shape[2])])
+                self._flags[r.flag:r.flag + 1].copy_(s.overflow, non_blocking=True)
+                r.event = torch.cuda.Event(enable_timing=tl)
+                r.event.record(b)
+            if tl:
+                marks.append(r.event)
+                self._timeline.append((s.index, r.fill, marks))
+        s.last_event = r.event
+        r.launched = True
         if s is self.slots[self._next]:
             self._next = (self._next + 1) % self.nslots
-            self._fill = 0
+
+    @staticmethod
+    def _mark(stream):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(stream)
+        return ev
+
+    def timeline(self, base, clear=True):
+        """[(slot, batches, [ms since `base` ...])] of the packages launched since the last call (timeline=True):
+        reached-by-its-stream, (stage A complete,) package complete -- device-side times from HIP events.  `base` is a
+        timing event recorded before them; call after a synchronize."""
+        out = [(i, fill, [round(base.elapsed_time(e), 3) for e in marks]) for i, fill, marks in self._timeline]
+        if clear:
+            self._timeline = []
+        return out
 
     def flush(self):
-        """Launch the slot that is waiting for more batches, if any (coalesce > 1)."""
-        if self._fill:
-            self._launch(self.slots[self._next])
+        """Launch the package that is waiting for more batches, if any (coalesce > 1)."""
+        s = self.slots[self._next]
+        if s.round is not None and not s.round.launched:
+            self._launch(s)
 
     def run_alone(self, batch):
         """One batch by itself on slot 0 (latency measurements): submit + launch + wait."""
-        self.flush()
+        self.drain()
         self._next = 0
         return self.submit(batch).wait()
 
     def drain(self):
         self.flush()
         for s in self.slots:
-            s.stream.synchronize()
+            s.stream_a.synchronize()
+            s.stream_b.synchronize()
+
+    def streams_used(self):
+        """HIP streams the executor issues on (the helper branch inside the captured graphs not counted)."""
+        return len({id(s.stream_a) for s in self.slots} | {id(s.stream_b) for s in self.slots})
 
     def forward_eager(self, batch):
         """The same network, eager launches on the current stream (the reference result of the tests)."""

@@ -23,7 +23,9 @@ from .tf_ops.sampling.tf_sampling import farthest_point_sample, farthest_point_s
 from .tf_ops.grouping.tf_grouping import query_ball_point, query_ball_point_dilated, group_point  # noqa: F401
 
 # cfg.MODEL.NETWORK.AGGREGATION_SA_FEATURE and cfg.MODEL.MAX_TRANSLATE_RANGE of the reference's global
-# config (configs/kitti/3dssd/3dssd.yaml:39,44); set by the backbone driver.
+# config (configs/kitti/3dssd/3dssd.yaml:39,44): the DEFAULTS of the keyword arguments `aggregation_sa_feature` /
+# `max_translate_range` below.  SABackbone passes its own values per call (two backbones with different settings
+# in one process do not share them); a caller that uses the reference's signatures only gets these.
 AGGREGATION_SA_FEATURE = True
 # frames with at least this many points go through the grid ball query (csrc/ballquery_grid.hip)
 # sa_group_mlp_max flags: 0 = evaluate only the distinct rows of every ball (default), 1 = all nsample rows (A/B)
@@ -63,15 +65,16 @@ def _dense(x, layer, relu):
     return y
 
 
-def vote_layer(xyz, points, mlp_list, is_training, bn_decay, bn, scope, variables=None):
-    """layers_util.py:12-24.  Returns (xyz + clipped offsets, features, raw offsets)."""
+def vote_layer(xyz, points, mlp_list, is_training, bn_decay, bn, scope, variables=None, max_translate_range=None):
+    """layers_util.py:12-24.  Returns (xyz + clipped offsets, features, raw offsets).  max_translate_range: the
+    reference's cfg.MODEL.MAX_TRANSLATE_RANGE (None: the module default above)."""
     vs = variables or W.default_variables()
     xyz = T.f32_cuda(xyz, "xyz")
     points = T.f32_cuda(points, "points")
     hidden = [vs.layer("%s/vote_layer_%d" % (scope, i), bn) for i, _channel in enumerate(mlp_list)]
     last = vs.layer(scope + "/vote_offsets", False)
     out = torch.empty_like(xyz)
-    lo = MAX_TRANSLATE_RANGE
+    lo = MAX_TRANSLATE_RANGE if max_translate_range is None else tuple(max_translate_range)
     for layer in hidden[:-1]:
         points = _dense(points, layer, relu=True)
     if hidden:
@@ -377,9 +380,11 @@ def sample_layer(xyz, points, fps_sample_range_list, fps_method_list, npoint_lis
 def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_training, bn_decay, bn,
                            fps_sample_range_list, fps_method_list, npoint_list, former_fps_idx,
                            use_attention, scope, dilated_group, vote_ctr=None, aggregation_channel=None,
-                           debugging=False, epsilon=1e-5, variables=None):
+                           debugging=False, epsilon=1e-5, variables=None, aggregation_sa_feature=None, presampled=None):
     """layers_util.py:59-189.  xyz (B,n,3), points (B,n,C) -> new_xyz (B,m,3), new_points (B,m,C'),
-    fps_idx (B,m) int32."""
+    fps_idx (B,m) int32.  aggregation_sa_feature: cfg.MODEL.NETWORK.AGGREGATION_SA_FEATURE (None: the module default);
+    presampled = (fps_idx, new_xyz, sliced_points) of an earlier `sample_layer` call with the same arguments (the staged
+    executor of pipeline.py runs the sampling half on its own stream)."""
     T.require(not use_attention, "use_attention (query_ball_point_withidx) is outside the 3DSSD SA path")
     vs = variables or W.default_variables()
     xyz = T.f32_cuda(xyz, "xyz")
@@ -388,8 +393,11 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
     dev = xyz.device
 
     # ---- sampling (layers_util.py:84-119)
-    fps_idx, new_xyz, sliced_points = sample_layer(xyz, points, fps_sample_range_list, fps_method_list, npoint_list,
-                                                   former_fps_idx, vote_ctr, radius_list)
+    if presampled is not None:
+        fps_idx, new_xyz, sliced_points = presampled
+    else:
+        fps_idx, new_xyz, sliced_points = sample_layer(xyz, points, fps_sample_range_list, fps_method_list, npoint_list,
+                                                       former_fps_idx, vote_ctr, radius_list)
     m = new_xyz.shape[1]
     lib = N.lib()
     stream = N.current_stream()
@@ -473,7 +481,7 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
                 nl = len(layers[i])
                 d_ = [c_feat + 3] + [l.N for l in layers[i]]
                 PLAN_LOG.append((bs, m, int(nsample_list[i]), sum(d_[j] * d_[j + 1] for j in range(nl)), plans[i][0]))
-        if AGGREGATION_SA_FEATURE:                                          # :184-185
+        if (AGGREGATION_SA_FEATURE if aggregation_sa_feature is None else aggregation_sa_feature):   # :184-185
             agg = vs.layer(scope + "/ensemble", bn)
             T.require(agg.N == aggregation_channel, "aggregation_channel does not match the ensemble weights")
             new_points_concat = _dense(new_points_concat, agg, relu=True)

@@ -52,8 +52,8 @@ def bf16_to_f32(h):
 # channel's weights sit in the fp16 subnormal range as a whole (column maximum >= FP16_MIN_COL_MAX = 2^-10, so that
 # every weight within a factor 16 of the column's largest keeps its 11 significant bits; BN folding with a tiny
 # gamma / sqrt(var) can scale a whole column down -- single tiny entries of a healthy column only add an absolute
-# error far below the column's scale).  Activations are converted with saturation by the kernels and a saturated
-# activation raises the overflow flag of the call (csrc/mlp_act.h; VariableStore.overflow, checked by
+# error far below the column's scale).  Activations are converted WITHOUT saturation (v_cvt_pk_f16_f32: a value beyond 65504
+# becomes inf) and an inf / NaN half -- or a NaN / inf input feature -- raises the overflow flag of the call (csrc/mlp_act.h; VariableStore.overflow, checked by
 # SABackbone.raise_if_overflow and by SAPipeline tickets).
 FP16_MIN_K = 128
 FP16_MAX_ABS = 6.0e4

@@ -30,8 +30,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-# 16 hardware queues for the 16 slots (3dssd_amd/pipeline.py sets the same default); must happen before HIP starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# (--executor slots asks for one hardware queue per slot -- pipeline.request_hw_queues, before the first CUDA call in
+# main(); the default staged executor runs on ROCm's default of 4 queues and sets nothing)
 
 import numpy as np
 import torch
@@ -151,6 +151,13 @@ def _algorithmic(name, a):
     return 0, 0, name
 
 
+EXECUTOR_NOTES = {
+    "staged": "3dssd_amd.pipeline.SAPipeline(mode='staged'): 3 HIP streams, %(n)d packages of %(C)d batches x %(B)d frames in a "
+              "ring; a package = two captured hipGraphs -- stage A (input split + layer-1 D-FPS + centres) on the sampler "
+              "stream, stage B (everything else) on one of two main streams behind an event; one block copy per step",
+    "slots": "3dssd_amd.pipeline.SAPipeline(mode='slots'): %(n)d slots = %(n)d HIP streams, each with one captured hipGraph "
+             "of the backbone over %(C)d batches x %(B)d frames; one block copy per step, one replay per %(C)d steps",
+}
 MLP_CALLS = ("sa_group_mlp_max", "sa_group_mlp_max_layer")
 MFMA_CALLS = MLP_CALLS + ("sa_dense", "sa_vote_tail")
 
@@ -388,11 +395,30 @@ def launch_check(args, sh):
 
 
 # ------------------------------------------------------------------------------------------------ workloads
-def timed_region(sh, dev, run, steps, warmup, frames_per_step):
+def sclk_mhz():
+    """Current shader clock of every GPU the kernel driver exposes (pp_dpm_sclk's starred level), or None."""
+    import glob
+    out = []
+    for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+        try:
+            for ln in open(f):
+                if "*" in ln:
+                    out.append(int("".join(ch for ch in ln.split(":")[1] if ch.isdigit())))
+        except Exception:  # noqa: BLE001
+            pass
+    return out or None
+
+
+def timed_region(sh, dev, run, steps, warmup, frames_per_step, prime=None, before=None, after=None):
+    """`prime()` (untimed, independent of --warmup) -> warmup steps -> barrier + synchronize -> EXACTLY `steps` steps ->
+    synchronize + barrier.  before() / after() run just outside the timed bracket (timeline base event, clocks)."""
+    primed = prime() if prime is not None else None
     run(warmup)
     torch.cuda.synchronize()
     sh.barrier()
     torch.cuda.synchronize()
+    if before is not None:
+        before()
     t0 = time.perf_counter()
     outs = run(steps)
     host_issue_ms = (time.perf_counter() - t0) / steps * 1e3
@@ -400,36 +426,43 @@ def timed_region(sh, dev, run, steps, warmup, frames_per_step):
     sh.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if after is not None:
+        after()
     t_max, frames_total = sh.reduce_timing(elapsed, steps * frames_per_step, device=dev)
-    return t_max, frames_total, host_issue_ms, outs
+    return t_max, frames_total, host_issue_ms, outs, primed
 
 
-def overlap_probe(run, k):
-    """How the steps of the headline run overlap, measured by the application itself (rocprofv3's kernel trace
+def overlap_probe(pipe, run, k):
+    """How the packages of the headline run overlap, measured by the application itself (rocprofv3's kernel trace
     serialises the streams: profiles/r02_trace16_summary.txt shows 1.4 kernels in flight under the profiler).  A
-    second, untimed run of k steps with a HIP event before and after every step on its stream: a step's device-side
-    span is several times the time between completions, i.e. that many steps are in flight."""
+    second, untimed run of k steps with the executor's own HIP timing events around every package (SAPipeline
+    timeline): a package's device-side span is several times the time between completions, i.e. that many are in
+    flight."""
     torch.cuda.synchronize()
     base = torch.cuda.Event(enable_timing=True)
     base.record()
-    marks = []
-    run(k, marks)
     torch.cuda.synchronize()
-    iv = sorted((base.elapsed_time(s), base.elapsed_time(e)) for s, e in marks)
-    ends = sorted(e for _, e in iv)
+    pipe.timeline(base)
+    pipe.record_timeline = True
+    run(k)
+    pipe.drain()
+    pipe.record_timeline = False
+    rows = pipe.timeline(base)
+    iv = sorted((ms[0], ms[-1], fill) for _slot, fill, ms in rows)
+    ends = sorted(e for _, e, _ in iv)
     # steady part: from the first completion to the last start
-    t0, t1 = ends[0], max(s for s, _ in iv)
+    t0, t1 = ends[0], max(s for s, _, _ in iv)
     if t1 <= t0:
         t0, t1 = iv[0][0], ends[-1]
-    busy = sum(max(0.0, min(e, t1) - max(s, t0)) for s, e in iv)
-    spans = [e - s for s, e in iv]
+    busy = sum(max(0.0, min(e, t1) - max(s, t0)) * f for s, e, f in iv)
+    spans = [e - s for s, e, _ in iv]
     done = [e for e in ends if t0 <= e <= t1]
-    return {"steps": k, "step_span_ms_mean": round(sum(spans) / len(spans), 3), "step_span_ms_min": round(min(spans), 3),
-            "step_span_ms_max": round(max(spans), 3),
+    return {"steps": k, "packages": len(iv), "package_span_ms_mean": round(sum(spans) / len(spans), 3),
+            "package_span_ms_min": round(min(spans), 3), "package_span_ms_max": round(max(spans), 3),
             "steps_in_flight_mean": round(busy / (t1 - t0), 2),
             "ms_between_completions": round((t1 - t0) / max(len(done) - 1, 1), 4),
-            "note": "device-side spans from HIP events around every step of a second, untimed run; in flight = sum of "
-                    "spans inside the steady window / its length"}
+            "note": "device-side spans (reached by its stream -> complete) of the packages of a second, untimed run; steps in "
+                    "flight = sum of (span inside the steady window x batches of the package) / its length"}
 
 
 def mlp_row_stats(net, batches):
@@ -497,9 +530,10 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
     arch = cfgs.KITTI_3DSSD_ARCH
     params = syn.random_backbone_params(arch)
     use_graphs = bool(args.graphs) and graphs_ok
-    pipe = pkg("pipeline").SAPipeline(arch, params, dev, batch=args.batch, points=points, channels=4,
-                                      streams=max(1, args.streams), graphs=use_graphs,
-                                      max_translate_range=cfgs.KITTI_MAX_TRANSLATE_RANGE, coalesce=max(1, args.coalesce))
+    P = pkg("pipeline")
+    pipe = P.SAPipeline(arch, params, dev, batch=args.batch, points=points, channels=4, streams=max(1, args.streams),
+                        graphs=use_graphs, max_translate_range=cfgs.KITTI_MAX_TRANSLATE_RANGE,
+                        coalesce=max(1, args.coalesce), mode=args.executor)
     C = pipe.coalesce
     net = pipe.net
     # this rank's frame pool: global frame f -> rank f mod world (weak scaling: `batch` frames per GPU per step);
@@ -511,31 +545,50 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
     torch.cuda.synchronize()
     cursor = [0]
 
-    def run(k, marks=None):
-        # k steps = k batches; a slot is launched by the submit that fills it (`coalesce` batches), the last, partly
-        # filled one by flush().  marks: a HIP event before the first copy and after the launch of every replay
-        tickets = []
-        s_ev = st = None
+    def run(k):
+        # k steps = k batches; a package is launched by the submit that fills it (`coalesce` batches), the last, partly
+        # filled one by flush()
+        tickets = [None] * k
         for i in range(k):
-            pts = batches[cursor[0] % nb]
+            tickets[i] = pipe.submit(batches[cursor[0] % nb], sync_source=False)
             cursor[0] += 1
-            if marks is not None and pipe._fill == 0:
-                st = pipe.slots[pipe._next].stream
-                s_ev = torch.cuda.Event(enable_timing=True)
-                s_ev.record(st)
-            tickets.append(pipe.submit(pts, sync_source=False))
-            if i == k - 1:
-                pipe.flush()
-            if marks is not None and pipe._fill == 0:
-                e_ev = torch.cuda.Event(enable_timing=True)
-                e_ev.record(st)
-                marks.append((s_ev, e_ev))
+        pipe.flush()
         return tickets
 
-    t_max, frames_total, host_issue_ms, tickets = timed_region(sh, dev, run, args.steps, args.warmup, args.batch)
+    def prime():
+        # untimed and independent of --warmup: every slot replayed at least twice on real frames, and the chip kept
+        # busy for >= 150 ms right before the barrier (clocks, first-use costs of every slot's graphs)
+        t0 = time.perf_counter()
+        n = 0
+        while n < 2 * pipe.nslots * C or time.perf_counter() - t0 < 0.15:
+            run(C)
+            n += C
+            if n % (pipe.nslots * C) == 0:
+                pipe.drain()
+        pipe.drain()
+        return {"batches": n, "packages": n // C, "wall_ms": round((time.perf_counter() - t0) * 1e3, 1),
+                "note": "untimed, before the warm-up steps: every slot replayed >= 2x on pool frames, >= 150 ms of work"}
+
+    clocks = {}
+    base = [None]
+
+    def before():
+        clocks["before"] = sclk_mhz()
+        pipe.record_timeline = True
+        base[0] = torch.cuda.Event(enable_timing=True)
+        base[0].record()
+        torch.cuda.synchronize()
+
+    def after():
+        pipe.record_timeline = False
+        clocks["after"] = sclk_mhz()
+
+    t_max, frames_total, host_issue_ms, tickets, primed = timed_region(sh, dev, run, args.steps, args.warmup, args.batch,
+                                                                       prime, before, after)
+    packages = pipe.timeline(base[0])
     x_last, f_last = tickets[-1].result()
     assert f_last.shape == (args.batch, 256, 512) and x_last.shape == (args.batch, 256, 3)
-    overlap = overlap_probe(run, min(args.steps, 96)) if rank == 0 else None
+    overlap = overlap_probe(pipe, run, min(args.steps, 96)) if rank == 0 else None
     # latency of one batch alone on the device (no overlap), for the record
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -545,27 +598,30 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
     verify = verify_pipeline(pipe, batches, args.verify)
     if verify is not None and not verify["all_equal_eager"]:
         sys.exit("bench.py: a pipeline output differs from the eager result of the same batch -- refusing to report")
-    uncoalesced = None
-    if C > 1 and use_graphs and not args.no_uncoalesced and world == 1:
-        # the same executor with one batch per replay, reported beside the headline so that the effect of coalescing is
-        # in the line itself.  A process of its own: a second pipeline in THIS process would share the 16 hardware
-        # queues with the first one's 16 idle streams (measured: 8.5 k instead of 10.7 k frames/s).
+    other = None
+    if use_graphs and not args.no_other_executor and world == 1:
+        # the other executor on the same workload, reported beside the headline.  A process of its own: the hardware
+        # queue count is fixed when the HIP runtime starts, and a second pipeline here would share queues with the first.
         torch.cuda.synchronize()
-        k1, w1 = max(min(args.steps, 128), 1), max(min(args.warmup, 24), 1)
-        cmd = [sys.executable, os.path.abspath(__file__), "--coalesce", "1", "--steps", str(k1), "--warmup", str(w1),
-               "--batch", str(args.batch), "--points", str(points), "--streams", str(args.streams), "--pool", str(args.pool),
-               "--data", args.data, "--no-cpu-baseline", "--no-uncoalesced", "--profile-iters", "0", "--verify", "0"]
+        alt = ({"executor": "slots", "streams": 16, "coalesce": 4} if args.executor == "staged" else
+               {"executor": "staged", "streams": P.DEFAULT_PACKAGES, "coalesce": 8})
+        cmd = [sys.executable, os.path.abspath(__file__), "--executor", alt["executor"], "--coalesce", str(alt["coalesce"]),
+               "--streams", str(alt["streams"]), "--steps", str(args.steps), "--warmup", str(args.warmup),
+               "--batch", str(args.batch), "--points", str(points), "--pool", str(args.pool),
+               "--data", args.data, "--no-cpu-baseline", "--no-other-executor", "--profile-iters", "0", "--verify", "0"]
         if args.allow_knobs:
             cmd.append("--allow-knobs")
         try:
-            out = subprocess.run(cmd, capture_output=True, text=True, timeout=300).stdout.strip().splitlines()
+            env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES" or args.hwq_from_env}
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env).stdout.strip().splitlines()
             d1 = json.loads(out[-1])
-            uncoalesced = {"value": d1["value"], "unit": d1["unit"], "steps": d1["steps"], "warmup": d1["warmup"],
-                           "ms_per_step": d1["ms_per_step"], "single_stream_batch_latency_ms": d1["single_stream_batch_latency_ms"],
-                           "note": "`bench.py --coalesce 1` in a process of its own right after the headline run: same pipeline "
-                                   "class, same kernels, one batch of %d frames per graph replay" % args.batch}
+            other = {"executor": alt, "value": d1["value"], "unit": d1["unit"], "steps": d1["steps"], "warmup": d1["warmup"],
+                     "ms_per_step": d1["ms_per_step"], "hw_queues": d1["config"].get("hw_queues"),
+                     "one_package_alone_ms": d1["config"].get("one_package_alone_ms"),
+                     "note": "`bench.py --executor %s` in a process of its own right after the headline run: same kernels, "
+                             "same frames" % alt["executor"]}
         except Exception as e:  # noqa: BLE001 -- the secondary figure must not take the headline down
-            uncoalesced = {"error": repr(e)}
+            other = {"error": repr(e)}
     if rank != 0:
         return None
     clock_mhz = MAX_CLOCK_MHZ
@@ -589,28 +645,39 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
                 "random-init weights" % (args.data, nb * args.batch),
         "config": {"workload": "%s: full 3DSSD SA backbone (3dssd.yaml rows 1-6), %d-pt frames, batch=%d per GPU"
                                % (tag, points, args.batch),
-                   "frames_per_step_per_gpu": args.batch, "streams": pipe.nslots, "data": args.data,
-                   "pool_frames_per_gpu": nb * args.batch,
+                   "frames_per_step_per_gpu": args.batch, "data": args.data, "pool_frames_per_gpu": nb * args.batch,
+                   "executor": args.executor, "slots": pipe.nslots, "streams_used": pipe.streams_used(),
+                   "hw_queues": P.hw_queues(), "hip_graphs": use_graphs,
                    "batches_per_replay": C, "frames_per_launch": fpl,
-                   "executor": ("3dssd_amd.pipeline.SAPipeline: per-slot static input buffer, one block copy per step, "
-                                "one hipGraph replay per %d step(s) (coalesce=%d: a slot takes %d consecutive batches of "
-                                "%d frames and runs the backbone over all of them in one pass)" % (C, C, C, args.batch))
-                               if use_graphs else
-                               "3dssd_amd.pipeline.SAPipeline, eager launches on the slots' streams (coalesce=%d)" % C,
-                   "sharding": "frame f -> rank f mod N, no data-path collective"},
+                   "executor_note": EXECUTOR_NOTES[args.executor] % {"C": C, "B": args.batch, "n": pipe.nslots},
+                   "sharding": "frame f -> rank f mod N, no data-path collective",
+                   # what decides a short run (the driver record keeps `config` and `roofline` verbatim):
+                   "timed_window_ms": round(window_ms, 3), "one_package_alone_ms": round(latency_ms, 3),
+                   "ramp_dominated": bool(window_ms < 20.0 * latency_ms),
+                   "host_issue_ms_per_step": round(host_issue_ms, 3),
+                   "steps_in_flight_mean": overlap["steps_in_flight_mean"] if overlap else None,
+                   "ms_between_completions": overlap["ms_between_completions"] if overlap else None,
+                   "priming": primed, "sclk_mhz": clocks,
+                   "timed_packages_ms": {"columns": ["slot", "batches", "reached", "stage_A_done", "done"] if args.executor == "staged"
+                                                    else ["slot", "batches", "reached", "done"],
+                                         "rows": [[i, f] + ms for i, f, ms in packages[:32]],
+                                         "note": "device-side times (HIP events, ms since the start of the timed region) of "
+                                                 "the packages the timed steps ran in: reached by its stream, (layer-1 "
+                                                 "sampling done,) complete"},
+                   "other_executor": other},
         "timed_window_ms": round(window_ms, 3),
         "single_stream_batch_latency_ms": round(latency_ms, 3),
-        "latency_note": "one batch submitted alone and waited for: its slot is launched at once, i.e. one pass over "
-                        "frames_per_launch frames (the other parts of the slot hold stale frames)",
+        "latency_note": "one batch submitted alone and waited for: its package is launched at once, i.e. one pass over "
+                        "frames_per_launch frames (the other parts of the package zeroed)",
         "ramp_dominated": bool(window_ms < 20.0 * latency_ms),
-        "ramp_note": "a run shorter than ~20 single-replay latencies mostly measures filling and draining the %d slots "
-                     "(every chain starts with the ~3 ms layer-1 D-FPS); the steady-state rate needs --steps >= %d"
-                     % (pipe.nslots, 100 * C),
+        "ramp_note": "a run shorter than ~20 single-package latencies mostly measures filling and draining the executor "
+                     "(every package starts with the ~3 ms layer-1 D-FPS); the steady-state rate needs --steps >= %d"
+                     % (100 * C),
         "host_issue_ms_per_step": round(host_issue_ms, 3),
         "hip_graphs": use_graphs,
         "env_knobs": env_knobs()[0],
         "verify": verify,
-        "uncoalesced": uncoalesced,
+        "other_executor": other,
         "mlp_rows_per_step": rows,
         "overlap": overlap,
     }
@@ -683,7 +750,7 @@ def workload_ffps_isolated(args, sh, rank, world, dev):
     def run(k):
         return [S.farthest_point_sample(m, pts) for _ in range(k)]
 
-    t_max, frames_total, host_issue_ms, outs = timed_region(sh, dev, run, args.steps, args.warmup, len(frames))
+    t_max, frames_total, host_issue_ms, outs, _ = timed_region(sh, dev, run, args.steps, args.warmup, len(frames))
     assert outs[-1].shape == (len(frames), m)
     if rank != 0:
         return None
@@ -756,7 +823,7 @@ def workload_group_materialised(args, sh, rank, world, dev):
     def run(k):
         return [step() for _ in range(k)]
 
-    t_max, frames_total, host_issue_ms, outs = timed_region(sh, dev, run, args.steps, args.warmup, len(frames))
+    t_max, frames_total, host_issue_ms, outs, _ = timed_region(sh, dev, run, args.steps, args.warmup, len(frames))
     if rank != 0:
         return None
     stages = profile_stages(step, max(1, args.profile_iters))
@@ -801,26 +868,39 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step")
     ap.add_argument("--points", type=int, default=None)
     ap.add_argument("--pool", type=int, default=None, help="distinct frames per GPU the steps cycle through")
-    ap.add_argument("--streams", type=int, default=None, help="pipeline slots (HIP streams) the steps are issued on")
-    ap.add_argument("--coalesce", type=int, default=None, help="batches a pipeline slot takes before it is launched (frames per replay = batch x coalesce)")
+    ap.add_argument("--executor", default=None, choices=["staged", "slots"],
+                    help="3dssd_amd/pipeline.py mode: staged (default; 3 streams, sampler stage ‖ the rest) or slots (one stream + graph per slot)")
+    ap.add_argument("--streams", type=int, default=None, help="pipeline slots: packages in the ring (staged) / HIP streams (slots)")
+    ap.add_argument("--coalesce", type=int, default=None, help="batches per package (frames per replay = batch x coalesce)")
+    ap.add_argument("--hw-queues", type=int, default=None, help="GPU_MAX_HW_QUEUES for this run (default: unset for staged, = --streams for slots)")
     ap.add_argument("--verify", type=int, default=None, help="batches re-run through the pipeline and compared with eager (0: skip)")
     ap.add_argument("--profile-iters", type=int, default=3)
     ap.add_argument("--graphs", type=int, default=1, help="1 (default): one captured hipGraph per slot; 0: eager launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-uncoalesced", action="store_true", help="skip the secondary coalesce=1 measurement of the backbone workload")
+    ap.add_argument("--no-other-executor", action="store_true", help="skip the secondary measurement with the other executor")
     ap.add_argument("--allow-knobs", action="store_true", help="run although SA_* / SA3D_* environment variables are set (recorded in the line)")
     ap.add_argument("--allow-shared-device", action="store_true",
                     help="--gpus N with fewer than N GPUs visible: ranks share devices (functional check of the multi-rank path)")
     ap.add_argument("--launch-check", action="store_true", help="exercise only the launch path (works without a GPU)")
     args = ap.parse_args()
     assert args.gpus >= 1
-    defaults = {"configs1": dict(steps=512, warmup=64, batch=8, points=16384, streams=16, pool=256, verify=64, coalesce=4),
-                "configs2": dict(steps=4, warmup=1, batch=32, points=16384, streams=1, pool=32, verify=0, coalesce=1),
-                "configs4": dict(steps=16, warmup=4, batch=16, points=65536, streams=4, pool=96, verify=8, coalesce=1),
-                "group": dict(steps=20, warmup=5, batch=8, points=16384, streams=1, pool=8, verify=0, coalesce=1)}[args.workload]
+    defaults = {"configs1": dict(steps=512, warmup=64, batch=8, points=16384, pool=256, verify=64, executor="staged"),
+                "configs2": dict(steps=4, warmup=1, batch=32, points=16384, streams=1, pool=32, verify=0, coalesce=1, executor="slots"),
+                "configs4": dict(steps=16, warmup=4, batch=16, points=65536, streams=4, pool=96, verify=8, coalesce=1, executor="slots"),
+                "group": dict(steps=20, warmup=5, batch=8, points=16384, streams=1, pool=8, verify=0, coalesce=1, executor="slots")}[args.workload]
     for k, v in defaults.items():
         if getattr(args, k) is None:
             setattr(args, k, v)
+    if args.streams is None:
+        args.streams = 4 if args.executor == "staged" else 16
+    if args.coalesce is None:
+        args.coalesce = 8 if args.executor == "staged" else 4
+    # hardware queues: fixed when the HIP runtime starts, so before the first CUDA call of this process
+    args.hwq_from_env = "GPU_MAX_HW_QUEUES" in os.environ
+    if args.hw_queues is not None:
+        os.environ["GPU_MAX_HW_QUEUES"] = str(args.hw_queues)
+    elif args.executor == "slots" and args.workload == "configs1" and not args.launch_check:
+        pkg("pipeline").request_hw_queues(args.streams)
 
     knobs, sa_keys = env_knobs()
     if "SA_ABLATE" in os.environ:

@@ -170,3 +170,35 @@ def test_backbone_with_the_gemm_chain_opted_in_is_bit_identical(gpu):
         lu.MLP_GEMM_CHAIN = False
     assert torch.equal(fl[-1], fl2[-1]) and torch.equal(xl[-1], xl2[-1])
     net.raise_if_overflow()
+
+
+def test_two_backbones_keep_their_own_settings(gpu):
+    # SABackbone wrote aggregation_sa_feature / max_translate_range into layers_util's module
+    # attributes, so two backbones in one process shared the last value.  They are per instance now.
+    cfgs, syn = pkg("configs"), pkg("synthetic")
+    arch = cfgs.KITTI_3DSSD_ARCH
+    params = syn.random_backbone_params(arch)
+    pts = torch.from_numpy(syn.kitti_like_batch(2, first_frame=77)).to(gpu)
+    B = pkg("backbone")
+    a = B.SABackbone(arch, params, gpu, max_translate_range=(-3.0, -2.0, -3.0))
+    xa, fa, _ = a(pts)
+    b = B.SABackbone(arch, params, gpu, max_translate_range=(-0.01, -0.01, -0.01))   # created later: must not leak into `a`
+    xb, fb, _ = b(pts)
+    xa2, fa2, _ = a(pts)
+    torch.cuda.synchronize()
+    assert torch.equal(xa[-1], xa2[-1]) and torch.equal(fa[-1], fa2[-1])
+    # the vote layer of `b` may move a centre by at most 0.01 per axis, that of `a` by up to (3, 2, 3)
+    vote = [i for i, row in enumerate(arch) if row[11] == "Vote_Layer"][0]
+    base = xb[arch[vote][0][0]]
+    assert float((xb[vote + 1] - base).abs().max()) <= 0.0101     # 0.01 + the rounding of x + 0.01 at |x| ~ 70
+    assert float((xa[vote + 1] - base).abs().max()) > 0.02
+    # and the staged form of forward() is the same computation
+    gen = a.forward_staged(pts)
+    next(gen)
+    try:
+        next(gen)
+        assert False
+    except StopIteration as e:
+        xs, fs, _ = e.value
+    torch.cuda.synchronize()
+    assert torch.equal(fs[-1], fa[-1]) and torch.equal(xs[-1], xa[-1])

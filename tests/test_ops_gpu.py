@@ -624,6 +624,30 @@ def test_group_mlp_fp16_overflow_is_flagged_and_bf16x3_is_unaffected(gpu, oracle
     assert np.abs(got - ref).max() / np.abs(ref).max() < 5e-5
 
 
+@pytest.mark.parametrize("c,ns,dims,m", [(128, 32, [128, 128, 256], 300), (256, 16, [256, 256, 512], 300),
+                                         (256, 32, [256, 512, 1024], 300), (200, 24, [160, 136], 90)])
+@pytest.mark.parametrize("bad", [float("nan"), -float("nan"), float("inf"), -float("inf")])
+def test_group_mlp_fp16_nan_and_inf_inputs_are_flagged(gpu, c, ns, dims, m, bad):
+    # the range guard reduced with v_pk_max_f16 (maxNum: a NaN half next to a finite one is dropped) and the
+    # packed ReLU turns a NaN activation into 0 -- a NaN input became zeros without raising the flag, where the
+    # reference would propagate it.  The input guard now compares magnitude bits as integers: NaN and inf of either
+    # sign, in a single gathered feature value, raise the word.
+    rng = np.random.default_rng(c + ns)
+    b, n = 2, 600
+    xyz = _cloud(rng, b, n, scale=4.0)
+    feat = rng.normal(0, 1, (b, n, c)).astype(np.float32)
+    new_xyz = xyz[:, rng.integers(0, n, m)] + rng.normal(0, 0.1, (b, m, 3)).astype(np.float32)
+    idx = rng.integers(0, n, (b, m, ns)).astype(np.int32)
+    cnt = rng.integers(1, ns + 1, (b, m)).astype(np.int32)
+    pidx = _pad_like_ball_query(idx, cnt)
+    ws, bs = _rand_layers(rng, [c + 3] + dims)
+    _run_group_mlp(gpu, xyz, feat, new_xyz, pidx, cnt, ws, bs, precision="fp16", overflow_ok=True)
+    assert _run_group_mlp.overflow == 0
+    feat[1, pidx[1, 11, 0], 6] = bad
+    _run_group_mlp(gpu, xyz, feat, new_xyz, pidx, cnt, ws, bs, precision="fp16", overflow_ok=True)
+    assert _run_group_mlp.overflow == 1, "fp16 form: %r input not flagged" % bad
+
+
 def test_backbone_raises_on_fp16_overflow_and_runs_in_bf16x3(gpu):
     # the same guard one level up: a feature scale that pushes layer3's inputs out of the fp16 range makes
     # SABackbone.raise_if_overflow() raise under the default per-scale precision rule, and precision="bf16x3" runs clean

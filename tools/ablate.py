@@ -39,6 +39,8 @@ class SkipProxy:
 
 
 COALESCE = int(os.environ.get("ABLATE_COALESCE", "4"))
+MODE = os.environ.get("ABLATE_MODE", "slots")          # "staged": ABLATE_COALESCE=8 ABLATE_STREAMS=4
+STREAMS = int(os.environ.get("ABLATE_STREAMS", "16"))
 
 
 def run(skip, steps=512, warmup=64):
@@ -48,8 +50,8 @@ def run(skip, steps=512, warmup=64):
     try:
         cfgs, syn = pkg("configs"), pkg("synthetic")
         arch = cfgs.KITTI_3DSSD_ARCH
-        pipe = pkg("pipeline").SAPipeline(arch, syn.random_backbone_params(arch), "cuda:0", batch=8, points=16384, streams=16,
-                                          check_overflow=False, coalesce=COALESCE)
+        pipe = pkg("pipeline").SAPipeline(arch, syn.random_backbone_params(arch), "cuda:0", batch=8, points=16384, streams=STREAMS,
+                                          check_overflow=False, coalesce=COALESCE, mode=MODE)
     finally:
         native._LIB = real            # the graphs are captured: replays no longer go through ctypes
     batches = [torch.from_numpy(syn.kitti_like_batch(8, first_frame=8 * i)).cuda() for i in range(20)]

@@ -40,7 +40,8 @@ def main():
     base = pkg("backbone").SABackbone(arch, params, dev, cfgs.KITTI_MAX_TRANSLATE_RANGE, True, None)
     batches = [torch.from_numpy(np.stack([syn.frame_of("default", 8 * i + f, 16384) for f in range(8)])).to(dev) for i in range(20)]
     for k in ks:
-        pipe = P.SAPipeline(arch, params, dev, net=Padded(base, k, dev), max_translate_range=cfgs.KITTI_MAX_TRANSLATE_RANGE)
+        pipe = P.SAPipeline(arch, params, dev, net=Padded(base, k, dev), max_translate_range=cfgs.KITTI_MAX_TRANSLATE_RANGE,
+                            mode="slots", streams=16)
         res = []
         for rep in range(3):
             for i in range(24):
