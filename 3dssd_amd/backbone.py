@@ -11,14 +11,17 @@ from .utils.weights import VariableStore
 
 class SABackbone:
     def __init__(self, arch, params, device="cuda:0", max_translate_range=(-3.0, -2.0, -3.0),
-                 aggregation_sa_feature=True, precision=None):
+                 aggregation_sa_feature=True, precision=None, dfps_side_stream=None):
         """precision: None = per-scale rule of utils/weights.py (fp16 one-pass on the wide scales, split bf16 elsewhere),
-        "bf16x3" = split bf16 everywhere (~1e-5 of fp32, no range limit), "fp16" = one pass wherever the weights fit."""
+        "bf16x3" = split bf16 everywhere (~1e-5 of fp32, no range limit), "fp16" = one pass wherever the weights fit.
+        dfps_side_stream: where the F-FPS || D-FPS launch of an 'FS' layer is issued (layers_util.DFPS_SIDE_STREAM; None =
+        its default 6, a helper-stream branch; 5 = on the issuing stream, which keeps a captured graph linear)."""
         self.device = torch.device(device)
         self.variables = params if isinstance(params, VariableStore) else VariableStore(params, self.device, precision)
         # per instance (round 3 wrote them into layers_util's module attributes: two backbones shared the last value)
         self.settings = {"aggregation_sa_feature": bool(aggregation_sa_feature),
-                         "max_translate_range": tuple(float(v) for v in max_translate_range)}
+                         "max_translate_range": tuple(float(v) for v in max_translate_range),
+                         "dfps_side_stream": dfps_side_stream}
         self.layers = [LayerBuilder(i, False, arch, variables=self.variables, settings=self.settings)
                        for i in range(len(arch))]
 

@@ -11,8 +11,10 @@ pass (frames never interact: every kernel indexes its frame only).  Two ways to 
   mode="staged" (default)  three HIP streams, software-pipelined inside the executor.  A package is TWO captured
       hipGraphs: stage A = input split + layer-1 D-FPS + centres (SABackbone.forward_staged up to its yield) on the
       sampler stream S; stage B = everything else on one of two main streams M0 / M1, behind an event.  S runs
-      stage A of package k+1 / k+2 while M0 / M1 run stage B of packages k / k+1.  Needs 3 hardware queues (+ the
-      in-graph helper branch of the F-FPS ‖ D-FPS launch): ROCm's DEFAULT of 4 is enough, no environment variable.
+      stage A of package k+1 / k+2 while M0 / M1 run stage B of packages k / k+1.  The captured graphs are linear
+      chains (no helper-stream branch), so the executor needs exactly 3 hardware queues: ROCm's DEFAULT of 4 is
+      enough, no environment variable.  Measured (profiles/r04_sweep_queues.txt): the same throughput on 4, 8 and 16
+      queues, and at least that of the 16-slot mode in the short and in the long run.
   mode="slots"  `streams` slots, each a HIP stream with one captured hipGraph of the whole backbone (rounds 2-3).
       Needs as many hardware queues as slots (`request_hw_queues(16)` BEFORE the HIP runtime starts), and collapses
       when it does not get them (measured: profiles/r04_sweep_queues.txt).
@@ -24,8 +26,10 @@ pass (frames never interact: every kernel indexes its frame only).  Two ways to 
 Slots are reused round-robin: the tensors a ticket hands out are the slot's static output buffers and stay valid
 until the slot's next round starts (`nslots x coalesce` further submits; use copy=True, or pass out=(xyz, feat) to
 `submit`, to keep them longer); `result()` raises if the slot was already reused.  A package that is only partly
-filled is launched by `flush()`, `drain()` or the first `result()` / `wait()` on one of its tickets; its unfilled
-parts are zeroed first.  Lifetime rule for inputs: `submit` copies the batch on an executor stream; a CUDA batch is
+filled is launched by `flush()`, `drain()` or the first `result()` / `wait()` on one of its tickets: every slot has
+captured graphs for `coalesce`, `coalesce / 2` and `coalesce / 4` batches (one memory pool: they never run at the same
+time), the smallest one that holds the package runs, and parts it has beyond the fill are copies of the package's
+first batch (real frames: all-zero frames would be the degenerate worst case of every data-dependent kernel).  Lifetime rule for inputs: `submit` copies the batch on an executor stream; a CUDA batch is
 `record_stream`-ed there, so the caller may drop it right after `submit`.  fp16 range guard (csrc/mlp_act.h): every
 round of a slot has its own flag word, zeroed on the slot's stream before the round and copied to pinned host memory
 after it -- a ticket raises for ITS package only.  Nothing here is a collective: on a multi-GPU node every rank owns
@@ -70,10 +74,10 @@ def hw_queues():
 
 class _Round:
     """One use of a slot: the package of up to `coalesce` batches that is launched together."""
-    __slots__ = ("slot", "fill", "launched", "event", "flag", "outs", "marks")
+    __slots__ = ("slot", "fill", "size", "launched", "event", "flag", "outs")
 
     def __init__(self, slot, flag):
-        self.slot, self.fill, self.launched, self.event, self.flag, self.outs, self.marks = slot, 0, False, None, flag, [], None
+        self.slot, self.fill, self.size, self.launched, self.event, self.flag, self.outs = slot, 0, 0, False, None, flag, []
 
 
 class Ticket:
@@ -99,8 +103,9 @@ class Ticket:
         return self._round.slot.round is not self._round
 
     def _views(self):
-        s, B = self._round.slot, self._round.slot.pipe.batch
-        return s.out_xyz[self._part * B:(self._part + 1) * B], s.out_feat[self._part * B:(self._part + 1) * B]
+        r, B = self._round, self._round.slot.pipe.batch
+        xl, fl, _ = r.slot.lists[r.size]
+        return xl[-1][self._part * B:(self._part + 1) * B], fl[-1][self._part * B:(self._part + 1) * B]
 
     def result(self, copy=False):
         """(new_xyz [B,m,3], features [B,m,C]) of the backbone's last row.  With `out=` given at submit time those
@@ -135,28 +140,39 @@ class Ticket:
             raise RuntimeError("this ticket's slot has been reused by a later submit")
         B, p = self._round.slot.pipe.batch, self._part
         cut = lambda t: None if t is None else t[p * B:(p + 1) * B]
-        return tuple([cut(t) for t in lst] for lst in self._round.slot.lists)
+        return tuple([cut(t) for t in lst] for lst in self._round.slot.lists[self._round.size])
 
 
 class _Slot:
-    __slots__ = ("pipe", "index", "stream_a", "stream_b", "inp", "overflow", "graph_a", "graph_b", "out_xyz", "out_feat",
-                 "lists", "round", "last_event")
+    # graphs: {package size (batches): (stage-A graph or None, stage-B / whole graph)}; lists: {size: forward()'s lists}
+    __slots__ = ("pipe", "index", "stream_a", "stream_b", "inp", "overflow", "graphs", "lists", "round", "last_event")
 
 
 class SAPipeline:
     def __init__(self, arch, params, device="cuda:0", batch=8, points=16384, channels=4, streams=None,
                  graphs=True, max_translate_range=(-3.0, -2.0, -3.0), aggregation_sa_feature=True, net=None,
-                 precision=None, check_overflow=True, coalesce=1, mode="staged", timeline=False):
+                 precision=None, check_overflow=True, coalesce=1, mode="staged", timeline=False, linear_graphs=None,
+                 main_streams=MAIN_STREAMS):
         """arch / params as for SABackbone.  mode / coalesce: module docstring.  `streams`: the number of slots --
         packages in the ring for mode="staged" (default 4), slots = HIP streams for mode="slots" (default 16).
         graphs=False launches eagerly on the same streams (frames whose layer-1 sampler cannot be captured).
-        timeline=True records HIP timing events around every package (`timeline()`)."""
+        timeline=True records HIP timing events around every package (`timeline()`).  linear_graphs=True issues the
+        F-FPS || D-FPS launch of the 'FS' layers on the capturing stream instead of a helper-stream branch, so that a
+        captured graph is one linear chain and its replay needs no internal branch stream -- the default for
+        mode="staged" (with branches the three streams + two branch streams share ROCm's default 4 hardware queues and
+        block one another: 10.8 k instead of 16.2 k frames/s, profiles/r04_sweep_queues.txt); mode="slots" defaults to
+        the branch form (15.7 k against 14.6 k on 16 queues).  main_streams: streams stage B alternates between."""
         self.device = torch.device(device)
         T.require(self.device.type == "cuda", "SAPipeline needs a GPU: the HIP path has no CPU fallback")
         T.require(mode in ("staged", "slots"), "SAPipeline mode must be 'staged' or 'slots'")
         N.lib()
+        if linear_graphs is None:
+            linear_graphs = mode == "staged"
+        self.linear_graphs = bool(linear_graphs)
+        self.n_main = max(1, int(main_streams))
         self.net = net if net is not None else SABackbone(arch, params, self.device, max_translate_range,
-                                                           aggregation_sa_feature, precision)
+                                                           aggregation_sa_feature, precision,
+                                                           dfps_side_stream=5 if linear_graphs else None)
         self.check_overflow = bool(check_overflow)
         self.mode = mode
         self.batch, self.points, self.channels = int(batch), int(points), int(channels)
@@ -164,6 +180,7 @@ class SAPipeline:
             streams = DEFAULT_PACKAGES if mode == "staged" else DEFAULT_STREAMS
         self.nslots = max(1, int(streams))
         self.coalesce = max(1, int(coalesce))
+        self.sizes = sorted({self.coalesce, max(1, self.coalesce // 2), max(1, self.coalesce // 4)})
         self.graphs = bool(graphs)
         self.record_timeline = bool(timeline)
         self._timeline = []
@@ -184,18 +201,17 @@ class SAPipeline:
         shape = (self.batch * self.coalesce, self.points, self.channels)
         if self.mode == "staged":
             self.sampler_stream = torch.cuda.Stream(device=dev)
-            self.main_streams = [torch.cuda.Stream(device=dev) for _ in range(MAIN_STREAMS)]
+            self.main_streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_main)]
         self.slots = []
         for i in range(self.nslots):
             s = _Slot()
-            s.pipe, s.index, s.graph_a, s.graph_b = self, i, None, None
+            s.pipe, s.index, s.graphs, s.lists = self, i, {}, {}
             if self.mode == "staged":
-                s.stream_a, s.stream_b = self.sampler_stream, self.main_streams[i % MAIN_STREAMS]
+                s.stream_a, s.stream_b = self.sampler_stream, self.main_streams[i % self.n_main]
             else:
                 s.stream_a = s.stream_b = torch.cuda.Stream(device=dev)
             s.inp = torch.zeros(shape, dtype=torch.float32, device=dev)
             s.overflow = torch.zeros(1, dtype=torch.int32, device=dev)
-            s.out_xyz = s.out_feat = s.lists = None
             s.round, s.last_event = None, None
             self.slots.append(s)
         if not self.graphs:
@@ -204,44 +220,52 @@ class SAPipeline:
         # tensor first created inside a capture would live in that graph's private pool
         warm = torch.zeros(shape, dtype=torch.float32, device=dev)
         warm[:, :, :3] = torch.rand((shape[0], self.points, 3), device=dev) * 20.0
-        for _ in range(2):
-            self.net(warm)
+        for size in self.sizes:
+            for _ in range(2):
+                self.net(warm[:size * self.batch])
         torch.cuda.synchronize(dev)
         for s in self.slots:
             s.inp.copy_(warm)
         torch.cuda.synchronize(dev)
         for s in self.slots:
-            with self._flag_word(s):
-                if self.mode == "staged":
-                    gen = self.net.forward_staged(s.inp)
-                    ga = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(ga, stream=s.stream_a):
-                        next(gen)
-                    gb = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gb, stream=s.stream_b, pool=ga.pool()):
-                        try:
+            pool = None
+            for size in reversed(self.sizes):                 # the largest first: the smaller ones fit into its pool
+                view = s.inp[:size * self.batch]
+                kw = {} if pool is None else {"pool": pool}
+                with self._flag_word(s):
+                    if self.mode == "staged":
+                        gen = self.net.forward_staged(view)
+                        ga = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(ga, stream=s.stream_a, **kw):
                             next(gen)
-                            raise RuntimeError("forward_staged yielded twice")
-                        except StopIteration as e:
-                            xl, fl, il = e.value
-                    s.graph_a, s.graph_b = ga, gb
-                else:
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=s.stream_b):
-                        xl, fl, il = self.net(s.inp)
-                    s.graph_b = g
-            s.lists = (xl, fl, il)
-            s.out_xyz, s.out_feat = xl[-1], fl[-1]
+                        pool = pool or ga.pool()
+                        gb = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(gb, stream=s.stream_b, pool=pool):
+                            try:
+                                next(gen)
+                                raise RuntimeError("forward_staged yielded twice")
+                            except StopIteration as e:
+                                lists = e.value
+                        s.graphs[size] = (ga, gb)
+                    else:
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, stream=s.stream_b, **kw):
+                            lists = self.net(view)
+                        pool = pool or g.pool()
+                        s.graphs[size] = (None, g)
+                s.lists[size] = lists
         torch.cuda.synchronize(dev)
         # every graph replayed once as part of the set-up (the first replay uploads the executable graph)
         for s in self.slots:
-            if s.graph_a is not None:
-                with torch.cuda.stream(s.stream_a):
-                    s.graph_a.replay()
+            for size in self.sizes:
+                ga, gb = s.graphs[size]
+                if ga is not None:
+                    with torch.cuda.stream(s.stream_a):
+                        ga.replay()
+                    torch.cuda.synchronize(dev)
+                with torch.cuda.stream(s.stream_b):
+                    gb.replay()
                 torch.cuda.synchronize(dev)
-            with torch.cuda.stream(s.stream_b):
-                s.graph_b.replay()
-            torch.cuda.synchronize(dev)
 
     class _flag_word:
         """While a slot's kernels are enqueued / captured, the network's fp16 range flag IS the slot's own word."""
@@ -299,31 +323,36 @@ class SAPipeline:
         return t
 
     def _launch(self, s):
-        """Run slot `s` over what its input buffer holds (unfilled parts zeroed); the slot the next submit fills is
-        the one after it."""
+        """Run slot `s` over what its input buffer holds: the smallest captured package size that holds the fill (parts
+        beyond the fill = copies of the first batch); the slot the next submit fills is the one after it."""
         r = s.round
         if r is None or r.launched:
             return
         B = self.batch
         tl = self.record_timeline
+        size = r.size = min(z for z in self.sizes if z >= r.fill)
+        view = s.inp[:size * B]
         with torch.cuda.device(self.device):
             a, b = s.stream_a, s.stream_b
             marks = []
             with torch.cuda.stream(a):
                 if tl:
                     marks.append(self._mark(a))
-                if r.fill < self.coalesce:
-                    s.inp[r.fill * B:].zero_()            # no stale frames (their range flags would re-raise)
+                if r.fill < size:
+                    k = size - r.fill
+                    s.inp[r.fill * B:size * B].view(k, B, self.points, self.channels).copy_(
+                        s.inp[:B].unsqueeze(0).expand(k, B, self.points, self.channels))
+            ga, gb = s.graphs.get(size, (None, None))
             staged = self.mode == "staged"
             gen = None
             if staged:
                 if s.last_event is not None:
                     a.wait_event(s.last_event)            # stage B of the slot's previous round still reads stage A's outputs
                 with torch.cuda.stream(a):
-                    if s.graph_a is not None:
-                        s.graph_a.replay()
+                    if ga is not None:
+                        ga.replay()
                     else:
-                        gen = self.net.forward_staged(s.inp)
+                        gen = self.net.forward_staged(view)
                         next(gen)
                     ev = torch.cuda.Event(enable_timing=tl)
                     ev.record(a)
@@ -332,8 +361,8 @@ class SAPipeline:
                 b.wait_event(ev)
             with torch.cuda.stream(b):
                 s.overflow.zero_()
-                if s.graph_b is not None:
-                    s.graph_b.replay()
+                if gb is not None:
+                    gb.replay()
                 else:
                     with self._flag_word(s):
                         if gen is not None:
@@ -341,13 +370,13 @@ class SAPipeline:
                                 next(gen)
                                 raise RuntimeError("forward_staged yielded twice")
                             except StopIteration as e:
-                                xl, fl, il = e.value
+                                s.lists[size] = e.value
                         else:
-                            xl, fl, il = self.net(s.inp)
-                    s.lists, s.out_xyz, s.out_feat = (xl, fl, il), xl[-1], fl[-1]
+                            s.lists[size] = self.net(view)
+                xl, fl, _ = s.lists[size]
                 for part, (ox, of) in r.outs:
-                    N.copy_blocks([(s.out_xyz[part * B:(part + 1) * B], ox, B, s.out_xyz.shape[1], 3),
-                                   (s.out_feat[part * B:(part + 1) * B], of, B, s.out_feat.shape[1], s.out_feat.shape[2])])
+                    N.copy_blocks([(xl[-1][part * B:(part + 1) * B], ox, B, xl[-1].shape[1], 3),
+                                   (fl[-1][part * B:(part + 1) * B], of, B, fl[-1].shape[1], fl[-1].shape[2])])
                 self._flags[r.flag:r.flag + 1].copy_(s.overflow, non_blocking=True)
                 r.event = torch.cuda.Event(enable_timing=tl)
                 r.event.record(b)

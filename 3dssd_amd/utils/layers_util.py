@@ -221,9 +221,12 @@ def _dfps_into(npoint, xyz, start, end, out, col, ctr):
     return done[0]
 
 
-def sample_layer(xyz, points, fps_sample_range_list, fps_method_list, npoint_list, former_fps_idx, vote_ctr, radius_list):
+def sample_layer(xyz, points, fps_sample_range_list, fps_method_list, npoint_list, former_fps_idx, vote_ctr, radius_list,
+                 side_mode=None):
     """The sampling half of pointnet_sa_module_msg (layers_util.py:84-119): range slicing, D-FPS / F-FPS / FS / identity
-    per range, index offsets, the centres.  Returns (fps_idx [B,m] int32, new_xyz [B,m,3], sliced_points or None)."""
+    per range, index offsets, the centres.  Returns (fps_idx [B,m] int32, new_xyz [B,m,3], sliced_points or None).
+    side_mode: DFPS_SIDE_STREAM for this call (None: the module default)."""
+    side_mode = DFPS_SIDE_STREAM if side_mode is None else side_mode
     bs, n_all, _ = xyz.shape
     dev = xyz.device
 
@@ -261,7 +264,7 @@ def sample_layer(xyz, points, fps_sample_range_list, fps_method_list, npoint_lis
     has_f = any(k in ("FS", "F-FPS") for k, _s, _e, _c in plan)
     has_d = any(k in ("FS", "D-FPS") for k, _s, _e, _c in plan)
     main = torch.cuda.current_stream()
-    side = _side_stream(main) if (has_f and has_d and DFPS_SIDE_STREAM in (1, 2)) else None
+    side = _side_stream(main) if (has_f and has_d and side_mode in (1, 2)) else None
     # The samplers read their range of xyz / points in place (frame stride = the whole tensor's) and write the picked
     # points themselves: no slice copies, no separate gather_point launch (:116-119) -- each launch of a step costs
     # 25-50 us of its span when 16 steps are in flight (tools/dispatch_chain.py).
@@ -289,7 +292,7 @@ def sample_layer(xyz, points, fps_sample_range_list, fps_method_list, npoint_lis
     # ---- one matrix sampler + one coordinate sampler (an 'FS' range, or an F-FPS range and a D-FPS range): ONE launch
     #      for both (sa_fps_dual_ex, modes 5 / 6); anything else takes the per-sampler path below
     dual_done = f_handled = False
-    if DFPS_SIDE_STREAM in (5, 6):
+    if side_mode in (5, 6):
         fparts = [(s0, e0, (c // 2 if k == "FS" else c), c0) for k, s0, e0, c, c0 in work if k in ("FS", "F-FPS")]
         dparts = [(s0, e0, (c // 2 if k == "FS" else c), (c0 + c // 2 if k == "FS" else c0)) for k, s0, e0, c, c0 in work
                   if k in ("FS", "D-FPS")]
@@ -305,7 +308,7 @@ def sample_layer(xyz, points, fps_sample_range_list, fps_method_list, npoint_lis
                                           xyz.data_ptr() + 12 * fs, 3 * n_all, cptr(fc), cstr, de - ds, dm,
                                           xyz.data_ptr() + 12 * ds, 3 * n_all, fps_idx.data_ptr() + 4 * dc, fps_idx.shape[1],
                                           ds, cptr(dc), cstr, N.current_stream())
-            if DFPS_SIDE_STREAM == 6:                       # on the helper stream between a fork and a join event
+            if side_mode == 6:                       # on the helper stream between a fork and a join event
                 hs = _side_stream(main)
                 ev = torch.cuda.Event()
                 ev.record(main)
@@ -333,7 +336,7 @@ def sample_layer(xyz, points, fps_sample_range_list, fps_method_list, npoint_lis
                                                                    for k, s0, e0, c, c0 in work if k == "FS"]
     if dual_done:
         side = None
-    if DFPS_SIDE_STREAM in (2, 3):
+    if side_mode in (2, 3):
         centres_ok = ffps_all() and centres_ok
     if side is not None:
         ev = torch.cuda.Event()
@@ -348,7 +351,7 @@ def sample_layer(xyz, points, fps_sample_range_list, fps_method_list, npoint_lis
                     centres_ok = _dfps_into(d_n, xyz, start, end, fps_idx, d_col, new_xyz) and centres_ok
             else:
                 centres_ok = _dfps_into(d_n, xyz, start, end, fps_idx, d_col, new_xyz) and centres_ok
-    if DFPS_SIDE_STREAM not in (2, 3) and not f_handled:                    # F-FPS parts (:94-96,102-104)
+    if side_mode not in (2, 3) and not f_handled:                    # F-FPS parts (:94-96,102-104)
         centres_ok = ffps_all() and centres_ok
     if side is not None:
         ev = torch.cuda.Event()
@@ -380,7 +383,8 @@ def sample_layer(xyz, points, fps_sample_range_list, fps_method_list, npoint_lis
 def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_training, bn_decay, bn,
                            fps_sample_range_list, fps_method_list, npoint_list, former_fps_idx,
                            use_attention, scope, dilated_group, vote_ctr=None, aggregation_channel=None,
-                           debugging=False, epsilon=1e-5, variables=None, aggregation_sa_feature=None, presampled=None):
+                           debugging=False, epsilon=1e-5, variables=None, aggregation_sa_feature=None, presampled=None,
+                           dfps_side_stream=None):
     """layers_util.py:59-189.  xyz (B,n,3), points (B,n,C) -> new_xyz (B,m,3), new_points (B,m,C'),
     fps_idx (B,m) int32.  aggregation_sa_feature: cfg.MODEL.NETWORK.AGGREGATION_SA_FEATURE (None: the module default);
     presampled = (fps_idx, new_xyz, sliced_points) of an earlier `sample_layer` call with the same arguments (the staged
@@ -397,7 +401,7 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
         fps_idx, new_xyz, sliced_points = presampled
     else:
         fps_idx, new_xyz, sliced_points = sample_layer(xyz, points, fps_sample_range_list, fps_method_list, npoint_list,
-                                                       former_fps_idx, vote_ctr, radius_list)
+                                                       former_fps_idx, vote_ctr, radius_list, dfps_side_stream)
     m = new_xyz.shape[1]
     lib = N.lib()
     stream = N.current_stream()

@@ -152,9 +152,11 @@ def _algorithmic(name, a):
 
 
 EXECUTOR_NOTES = {
-    "staged": "3dssd_amd.pipeline.SAPipeline(mode='staged'): 3 HIP streams, %(n)d packages of %(C)d batches x %(B)d frames in a "
-              "ring; a package = two captured hipGraphs -- stage A (input split + layer-1 D-FPS + centres) on the sampler "
-              "stream, stage B (everything else) on one of two main streams behind an event; one block copy per step",
+    "staged": "3dssd_amd.pipeline.SAPipeline(mode='staged'): 3 HIP streams on ROCm's default 4 hardware queues (no "
+              "environment variable), %(n)d packages of %(C)d batches x %(B)d frames in a ring; a package = two captured, "
+              "linear hipGraphs -- stage A (input split + layer-1 D-FPS + centres) on the sampler stream, stage B "
+              "(everything else) on one of two main streams behind an event; one block copy per step; a partly filled "
+              "package runs the smallest captured size (C, C/2, C/4) that holds it",
     "slots": "3dssd_amd.pipeline.SAPipeline(mode='slots'): %(n)d slots = %(n)d HIP streams, each with one captured hipGraph "
              "of the backbone over %(C)d batches x %(B)d frames; one block copy per step, one replay per %(C)d steps",
 }
@@ -533,7 +535,7 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
     P = pkg("pipeline")
     pipe = P.SAPipeline(arch, params, dev, batch=args.batch, points=points, channels=4, streams=max(1, args.streams),
                         graphs=use_graphs, max_translate_range=cfgs.KITTI_MAX_TRANSLATE_RANGE,
-                        coalesce=max(1, args.coalesce), mode=args.executor)
+                        coalesce=max(1, args.coalesce), mode=args.executor, linear_graphs=args.linear_graphs, main_streams=args.main_streams)
     C = pipe.coalesce
     net = pipe.net
     # this rank's frame pool: global frame f -> rank f mod world (weak scaling: `batch` frames per GPU per step);
@@ -604,7 +606,7 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
         # queue count is fixed when the HIP runtime starts, and a second pipeline here would share queues with the first.
         torch.cuda.synchronize()
         alt = ({"executor": "slots", "streams": 16, "coalesce": 4} if args.executor == "staged" else
-               {"executor": "staged", "streams": P.DEFAULT_PACKAGES, "coalesce": 8})
+               {"executor": "staged", "streams": P.DEFAULT_PACKAGES, "coalesce": 16})
         cmd = [sys.executable, os.path.abspath(__file__), "--executor", alt["executor"], "--coalesce", str(alt["coalesce"]),
                "--streams", str(alt["streams"]), "--steps", str(args.steps), "--warmup", str(args.warmup),
                "--batch", str(args.batch), "--points", str(points), "--pool", str(args.pool),
@@ -648,7 +650,8 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
                    "frames_per_step_per_gpu": args.batch, "data": args.data, "pool_frames_per_gpu": nb * args.batch,
                    "executor": args.executor, "slots": pipe.nslots, "streams_used": pipe.streams_used(),
                    "hw_queues": P.hw_queues(), "hip_graphs": use_graphs,
-                   "batches_per_replay": C, "frames_per_launch": fpl,
+                   "batches_per_replay": C, "frames_per_launch": fpl, "package_sizes": pipe.sizes,
+                   "linear_graphs": pipe.linear_graphs,
                    "executor_note": EXECUTOR_NOTES[args.executor] % {"C": C, "B": args.batch, "n": pipe.nslots},
                    "sharding": "frame f -> rank f mod N, no data-path collective",
                    # what decides a short run (the driver record keeps `config` and `roofline` verbatim):
@@ -872,6 +875,8 @@ def main():
                     help="3dssd_amd/pipeline.py mode: staged (default; 3 streams, sampler stage ‖ the rest) or slots (one stream + graph per slot)")
     ap.add_argument("--streams", type=int, default=None, help="pipeline slots: packages in the ring (staged) / HIP streams (slots)")
     ap.add_argument("--coalesce", type=int, default=None, help="batches per package (frames per replay = batch x coalesce)")
+    ap.add_argument("--linear-graphs", type=int, default=None, help="1: the F-FPS || D-FPS launch on the capturing stream (captured graphs are linear chains; default for staged), 0: on a helper-stream branch (default for slots)")
+    ap.add_argument("--main-streams", type=int, default=2, help="staged executor: streams stage B alternates between")
     ap.add_argument("--hw-queues", type=int, default=None, help="GPU_MAX_HW_QUEUES for this run (default: unset for staged, = --streams for slots)")
     ap.add_argument("--verify", type=int, default=None, help="batches re-run through the pipeline and compared with eager (0: skip)")
     ap.add_argument("--profile-iters", type=int, default=3)
@@ -894,7 +899,7 @@ def main():
     if args.streams is None:
         args.streams = 4 if args.executor == "staged" else 16
     if args.coalesce is None:
-        args.coalesce = 8 if args.executor == "staged" else 4
+        args.coalesce = 16 if args.executor == "staged" else 4
     # hardware queues: fixed when the HIP runtime starts, so before the first CUDA call of this process
     args.hwq_from_env = "GPU_MAX_HW_QUEUES" in os.environ
     if args.hw_queues is not None:

@@ -85,6 +85,27 @@ def test_kitti_backbone_teacher_forced(gpu, oracle, batch, n, dup):
         assert _rel(fl[li + 1], rf) < TOL, "features of row %d (%s): %g" % (li, row[12], _rel(fl[li + 1], rf))
 
 
+@pytest.mark.parametrize("variant", ["rings64", "dense"])
+def test_backbone_teacher_forced_on_ring_structured_and_dense_frames(gpu, oracle, variant):
+    # the simulated 64-beam sweep (dense near-field rings: full balls, overflowing candidate lists, many FPS ties in the
+    # with-replacement pad) and the uniform box, layer by layer against the oracle like the KITTI-shape frames above
+    cfgs, syn = pkg("configs"), pkg("synthetic")
+    arch = cfgs.KITTI_3DSSD_ARCH
+    params = syn.random_backbone_params(arch)
+    pts = np.stack([syn.frame_of(variant, 5 + i) for i in range(2)])
+    xl, fl, il = _run_gpu(arch, params, pts, gpu)
+    for li, row in enumerate(arch):
+        rx, rf, ri = _oracle_row(oracle, row, xl[:li + 1], fl[:li + 1], il[:li + 1], params,
+                                 cfgs.KITTI_MAX_TRANSLATE_RANGE)
+        if ri is not None:
+            assert np.array_equal(il[li + 1], ri), "fps_idx of row %d (%s) differs" % (li, row[12])
+        if row[11] == "SA_Layer":
+            assert np.array_equal(xl[li + 1], rx), "centres of row %d differ" % li
+        else:
+            assert _rel(xl[li + 1], rx) < TOL
+        assert _rel(fl[li + 1], rf) < TOL, "features of row %d (%s): %g" % (li, row[12], _rel(fl[li + 1], rf))
+
+
 @pytest.mark.parametrize("first_frame", [7, 41, 300, 1234])
 def test_kitti_backbone_free_running(gpu, oracle, first_frame):
     cfgs, syn = pkg("configs"), pkg("synthetic")

@@ -283,6 +283,27 @@ def test_gather_and_group_point(gpu, oracle, c):
     assert np.array_equal(got, oracle.group_point(pts, gidx))
 
 
+@pytest.mark.parametrize("b,n,c,m,ns", [(3, 700, 3, 37, 16),      # 4-rows-per-lane path, rows per frame % 64 != 0
+                                         (2, 900, 3, 33, 7),       # rows per frame % 4 != 0 -> generic path
+                                         (2, 4096, 64, 1024, 32),  # layer-2 shape: 64-row blocks, one frame per block
+                                         (3, 500, 64, 21, 5),      # blocks straddle frames, ragged tail
+                                         (2, 512, 128, 100, 32), (2, 512, 256, 60, 16), (5, 300, 4, 19, 9),
+                                         (2, 300, 8, 50, 3), (1, 100, 16, 1, 1), (2, 640, 32, 64, 64), (2, 300, 12, 31, 4)])
+def test_group_and_gather_point_shapes_of_the_fast_paths(gpu, oracle, b, n, c, m, ns):
+    # round 4: gather.hip's 64-row-block kernels (c = 4..256, a power of two), the packed c = 3 kernel and the generic
+    # fallback -- bit-exact copies, -1 rows zero (group_point), frame boundaries inside a block, ragged ends
+    S = pkg("utils.tf_ops.sampling.tf_sampling")
+    G = pkg("utils.tf_ops.grouping.tf_grouping")
+    rng = np.random.default_rng(b * 1000 + c * 10 + ns)
+    pts = rng.normal(0, 1, (b, n, c)).astype(np.float32)
+    gidx = rng.integers(-1, n, (b, m, ns)).astype(np.int32)
+    gidx[:, 0, :] = -1                                            # a whole ball of zero rows
+    got = G.group_point(_t(pts, gpu), _t(gidx, gpu)).cpu().numpy()
+    assert np.array_equal(got, oracle.group_point(pts, gidx))
+    idx = rng.integers(0, n, (b, m * ns)).astype(np.int32)
+    assert np.array_equal(S.gather_point(_t(pts, gpu), _t(idx, gpu)).cpu().numpy(), oracle.gather_point(pts, idx))
+
+
 # ----------------------------------------------------------------------------------- ball query
 def _check_ball(got_idx, got_cnt, ref_idx, ref_cnt):
     assert np.array_equal(got_cnt, ref_cnt)
@@ -959,6 +980,29 @@ def test_grid_ball_query_matches_oracle(gpu, oracle, n, m, scale, radii, nss, di
         else:
             ridx, rcnt = oracle.query_ball_point(radii[i], nss[i], xyz1, xyz2)
         _check_ball(idx[i], cnt[i], ridx, rcnt)
+
+
+@pytest.mark.parametrize("variant,radii,nss", [("dense", [0.2, 0.4, 0.8], [32, 32, 64]),      # every band of every query overflows
+                                                ("rings64", [0.2, 0.4, 0.8], [32, 32, 64]),    # near-field balls overflow, far ones do not
+                                                ("rings64", [0.4, 0.8, 1.6], [32, 32, 64]),
+                                                ("dense", [0.5, 3.0], [192, 5]),               # the largest nsample the grid kernel takes
+                                                ("rings64", [1.0], [200])])                    # beyond it: the plain scan kernels
+def test_grid_ball_query_bands_with_more_hits_than_the_lds_list(gpu, oracle, variant, radii, nss):
+    # round 4: a band whose hits exceed its 256-entry LDS list is cut down IN PLACE to its nsample smallest indices
+    # (bisection on ballots) instead of being redone by an ordered scan of all n points -- same rows, same counts
+    syn = pkg("synthetic")
+    n, m = 16384, 384
+    xyz1 = np.stack([syn.frame_of(variant, 11 + i, n)[:, :3] for i in range(2)])
+    rng = np.random.default_rng(len(radii) + nss[0])
+    xyz2 = np.ascontiguousarray(np.stack([x[rng.permutation(n)[:m]] for x in xyz1]))
+    rmins = [0.0] + radii[:-1]
+    idx, cnt = _run_grid_bq(gpu, xyz1, xyz2, rmins, radii, nss, True)
+    over = 0
+    for i in range(len(radii)):
+        ridx, rcnt = oracle.query_ball_point_dilated(rmins[i], radii[i], nss[i], xyz1, xyz2)
+        _check_ball(idx[i], cnt[i], ridx, rcnt)
+        over += int((rcnt >= nss[i]).sum())
+    assert over > 0                                               # the case really has full balls
 
 
 @pytest.mark.parametrize("b,n,m", [(8, 3000, 64), (16, 2500, 96), (8, 2100, 30), (8, 2200, 40)])

@@ -67,10 +67,10 @@ def test_pipeline_takes_pinned_host_batches_and_checks_shapes(gpu, pipe6):
         pipe.submit(torch.zeros((2, 16384, 4), device=gpu, dtype=torch.float64))
 
 
-@pytest.mark.parametrize("variant", ["dup10", "dense"])
+@pytest.mark.parametrize("variant", ["dup10", "dense", "rings64"])
 def test_pipeline_on_the_other_data_variants(gpu, pipe6, variant):
-    # the sensitivity variants of bench.py --data: duplicated rows (tie-breaks) and the uniform box where every ball is
-    # full (candidate lists of the grid ball query overflow, row plans are dense)
+    # the sensitivity variants of bench.py --data: duplicated rows (tie-breaks), the uniform box where every ball is
+    # full (candidate lists of the grid ball query overflow, row plans are dense) and the simulated 64-beam sweep
     pipe = pipe6
     dev = [torch.from_numpy(h).to(gpu) for h in _batches(variant, 6, 2, first=50)]
     eager = [pipe.forward_eager(t)[1][-1].clone() for t in dev]
