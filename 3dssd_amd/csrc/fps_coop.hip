@@ -9,8 +9,17 @@
 //   * the picked point's c channels (scalar loads, L2 hits), and
 //   * one 8-byte slot per workgroup: {max value | pick number | tie key}, written with an agent-scope atomic
 //     store and polled by the G-1 partners (agent-scope atomic loads) -- the cross-workgroup arg-max.
-// Co-residency of the partners is guaranteed by hipLaunchCooperativeKernel; the poll is bounded and traps, so a
-// bug cannot hang the device.
+// Co-residency of the partners: an eager call uses hipLaunchCooperativeKernel (the runtime guarantees it and runs
+// cooperative grids one at a time).  Cooperative launches cannot be captured into a hipGraph, so on a CAPTURING stream the
+// same kernel is launched plainly (round 4): the grid of one launch never exceeds the device's
+// resident capacity for this kernel (checked below, larger batches run as consecutive launches inside the call), and
+// the CALLER guarantees that no two such launches from different streams are in flight together -- the staged
+// executor (pipeline.py) issues every layer-1 sampling stage on its one sampler stream, and refuses graphs in its
+// one-stream-per-slot mode for frames that need this kernel.  Why the restriction: partners of one frame sit on up to
+// eight XCDs, each XCD places its workgroups in its own order, and with two such grids interleaved by the dispatcher
+// XCD 0 can fill up with halves of grid X whose partners queue on XCD 1 behind halves of grid Y whose partners queue
+// on XCD 0 behind X.  One grid at a time cannot do that (the oldest incomplete frame is first in every queue).  The
+// poll is bounded and traps, so a violated assumption aborts the process instead of hanging the device.
 // Tried and dropped (measured, MI355X): keeping the G partners of a frame on one XCD (ids of one residue class mod 8,
 // verified in-kernel through HW_REG_XCC_ID) and exchanging the slots through that XCD's L2 instead of the
 // device-coherent sc1 path.  A plain / sc0 store is not seen by an sc0 load outside threadgroup-split mode (poll
@@ -156,10 +165,11 @@ extern "C" int sa_fps_coop_ex(int b, int n, int c, int m, const float *inp, floa
     const int G = 1 << gshift;
     if ((size_t)n * sizeof(float) < (size_t)2 * G * sizeof(unsigned long long)) return SA_ERR_UNSUPPORTED;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess) {
         (void)hipGetLastError();
-        return SA_ERR_UNSUPPORTED;                      // cooperative launches are not captured into graphs
+        return SA_ERR_UNSUPPORTED;
     }
+    const bool capturing = cs != hipStreamCaptureStatusNone;   // -> plain launches (header comment)
     if (v->cap == 0) {
         int dev = 0, cus = 0, per_cu = 0, coop = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
@@ -173,15 +183,20 @@ extern "C" int sa_fps_coop_ex(int b, int n, int c, int m, const float *inp, floa
     }
     if (v->cap < G) return SA_ERR_UNSUPPORTED;
     const int per_launch = v->cap / G;                  // frames per cooperative launch
-    unsigned long long *slots = (unsigned long long *)temp;
+    // every frame of the call has its OWN slots (2 G words), zeroed by one memset in front of the first launch: the
+    // consecutive launches of a large batch share nothing, so nothing depends on how a memset between two of them is
+    // ordered (a shared region re-zeroed between the launches gave wrong picks in frames of the SECOND launch when the
+    // call was replayed from a hipGraph beside other streams' kernels -- round 4, tools/dbg_pipe.py)
+    unsigned long long *slots0 = (unsigned long long *)temp;
+    if (hipMemsetAsync(slots0, 0, (size_t)b * 2 * G * sizeof(unsigned long long), stream) != hipSuccess) return SA_ERR_LAUNCH;
     for (int f0 = 0; f0 < b; f0 += per_launch) {
         const int nf = b - f0 < per_launch ? b - f0 : per_launch;
-        if (hipMemsetAsync(slots, 0, (size_t)nf * 2 * G * sizeof(unsigned long long), stream) != hipSuccess)
-            return SA_ERR_LAUNCH;
+        unsigned long long *slots = slots0 + (size_t)f0 * 2 * G;
         const float *inp_f = inp + (size_t)f0 * n * c;
         int *out_f = out + (size_t)f0 * out_stride;
         void *args[] = {&n, &m, &gshift, &inp_f, &slots, &out_f, &out_stride, &idx_off};
-        static const int plain = SA_KNOB("SA_FPS_COOP_PLAIN", 0);
+        static const int plain_knob = SA_KNOB("SA_FPS_COOP_PLAIN", 0);
+        const bool plain = capturing || plain_knob;
         const hipError_t le = plain ? hipLaunchKernel(v->fn, dim3(nf * G), dim3(kBlock), args, 0, stream)
                                     : hipLaunchCooperativeKernel(v->fn, dim3(nf * G), dim3(kBlock), args, 0, stream);
         if (le != hipSuccess) {

@@ -109,6 +109,24 @@ __global__ __launch_bounds__(256) void gather_rows3x4_kernel(long quads, int n, 
     }
 }
 
+// c == 1 (the intensity channel of layer 1): four rows per lane, one 16-byte store
+template <bool NEG1_ZERO>
+__global__ __launch_bounds__(256) void gather_rows1x4_kernel(long quads, int n, long quads_per_batch, int nblk_wg,
+                                                             const float *__restrict__ src, const vi4 *__restrict__ idx4,
+                                                             vf4 *__restrict__ out) {
+    int stride;
+    const int pos = sa::xcd_block(blockIdx.x, gridDim.x, nblk_wg, stride);
+    if (pos < 0) return;
+    for (long q = (long)pos * 256 + threadIdx.x; q < quads; q += (long)stride * 256) {
+        const vi4 a = idx4[q];
+        const float *fr = src + (size_t)(q / quads_per_batch) * n;
+        vf4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (NEG1_ZERO && a[k] == -1) ? 0.f : fr[a[k] == -1 ? 0 : a[k]];
+        __builtin_nontemporal_store(v, out + q);
+    }
+}
+
 template <bool NEG1_ZERO>
 int launch_gather(int b, int n, int c, long rows_per_batch, const float *src, const int *idx, float *out,
                   hipStream_t stream) {
@@ -142,6 +160,16 @@ int launch_gather(int b, int n, int c, long rows_per_batch, const float *src, co
         const int need = (int)(wgs > 4096 ? 4096 : wgs);
         const unsigned grid = (unsigned)((need + 7) & ~7);
         hipLaunchKernelGGL((gather_rows3x4_kernel<NEG1_ZERO>), dim3(grid), dim3(256), 0, stream, quads, n,
+                           rows_per_batch / 4, need, src, (const vi4 *)idx, (vf4 *)out);
+        SA_CHECK_LAUNCH();
+        return SA_OK;
+    }
+    if (c == 1 && rows_per_batch % 4 == 0 && (((uintptr_t)idx | (uintptr_t)out) % 16 == 0)) {
+        const long quads = rows / 4;
+        long wgs = (quads + 255) / 256;
+        const int need = (int)(wgs > 4096 ? 4096 : wgs);
+        const unsigned grid = (unsigned)((need + 7) & ~7);
+        hipLaunchKernelGGL((gather_rows1x4_kernel<NEG1_ZERO>), dim3(grid), dim3(256), 0, stream, quads, n,
                            rows_per_batch / 4, need, src, (const vi4 *)idx, (vf4 *)out);
         SA_CHECK_LAUNCH();
         return SA_OK;

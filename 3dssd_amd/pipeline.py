@@ -188,6 +188,10 @@ class SAPipeline:
         self.submitted = 0
         self._flags = torch.zeros(_FLAG_RING, dtype=torch.int32).pin_memory()
         self._flag_next = 0
+        T.require(not (mode == "slots" and self.graphs and self.points > 16384),
+                  "SAPipeline(mode='slots', graphs=True) cannot serve frames of more than 16384 points: their layer-1 sampler "
+                  "is the multi-workgroup kernel, whose captured (plain) launches must all be issued on ONE stream "
+                  "(csrc/fps_coop.hip) -- use mode='staged', or graphs=False")
         if mode == "slots" and self.nslots > hw_queues():
             warnings.warn("SAPipeline(mode='slots') with %d slots on %d hardware queues: slots beyond the queue count "
                           "serialise (call pipeline.request_hw_queues(%d) before the first CUDA call, or use "

@@ -6,7 +6,9 @@ there is NO collective on the data path.  torch.distributed (backend "nccl" = RC
 GPU box, "gloo" in the CPU tests) is used only to agree on the wall time (max over ranks), to add up the
 frame counts, and optionally to gather the small backbone outputs on rank 0.
 """
+import hashlib
 import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -70,3 +72,43 @@ def gather_outputs(xyz, feat):
     dist.all_gather(xs, xyz.contiguous())
     dist.all_gather(fs, feat.contiguous())
     return xs, fs
+
+
+def _digest(xyz, feat):
+    h = hashlib.sha1()
+    h.update(xyz.detach().cpu().contiguous().numpy().tobytes())
+    h.update(feat.detach().cpu().contiguous().numpy().tobytes())
+    return h.digest()
+
+
+def gather_check(xyz, feat):
+    """BASELINE.json configs[3] "RCCL result gather", with proof that it happened: all-gather this rank's last batch of
+    backbone outputs (gather_outputs), all-gather the 20-byte sha1 every rank computed of ITS OWN tensors, and check
+    that the tensor received in position r hashes to rank r's digest (rank order, no mix-up); `ranks_seen` is an
+    all-reduce(sum) of ones.  Not part of the timed path (lib/core/trainer.py:120-155 moves tower outputs likewise
+    outside any timing).  Under gloo (CPU tests; two ranks sharing one GPU) tensors travel through host memory."""
+    if not dist.is_initialized():
+        return {"ranks_seen": 1, "world": 1, "backend": None, "rank_order_ok": True, "bytes_gathered": 0, "ms": 0.0}
+    backend = dist.get_backend()
+    world = dist.get_world_size()
+    on_gpu = backend == "nccl"
+    x = xyz.contiguous() if on_gpu else xyz.detach().cpu().contiguous()
+    f = feat.contiguous() if on_gpu else feat.detach().cpu().contiguous()
+    dev = x.device
+    if on_gpu:
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    xs, fs = gather_outputs(x, f)
+    mine = torch.tensor(list(_digest(x, f)), dtype=torch.uint8, device=dev)
+    digs = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(digs, mine)
+    ones = torch.ones(1, dtype=torch.int32, device=dev)
+    dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+    if on_gpu:
+        torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    ok = all(bytes(digs[r].cpu().tolist()) == _digest(xs[r], fs[r]) for r in range(world))
+    distinct = len({bytes(d.cpu().tolist()) for d in digs})
+    nbytes = sum(t.numel() * t.element_size() for t in xs + fs)
+    return {"ranks_seen": int(ones.item()), "world": world, "backend": backend + (" (RCCL)" if on_gpu else ""),
+            "rank_order_ok": bool(ok), "distinct_rank_digests": distinct, "bytes_gathered": int(nbytes), "ms": round(ms, 3)}

@@ -590,6 +590,8 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
     packages = pipe.timeline(base[0])
     x_last, f_last = tickets[-1].result()
     assert f_last.shape == (args.batch, 256, 512) and x_last.shape == (args.batch, 256, 3)
+    # configs[3] "RCCL result gather" (untimed): every rank's last batch of outputs all-gathered and checked by digest
+    gathered = sh.gather_check(x_last, f_last) if args.gather else None
     overlap = overlap_probe(pipe, run, min(args.steps, 96)) if rank == 0 else None
     # latency of one batch alone on the device (no overlap), for the record
     torch.cuda.synchronize()
@@ -667,7 +669,7 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
                                          "note": "device-side times (HIP events, ms since the start of the timed region) of "
                                                  "the packages the timed steps ran in: reached by its stream, (layer-1 "
                                                  "sampling done,) complete"},
-                   "other_executor": other},
+                   "other_executor": other, "gather": gathered},
         "timed_window_ms": round(window_ms, 3),
         "single_stream_batch_latency_ms": round(latency_ms, 3),
         "latency_note": "one batch submitted alone and waited for: its package is launched at once, i.e. one pass over "
@@ -831,6 +833,28 @@ def workload_group_materialised(args, sh, rank, world, dev):
         return None
     stages = profile_stages(step, max(1, args.profile_iters))
     ms_step = t_max / args.steps * 1e3
+    # device time of the whole sequence: the same calls captured into one hipGraph and replayed (no host launch gaps, no
+    # per-call event floor: an event pair around a 2 us kernel reads 7-9 us)
+    graph_ms = None
+    try:
+        side = torch.cuda.Stream(device=dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            keep = step()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            g.replay()
+        e0.record()
+        for _ in range(20):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        graph_ms = e0.elapsed_time(e1) / 20
+        del keep
+    except Exception as e:  # noqa: BLE001
+        graph_ms = None
+        print("bench.py: graph timing of the group workload failed: %r" % (e,), file=sys.stderr)
     grp = [s for s in stages if s["kernel"] == "sa_group_point"]
     bq = [s for s in stages if s["kernel"].startswith("sa_query_ball")]
     grp_ms = sum(s["avg_ms"] * s["calls_per_step"] for s in grp)
@@ -847,6 +871,11 @@ def workload_group_materialised(args, sh, rank, world, dev):
                          "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
                          "traffic": None, "algorithmic_bytes": int(by_alg), "algorithmic_mb_per_frame": round(by_alg / len(frames) / 1e6, 2),
                          "kernel_ms": round(grp_ms + bq_ms, 5),
+                         "sequence_as_one_graph": None if graph_ms is None else {
+                             "ms": round(graph_ms, 5), "gbs": round(by_alg / graph_ms / 1e6, 1),
+                             "frac": round(by_alg / graph_ms / 1e6 / HBM_PEAK_GBS, 5),
+                             "note": "the same %d calls captured into ONE hipGraph, device time per replay (HIP events around "
+                                     "20 replays): no host gaps and no per-call event floor" % sum(s["calls_per_step"] for s in grp + bq)},
                          "group_point_only": {"ms": round(grp_ms, 5),
                                               "gbs": round(sum(s["mbytes"] * s["calls_per_step"] for s in grp) / grp_ms, 1) if grp_ms else 0.0,
                                               "frac": round(sum(s["mbytes"] * s["calls_per_step"] for s in grp) / grp_ms / HBM_PEAK_GBS, 5) if grp_ms else 0.0},
@@ -886,16 +915,19 @@ def main():
     ap.add_argument("--allow-knobs", action="store_true", help="run although SA_* / SA3D_* environment variables are set (recorded in the line)")
     ap.add_argument("--allow-shared-device", action="store_true",
                     help="--gpus N with fewer than N GPUs visible: ranks share devices (functional check of the multi-rank path)")
+    ap.add_argument("--gather", type=int, default=None, help="after the timed region all-gather every rank's last batch of outputs and check rank order by sha1 (default: on when --gpus > 1)")
     ap.add_argument("--launch-check", action="store_true", help="exercise only the launch path (works without a GPU)")
     args = ap.parse_args()
     assert args.gpus >= 1
     defaults = {"configs1": dict(steps=512, warmup=64, batch=8, points=16384, pool=256, verify=64, executor="staged"),
                 "configs2": dict(steps=4, warmup=1, batch=32, points=16384, streams=1, pool=32, verify=0, coalesce=1, executor="slots"),
-                "configs4": dict(steps=16, warmup=4, batch=16, points=65536, streams=4, pool=96, verify=8, coalesce=1, executor="slots"),
+                "configs4": dict(steps=16, warmup=4, batch=16, points=65536, streams=4, pool=96, verify=8, coalesce=1, executor="staged"),
                 "group": dict(steps=20, warmup=5, batch=8, points=16384, streams=1, pool=8, verify=0, coalesce=1, executor="slots")}[args.workload]
     for k, v in defaults.items():
         if getattr(args, k) is None:
             setattr(args, k, v)
+    if args.gather is None:
+        args.gather = 1 if args.gpus > 1 else 0
     if args.streams is None:
         args.streams = 4 if args.executor == "staged" else 16
     if args.coalesce is None:
@@ -938,8 +970,9 @@ def main():
     if args.workload == "configs1":
         line = workload_backbone(args, sh, rank, world, dev, args.points, True, "configs[1]")
     elif args.workload == "configs4":
-        # 65536-pt frames: layer-1 FPS is the cooperative multi-workgroup kernel, which cannot be graph-captured
-        line = workload_backbone(args, sh, rank, world, dev, args.points, False, "configs[4]")
+        # 65536-pt frames: layer-1 FPS is the multi-workgroup kernel (fps_coop.hip); captured as a plain launch, every
+        # such launch on the staged executor's one sampler stream (--executor slots falls back to eager launches)
+        line = workload_backbone(args, sh, rank, world, dev, args.points, args.executor == "staged", "configs[4]")
     elif args.workload == "group":
         line = workload_group_materialised(args, sh, rank, world, dev)
     else:

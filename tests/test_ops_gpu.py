@@ -288,7 +288,8 @@ def test_gather_and_group_point(gpu, oracle, c):
                                          (2, 4096, 64, 1024, 32),  # layer-2 shape: 64-row blocks, one frame per block
                                          (3, 500, 64, 21, 5),      # blocks straddle frames, ragged tail
                                          (2, 512, 128, 100, 32), (2, 512, 256, 60, 16), (5, 300, 4, 19, 9),
-                                         (2, 300, 8, 50, 3), (1, 100, 16, 1, 1), (2, 640, 32, 64, 64), (2, 300, 12, 31, 4)])
+                                         (2, 300, 8, 50, 3), (1, 100, 16, 1, 1), (2, 640, 32, 64, 64), (2, 300, 12, 31, 4),
+                                         (3, 800, 1, 40, 32), (2, 800, 1, 33, 7)])   # c = 1: packed / generic
 def test_group_and_gather_point_shapes_of_the_fast_paths(gpu, oracle, b, n, c, m, ns):
     # round 4: gather.hip's 64-row-block kernels (c = 4..256, a power of two), the packed c = 3 kernel and the generic
     # fallback -- bit-exact copies, -1 rows zero (group_point), frame boundaries inside a block, ragged ends

@@ -97,6 +97,28 @@ def test_eager_pipeline_mode_for_uncapturable_frames(gpu, mode):
         assert torch.equal(tk.result()[1], eager[i])
 
 
+def test_frames_beyond_16384_points_are_captured_by_the_staged_executor(gpu):
+    # round 4: the multi-workgroup layer-1 sampler (csrc/fps_coop.hip) is launched plainly on a
+    # capturing stream, every such launch on the staged executor's one sampler stream -> 20000-point frames run from
+    # hipGraphs, results equal to the eager (cooperative-launch) ones; the one-stream-per-slot mode refuses
+    cfgs, syn = pkg("configs"), pkg("synthetic")
+    arch = cfgs.KITTI_3DSSD_ARCH
+    params = syn.random_backbone_params(arch)
+    P = pkg("pipeline")
+    pipe = P.SAPipeline(arch, params, gpu, batch=2, points=20000, streams=3, coalesce=2,
+                        max_translate_range=cfgs.KITTI_MAX_TRANSLATE_RANGE, mode="staged")
+    assert pipe.graphs and all(ga is not None for s in pipe.slots for ga, _gb in s.graphs.values())
+    dev = [torch.from_numpy(h).to(gpu) for h in _batches("default", 9, 2, first=10, n=20000)]
+    eager = [pipe.forward_eager(t)[1][-1].clone() for t in dev]
+    torch.cuda.synchronize()
+    outs = [(torch.empty((2, 256, 3), device=gpu), torch.empty((2, 256, 512), device=gpu)) for _ in dev]
+    tickets = [pipe.submit(t, out=o) for t, o in zip(dev, outs)]   # 4 full packages + one of a single batch (size-1 graph)
+    for i, tk in enumerate(tickets):
+        assert torch.equal(tk.result()[1], eager[i]), i
+    with pytest.raises(ValueError, match="ONE stream"):
+        P.SAPipeline(arch, params, gpu, batch=1, points=20000, streams=2, mode="slots")
+
+
 @pytest.mark.parametrize("mode", ["staged", "slots"])
 def test_coalescing_slots_give_every_batch_its_own_eager_result(gpu, mode):
     # coalesce=3: a slot takes three consecutive batches and runs the backbone over all six frames in one pass.  Frames

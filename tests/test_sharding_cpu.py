@@ -25,7 +25,8 @@ def _worker(rank, world, port, q):
     xyz = torch.cat([xyz, torch.zeros(pad, 4, 3)])
     feat = torch.cat([feat, torch.zeros(pad, 4, 8)])
     xs, fs = sh.gather_outputs(xyz, feat)
-    q.put((r, mine, t, total, [float(x[0, 0, 0]) for x in xs]))
+    chk = sh.gather_check(xyz, feat)
+    q.put((r, mine, t, total, [float(x[0, 0, 0]) for x in xs], chk))
     import torch.distributed as dist
     dist.destroy_process_group()
 
@@ -41,7 +42,10 @@ def test_two_rank_sharding_and_reduction():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, f0, t0, n0, g0), (r1, f1, t1, n1, g1) = res
+    (r0, f0, t0, n0, g0, c0), (r1, f1, t1, n1, g1, c1) = res
+    for c in (c0, c1):                                         # the "result gather" of configs[3], checked by digest
+        assert c["ranks_seen"] == 2 and c["world"] == 2 and c["rank_order_ok"] and c["distinct_rank_digests"] == 2
+        assert c["bytes_gathered"] == 2 * (4 * 4 * 3 + 4 * 4 * 8) * 4 and c["backend"] == "gloo"
     assert f0 == [10, 12, 14, 16] and f1 == [11, 13, 15]       # f mod 2 == rank, disjoint, complete
     assert t0 == t1 == 2.0                                     # max over ranks
     assert n0 == n1 == 7                                       # frames add up
@@ -52,3 +56,4 @@ def test_single_process_passthrough():
     sh = pkg("sharding")
     assert sh.frames_of_rank(0, 5, 0, 1) == [0, 1, 2, 3, 4]
     assert sh.reduce_timing(0.5, 8) == (0.5, 8)
+    assert sh.gather_check(torch.zeros(1, 2, 3), torch.zeros(1, 2, 4))["ranks_seen"] == 1
