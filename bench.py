@@ -41,7 +41,7 @@ MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 / fp16 MFMA
 VALU_F32_PEAK_TF = 157.3
 MAX_CLOCK_MHZ = 2400.0      # MI355X_MICROARCH.md "Max clock"; cycles_per_pick is quoted at this clock (DVFS runs lower)
 FPS_FLOP_PER_PAIR = 11      # 3 sub + 3 mul/fma + min + compare/select chain, SURVEY.md 8d (3c + 2 with c = 3)
-TRAFFIC_PROFILES = [os.path.join("profiles", "r03_traffic.json"), os.path.join("profiles", "r02_traffic.json")]
+TRAFFIC_PROFILES = [os.path.join("profiles", "r04_traffic.json"), os.path.join("profiles", "r03_traffic.json")]
 
 
 def pkg(name):
@@ -921,7 +921,7 @@ def main():
     assert args.gpus >= 1
     defaults = {"configs1": dict(steps=512, warmup=64, batch=8, points=16384, pool=256, verify=64, executor="staged"),
                 "configs2": dict(steps=4, warmup=1, batch=32, points=16384, streams=1, pool=32, verify=0, coalesce=1, executor="slots"),
-                "configs4": dict(steps=16, warmup=4, batch=16, points=65536, streams=4, pool=96, verify=8, coalesce=1, executor="staged"),
+                "configs4": dict(steps=16, warmup=4, batch=16, points=65536, streams=4, pool=96, verify=8, coalesce=2, executor="staged"),
                 "group": dict(steps=20, warmup=5, batch=8, points=16384, streams=1, pool=8, verify=0, coalesce=1, executor="slots")}[args.workload]
     for k, v in defaults.items():
         if getattr(args, k) is None:
