@@ -33,6 +33,7 @@ SIGNATURES = {
     "sa_fps_with_distance_ex2": [_c_int] * 3 + [_vp, _vp, _vp, _c_int, _c_int, _vp, _c_long, _vp, _c_long, _vp],
     "sa_calc_square_dist_self_ws": [_c_int] * 4 + [_vp, _c_int, _vp, _c_int, _vp, _vp, _vp],
     "sa_fps_bucket_ex": [_c_int] * 3 + [_vp, _vp, _c_int, _c_int, _vp],
+    "sa_ffps_fly_ex": [_c_int] * 4 + [_vp, _c_long, _vp, _c_long, _vp, _vp, _c_int, _c_int, _vp, _c_long, _vp],
     "sa_fps_bucket_stats": [_c_int] * 3 + [_vp, _vp, _vp, _vp],
     "sa_fps_generic": [_c_int] * 4 + [_vp, _vp, _vp, _c_int, _vp],
     "sa_calc_square_dist_split": [_c_int] * 5 + [_vp, _vp, _vp, _vp, _vp, _vp],
@@ -108,6 +109,8 @@ def lib():
         h.sa_group_mlp_gemm_ws_bytes.restype = ctypes.c_size_t
         h.sa_calc_square_dist_ws_bytes.argtypes = [_c_int] * 5
         h.sa_calc_square_dist_ws_bytes.restype = ctypes.c_size_t
+        h.sa_ffps_fly_ws_bytes.argtypes = [_c_int] * 2
+        h.sa_ffps_fly_ws_bytes.restype = ctypes.c_size_t
         h.sa_host_crc32c.argtypes = [_vp, ctypes.c_size_t, ctypes.c_uint32]          # host helper: returns the CRC
         h.sa_host_crc32c.restype = ctypes.c_uint32
         _LIB = h

@@ -50,6 +50,11 @@ MLP_PLAN_FLAGS = 0  # sa_group_mlp_max flag bit 0 (all nsample rows instead of t
 GRID_BALL_QUERY_MIN_N = 2048
 MLP_GEMM_CHAIN = False  # True: eligible fp16 scales (layer4) run as three large-tile GEMM launches (flags bit 4); measured slower
 MAX_TRANSLATE_RANGE = (-3.0, -2.0, -3.0)
+# F-FPS without the distance matrix (csrc/ffps_fly.hip) where the shape allows it (64 feature channels, 1024 / 2048 /
+# 4096 points: layer 2 of 3dssd.yaml).  Several workgroups share a frame, so every call of a process must be on one
+# stream at a time: the staged executor (pipeline.py) turns it on for its own network and gives the stage a stream;
+# default off for direct callers.
+FFPS_FLY = False
 
 
 _UNSUPPORTED = -3
@@ -222,11 +227,12 @@ def _dfps_into(npoint, xyz, start, end, out, col, ctr):
 
 
 def sample_layer(xyz, points, fps_sample_range_list, fps_method_list, npoint_list, former_fps_idx, vote_ctr, radius_list,
-                 side_mode=None):
+                 side_mode=None, ffps_fly=None):
     """The sampling half of pointnet_sa_module_msg (layers_util.py:84-119): range slicing, D-FPS / F-FPS / FS / identity
     per range, index offsets, the centres.  Returns (fps_idx [B,m] int32, new_xyz [B,m,3], sliced_points or None).
     side_mode: DFPS_SIDE_STREAM for this call (None: the module default)."""
     side_mode = DFPS_SIDE_STREAM if side_mode is None else side_mode
+    ffps_fly = FFPS_FLY if ffps_fly is None else ffps_fly
     bs, n_all, _ = xyz.shape
     dev = xyz.device
 
@@ -298,10 +304,24 @@ def sample_layer(xyz, points, fps_sample_range_list, fps_method_list, npoint_lis
                   if k in ("FS", "D-FPS")]
         if len(fparts) == 1 and len(dparts) == 1 and xyz.shape[2] == 3:
             (fs, fe, fm, fc), (ds, de, dm, dc) = fparts[0], dparts[0]
-            dist = _ffps_into(fm, xyz, points, fs, fe, fps_idx, fc, new_xyz, matrix_only=True)
             lib = N.lib()
             cptr = (lambda col_: new_xyz.data_ptr() + 12 * col_) if new_xyz is not None else (lambda col_: None)
             cstr = 3 * new_xyz.shape[1] if new_xyz is not None else 0
+            if ffps_fly and points.shape[2] == 64 and (fe - fs) in (1024, 2048, 4096):
+                # the matrix is never built: every row a pick needs is computed on the fly (same picks, bit for bit)
+                ws = torch.empty((int(lib.sa_ffps_fly_ws_bytes(bs, fe - fs)) + 7) // 8, dtype=torch.int64, device=dev)
+                st = lib.sa_ffps_fly_ex(bs, fe - fs, 64, fm, xyz.data_ptr() + 12 * fs, 3 * n_all,
+                                        points.data_ptr() + 4 * 64 * fs, 64 * n_all, ws.data_ptr(),
+                                        fps_idx.data_ptr() + 4 * fc, fps_idx.shape[1], fs, cptr(fc), cstr, N.current_stream())
+                if st != _UNSUPPORTED:
+                    N.check(st, "ffps_fly")
+                    f_handled = dual_done = True
+                    ok_d = _dfps_into(dm, xyz, ds, de, fps_idx, dc, new_xyz)
+                    centres_ok = centres_ok and new_xyz is not None and ok_d
+                    work = []
+        if not dual_done and len(fparts) == 1 and len(dparts) == 1 and xyz.shape[2] == 3:
+            (fs, fe, fm, fc), (ds, de, dm, dc) = fparts[0], dparts[0]
+            dist = _ffps_into(fm, xyz, points, fs, fe, fps_idx, fc, new_xyz, matrix_only=True)
 
             def dual():
                 return lib.sa_fps_dual_ex(bs, fe - fs, fm, dist.data_ptr(), fps_idx.data_ptr() + 4 * fc, fps_idx.shape[1], fs,
@@ -384,7 +404,7 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
                            fps_sample_range_list, fps_method_list, npoint_list, former_fps_idx,
                            use_attention, scope, dilated_group, vote_ctr=None, aggregation_channel=None,
                            debugging=False, epsilon=1e-5, variables=None, aggregation_sa_feature=None, presampled=None,
-                           dfps_side_stream=None):
+                           dfps_side_stream=None, ffps_fly=None):
     """layers_util.py:59-189.  xyz (B,n,3), points (B,n,C) -> new_xyz (B,m,3), new_points (B,m,C'),
     fps_idx (B,m) int32.  aggregation_sa_feature: cfg.MODEL.NETWORK.AGGREGATION_SA_FEATURE (None: the module default);
     presampled = (fps_idx, new_xyz, sliced_points) of an earlier `sample_layer` call with the same arguments (the staged
@@ -401,7 +421,7 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
         fps_idx, new_xyz, sliced_points = presampled
     else:
         fps_idx, new_xyz, sliced_points = sample_layer(xyz, points, fps_sample_range_list, fps_method_list, npoint_list,
-                                                       former_fps_idx, vote_ctr, radius_list, dfps_side_stream)
+                                                       former_fps_idx, vote_ctr, radius_list, dfps_side_stream, ffps_fly)
     m = new_xyz.shape[1]
     lib = N.lib()
     stream = N.current_stream()

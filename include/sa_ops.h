@@ -100,6 +100,16 @@ int sa_fps_dual_ex(int b, int nf, int mf, const float *dist, int *out_f, int out
                    const float *xyz_f, long xyz_bstride_f, float *ctr_f, long ctr_bstride_f, int nd, int md,
                    const float *inp, long in_bstride, int *out_d, int out_stride_d, int idx_off_d, float *ctr_d,
                    long ctr_bstride_d, sa_stream_t stream);
+/* F-FPS without the distance matrix (csrc/ffps_fly.hip): the composition farthest_point_sample_with_distance(m,
+ * calc_square_dist(concat(xyz, feat))) of layers_util.py:94-96,102-104 (model_util.py:144-160, tf_sampling_g.cu:180-230)
+ * with every needed row of the matrix computed on the fly -- same picks, bit for bit.  xyz [b,.,3] / feat [b,.,c1] point
+ * at the start of the sampled range (frames xyz_bstride / feat_bstride floats apart, 0 = dense); workspace = caller-owned
+ * device memory of sa_ffps_fly_ws_bytes(b, n) bytes; out / idx_off / ctr as in sa_fps_with_distance_ex2.  n / 1024
+ * workgroups share a frame: all calls of a process must be issued on ONE stream at a time (see the file header).
+ * SA_ERR_UNSUPPORTED unless c1 == 64 and n is 1024, 2048 or 4096 (the caller then builds the matrix). */
+unsigned long sa_ffps_fly_ws_bytes(int b, int n);
+int sa_ffps_fly_ex(int b, int n, int c1, int m, const float *xyz, long xyz_bstride, const float *feat, long feat_bstride,
+                   void *workspace, int *out, int out_stride, int idx_off, float *ctr, long ctr_bstride, sa_stream_t stream);
 /* Up to four strided block copies in one launch (the tf.slice calls of single_stage_detector.py:117-118 and
  * layers_util.py:85-86): jobs = host array of njobs records of 9 longs {src, dst, frames, rows, cols,
  * src_frame_stride, src_row_stride, dst_frame_stride, dst_row_stride}, pointers as integers, strides in floats;

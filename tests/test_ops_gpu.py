@@ -268,6 +268,76 @@ def test_fps_with_distance_negative_rows(gpu, oracle):
     assert np.array_equal(got, oracle.farthest_point_sample_with_distance(100, d))
 
 
+# ----------------------------------------------------------------------------------- F-FPS without the matrix
+def _run_ffps_fly(gpu, xyz, feat, m, start=0, end=None):
+    N = pkg("utils._native")
+    b, n_all, _ = xyz.shape
+    end = n_all if end is None else end
+    n = end - start
+    tx, tf = _t(xyz, gpu), _t(feat, gpu)
+    out = torch.full((b, m + 3), -7, dtype=torch.int32, device=gpu)
+    ctr = torch.zeros((b, m + 3, 3), dtype=torch.float32, device=gpu)
+    ws = torch.empty((int(N.lib().sa_ffps_fly_ws_bytes(b, n)) + 7) // 8, dtype=torch.int64, device=gpu)
+    st = N.lib().sa_ffps_fly_ex(b, n, feat.shape[2], m, tx.data_ptr() + 12 * start, 3 * n_all, tf.data_ptr() + 4 * feat.shape[2] * start,
+                                feat.shape[2] * n_all, ws.data_ptr(), out.data_ptr() + 4 * 2, m + 3, start, ctr.data_ptr() + 12 * 2,
+                                3 * (m + 3), N.current_stream())
+    return st, out.cpu().numpy(), ctr.cpu().numpy()
+
+
+@pytest.mark.parametrize("b,n,m,dup", [(3, 4096, 512, 0), (2, 4096, 300, 600), (2, 2048, 256, 100), (3, 1024, 128, 0),
+                                       (70, 4096, 64, 0)])          # 70 frames x 4 workgroups: two launches inside the call
+def test_ffps_fly_equals_the_matrix_sampler(gpu, oracle, b, n, m, dup):
+    # csrc/ffps_fly.hip: farthest_point_sample_with_distance(m, calc_square_dist(concat(xyz, feat))) with every row
+    # computed on the fly -- the SAME picks as the oracle's matrix + sampler, ties (duplicated rows) included
+    rng = np.random.default_rng(b * 7 + n + m)
+    xyz = _cloud(rng, b, n, scale=6.0)
+    feat = rng.normal(0, 0.7, (b, n, 64)).astype(np.float32)
+    if dup:
+        src = rng.integers(0, n - dup, dup)
+        xyz[:, n - dup:] = xyz[:, src]
+        feat[:, n - dup:] = feat[:, src]
+    st, out, ctr = _run_ffps_fly(gpu, xyz, feat, m)
+    assert st == 0
+    cat = np.concatenate([xyz, feat], -1)
+    nref = min(b, 6)                                               # the oracle's matrix is n x n per frame
+    ref = oracle.farthest_point_sample_with_distance(m, oracle.calc_square_dist(cat[:nref], cat[:nref]))
+    assert np.array_equal(out[:nref, 2:2 + m], ref)
+    assert (out[:, :2] == -7).all() and (out[:, 2 + m:] == -7).all()      # nothing outside its columns
+    for f in range(nref):
+        assert np.array_equal(ctr[f, 2:2 + m], xyz[f][ref[f]])
+    if b > nref:                                                   # the frames of the second launch: against the HIP matrix path
+        S, M = pkg("utils.tf_ops.sampling.tf_sampling"), pkg("utils.model_util")
+        tc = _t(cat[nref:], gpu)
+        ref2 = S.farthest_point_sample_with_distance(m, M.calc_square_dist(tc, tc, norm=False)).cpu().numpy()
+        assert np.array_equal(out[nref:, 2:2 + m], ref2)
+
+
+def test_ffps_fly_on_a_range_and_unsupported_shapes(gpu, oracle):
+    rng = np.random.default_rng(5)
+    xyz = _cloud(rng, 2, 3000, scale=4.0)
+    feat = rng.normal(0, 1, (2, 3000, 64)).astype(np.float32)
+    st, out, ctr = _run_ffps_fly(gpu, xyz, feat, 100, start=500, end=2548)          # rows 500 .. 2547 of every frame, in place
+    assert st == 0
+    cat = np.concatenate([xyz, feat], -1)[:, 500:2548]
+    ref = oracle.farthest_point_sample_with_distance(100, oracle.calc_square_dist(cat, cat)) + 500
+    assert np.array_equal(out[:, 2:102], ref)
+    assert np.array_equal(ctr[0, 2:102], xyz[0][ref[0]])
+    assert _run_ffps_fly(gpu, xyz, feat, 10, start=0, end=3000)[0] == -3                                  # n not 1024 / 2048 / 4096
+    assert _run_ffps_fly(gpu, xyz[:, :1024], rng.normal(0, 1, (2, 1024, 32)).astype(np.float32), 10)[0] == -3   # c1 != 64
+
+
+def test_sample_layer_with_and_without_the_matrix_gives_the_same_layer(gpu):
+    # the 'FS' layer of 3dssd.yaml row 2 through sample_layer both ways: fps_idx [F-FPS | D-FPS] and the centres
+    lu = pkg("utils.layers_util")
+    rng = np.random.default_rng(9)
+    xyz = _t(_cloud(rng, 5, 4096, scale=20.0), gpu)
+    feat = _t(rng.normal(0, 0.5, (5, 4096, 64)).astype(np.float32), gpu)
+    a = lu.sample_layer(xyz, feat, [-1], ["FS"], [512], None, None, [0.4], side_mode=5, ffps_fly=False)
+    b = lu.sample_layer(xyz, feat, [-1], ["FS"], [512], None, None, [0.4], side_mode=5, ffps_fly=True)
+    torch.cuda.synchronize()
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[0].shape == (5, 1024)
+
+
 # ----------------------------------------------------------------------------------- gathers
 @pytest.mark.parametrize("c", [1, 3, 4, 64, 67, 256])
 def test_gather_and_group_point(gpu, oracle, c):

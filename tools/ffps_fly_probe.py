@@ -34,5 +34,14 @@ for frames in (8, 32, 64):
     # the matrix path as the backbone issues it: 'FS' layer, F-FPS 512 + D-FPS 512 of the same range in one dual launch
     t_mat = timed(lambda: lu.sample_layer(xyz, feat, [-1], ["FS"], [m], None, None, [0.4], side_mode=5))
     t_d = timed(lambda: S.farthest_point_sample(m, xyz))
+    # csrc/ffps_fly.hip: the same idea with the matrix arithmetic (the layer's own picks), two points per thread and one
+    # packed FMA per channel, the squared norm of the candidate travelling with the exchange; + the D-FPS half behind it
+    a = lu.sample_layer(xyz, feat, [-1], ["FS"], [m], None, None, [0.4], side_mode=5, ffps_fly=False)
+    bfly = lu.sample_layer(xyz, feat, [-1], ["FS"], [m], None, None, [0.4], side_mode=5, ffps_fly=True)
+    torch.cuda.synchronize()
+    same = bool(torch.equal(a[0], bfly[0]) and torch.equal(a[1], bfly[1]))
+    t_new = timed(lambda: lu.sample_layer(xyz, feat, [-1], ["FS"], [m], None, None, [0.4], side_mode=5, ffps_fly=True))
+    print("frames %3d: ffps_fly.hip F-FPS + D-FPS half %.3f ms -> F part %.3f ms = %.2f us per pick, %.1f CU-ms (picks equal to the matrix "
+          "path: %s)" % (frames, t_new, t_new - t_d, (t_new - t_d) * 1e3 / (m - 1), (t_new - t_d) * 4 * frames, same), flush=True)
     print("frames %3d: on-the-fly multi-workgroup F-FPS %.3f ms (%d CUs, %.2f us per pick, %.1f CU-ms) | matrix + dual sampler %.3f ms | "
           "D-FPS half alone %.3f ms" % (frames, t_fly, 4 * frames, t_fly * 1e3 / (m - 1), t_fly * 4 * frames, t_mat, t_d), flush=True)
