@@ -1,8 +1,9 @@
-"""The bench lines committed under profiles/ (outputs of `python bench.py` on the GPU box, round 3) carry every field
+"""The bench lines committed under profiles/ (outputs of `python bench.py` on the GPU box, round 4) carry every field
 of the driver's contract, the round-3 additions (distinct frames, verification against eager, recorded environment,
-latency-bound roofline for FPS, executed-flop MFMA fraction, batches coalesced per replay), and their algorithmic work
-model reproduces SURVEY.md 8d: 30.93 GFLOP of MLP per frame.  Stages / rooflines describe the calls as the pipeline
-issues them: one pass over config.frames_per_launch frames."""
+latency-bound roofline for FPS, executed-flop MFMA fraction, batches per package), the round-4 ones (the executor and
+what decides a short run inside `config`, where the driver's record keeps them: queues, priming, package timeline), and
+their algorithmic work model reproduces SURVEY.md 8d: 30.93 GFLOP of MLP per frame.  Stages / rooflines describe the
+calls as the pipeline issues them: one pass over config.frames_per_launch frames."""
 import json
 import os
 
@@ -13,12 +14,13 @@ from conftest import ROOT
 MLP_CALLS = ("sa_group_mlp_max", "sa_group_mlp_max_layer")
 
 
-def _line(name="r03_bench_default.json"):
+def _line(name="r04_bench_default.json"):
     with open(os.path.join(ROOT, "profiles", name)) as f:
         return json.loads(f.read().strip().splitlines()[-1])
 
 
-@pytest.mark.parametrize("name", ["r03_bench_default.json", "r03_bench_20steps.json", "r03_bench_dup10.json", "r03_bench_dense.json"])
+@pytest.mark.parametrize("name", ["r04_bench_default.json", "r04_bench_20steps.json", "r04_bench_dup10.json", "r04_bench_dense.json",
+                                  "r04_bench_rings64.json", "r04_cold_2.json", "r04_cold_3.json"])
 def test_bench_line_has_the_contract_fields(name):
     d = _line(name)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -26,7 +28,20 @@ def test_bench_line_has_the_contract_fields(name):
         assert k in d, k
     assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"] and "configs[1]" in d["config"]["workload"]
-    assert "SAPipeline" in d["config"]["executor"] and d["config"]["pool_frames_per_gpu"] >= 128
+    c = d["config"]
+    assert c["executor"] == "staged" and "SAPipeline" in c["executor_note"] and c["pool_frames_per_gpu"] >= 128
+    # the staged executor: three streams on ROCm's default four hardware queues, linear graphs, nothing set in the environment
+    assert c["streams_used"] == 3 and c["hw_queues"] == 4 and c["linear_graphs"] is True and c["hip_graphs"] is True
+    assert "GPU_MAX_HW_QUEUES" not in d["env_knobs"]
+    # what decides a short run travels inside `config` (the driver's record keeps `config` and `roofline` verbatim)
+    for k in ("timed_window_ms", "one_package_alone_ms", "ramp_dominated", "host_issue_ms_per_step", "steps_in_flight_mean",
+              "priming", "sclk_mhz", "timed_packages_ms", "package_sizes"):
+        assert k in c, k
+    assert c["priming"]["wall_ms"] >= 150 and c["priming"]["packages"] >= 2 * c["slots"]     # independent of --warmup
+    rows = c["timed_packages_ms"]["rows"]
+    assert rows and sum(r[1] for r in rows) >= min(d["steps"], sum(r[1] for r in rows))
+    for _slot, _fill, reached, a_done, done in rows:
+        assert 0 <= reached <= a_done <= done <= c["timed_window_ms"] + 0.5
     assert d["config"]["frames_per_launch"] == d["config"]["frames_per_step_per_gpu"] * d["config"]["batches_per_replay"]
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
@@ -43,11 +58,22 @@ def test_bench_line_has_the_contract_fields(name):
     assert not [k for k in d["env_knobs"] if k.startswith("SA_")]
 
 
-def test_default_line_reports_the_uncoalesced_executor_beside_the_headline():
-    d = _line()
-    u = d["uncoalesced"]
-    assert u["unit"] == d["unit"] and u["steps"] >= 100 and 0 < u["value"] < d["value"]     # coalescing is what it says
-    assert abs(u["value"] - d["config"]["frames_per_step_per_gpu"] / (u["ms_per_step"] * 1e-3)) / u["value"] < 1e-3
+def test_default_line_reports_the_other_executor_beside_the_headline():
+    for name in ("r04_bench_default.json", "r04_bench_20steps.json", "r04_cold_2.json"):
+        d = _line(name)
+        u = d["config"]["other_executor"]
+        assert u["executor"]["executor"] == "slots" and u["hw_queues"] == 16 and u["unit"] == d["unit"] and u["steps"] == d["steps"]
+        assert abs(u["value"] - d["config"]["frames_per_step_per_gpu"] / (u["ms_per_step"] * 1e-3)) / u["value"] < 1e-3
+        # the 3-stream executor is at least the 16-slot one, in the short run and in the long one
+        assert d["value"] >= 0.98 * u["value"]
+
+
+def test_cold_first_command_runs_agree_with_the_warm_one():
+    # `python bench.py --gpus 1 --steps 20 --warmup 5` as the first and only command of a fresh lease
+    warm = _line("r04_bench_20steps.json")["value"]
+    for name in ("r04_cold_2.json", "r04_cold_3.json"):
+        d = _line(name)
+        assert d["steps"] == 20 and d["warmup"] == 5 and abs(d["value"] - warm) / warm < 0.15
 
 
 def test_default_line_cpu_baseline_and_ramp_flag():
@@ -57,7 +83,7 @@ def test_default_line_cpu_baseline_and_ramp_flag():
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["unit"] == d["unit"]
     assert d["ramp_dominated"] is False and d["steps"] >= 100
-    assert _line("r03_bench_20steps.json")["ramp_dominated"] is True      # the driver's 20-step run says so itself
+    assert _line("r04_bench_20steps.json")["ramp_dominated"] is True      # the driver's 20-step run says so itself
 
 
 def test_fps_roofline_is_latency_bound_with_evaluated_pairs():
@@ -89,11 +115,14 @@ def test_algorithmic_mlp_work_matches_survey_8d():
     assert rows["frames"] == frames
     # the north star's ">= 30 % MFMA utilisation on the grouped MLP": the hardware counter over the MLP kernels of the
     # committed PMC pass (same launch shape), not the flop model
-    assert g["pmc"]["mfma_util"] >= 0.30 and "r03_traffic.json" in g["pmc"]["source"]
+    assert g["pmc"]["mfma_util"] >= 0.30 and "_traffic.json" in g["pmc"]["source"]
 
 
 def test_data_variants_move_the_data_dependent_counters():
-    base, dense, dup = _line(), _line("r03_bench_dense.json"), _line("r03_bench_dup10.json")
+    base, dense, dup = _line(), _line("r04_bench_dense.json"), _line("r04_bench_dup10.json")
+    rings = _line("r04_bench_rings64.json")
+    assert rings["config"]["data"] == "rings64" and dense["value"] < rings["value"] < base["value"]
+    assert base["mlp_rows_per_step"]["evaluated_frac"] < rings["mlp_rows_per_step"]["evaluated_frac"] < dense["mlp_rows_per_step"]["evaluated_frac"]
     assert dense["config"]["data"] == "dense" and dup["config"]["data"] == "dup10"
     assert dense["mlp_rows_per_step"]["evaluated_frac"] > 0.95 > 0.5 > base["mlp_rows_per_step"]["evaluated_frac"]
     assert dense["value"] < base["value"]               # the uniform box is the slow case, and the line shows it
