@@ -497,12 +497,13 @@ def _sha1(t):
     return hashlib.sha1(t.detach().cpu().numpy().tobytes()).hexdigest()
 
 
-def verify_pipeline(pipe, batches, nverify):
+def verify_pipeline(pipe, batches, nverify, submit_from=None):
     """`nverify` DISTINCT batches through the pipeline with all slots in flight, each output compared bit for bit with
     the eager single-stream result of the same batch (a replay that read another slot's scratch or input would differ)."""
     nverify = min(nverify, len(batches))
     if nverify <= 0:
         return None
+    submit_from = batches if submit_from is None else submit_from      # (the pinned host copies with --host-input)
     eager = []
     for i in range(nverify):
         xl, fl, _ = pipe.forward_eager(batches[i])
@@ -511,7 +512,7 @@ def verify_pipeline(pipe, batches, nverify):
     equal, first = True, None
     per_round = pipe.nslots * pipe.coalesce                     # every slot full: that many batches in flight
     for r0 in range(0, nverify, per_round):
-        tickets = [(i, pipe.submit(batches[i], sync_source=False)) for i in range(r0, min(r0 + per_round, nverify))]
+        tickets = [(i, pipe.submit(submit_from[i], sync_source=False)) for i in range(r0, min(r0 + per_round, nverify))]
         pipe.flush()
         for i, t in tickets:
             x, f = t.result()
@@ -544,6 +545,12 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
     frames = sh.frames_of_rank(0, nb * args.batch * world, rank, world)
     batches = [torch.from_numpy(np.stack([syn.frame_of(args.data, f, points) for f in frames[i * args.batch:(i + 1) * args.batch]])).to(dev)
                for i in range(nb)]
+    if args.host_input:
+        # the PCIe-inclusive variant (never the headline): the pool lives in pinned HOST memory, submit() copies a batch
+        # host -> device asynchronously on the executor's stream in front of the package
+        sub = [b.cpu().pin_memory() for b in batches]
+    else:
+        sub = batches
     torch.cuda.synchronize()
     cursor = [0]
 
@@ -552,7 +559,7 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
         # filled one by flush()
         tickets = [None] * k
         for i in range(k):
-            tickets[i] = pipe.submit(batches[cursor[0] % nb], sync_source=False)
+            tickets[i] = pipe.submit(sub[cursor[0] % nb], sync_source=False)
             cursor[0] += 1
         pipe.flush()
         return tickets
@@ -597,9 +604,9 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     for i in range(3):
-        pipe.run_alone(batches[i % nb])
+        pipe.run_alone(sub[i % nb])
     latency_ms = (time.perf_counter() - t1) / 3 * 1e3          # one replay (batch x coalesce frames) alone on the device
-    verify = verify_pipeline(pipe, batches, args.verify)
+    verify = verify_pipeline(pipe, batches, args.verify, sub)
     if verify is not None and not verify["all_equal_eager"]:
         sys.exit("bench.py: a pipeline output differs from the eager result of the same batch -- refusing to report")
     other = None
@@ -646,10 +653,13 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
                  "wide (layer3, layer4), split bf16 hi/lo (three passes) on the narrow scales and the aggregation layers; "
                  "fp32 for FPS / ball query / distance matrix",
         "data": "synthetic KITTI-shape frames (seeded, --data %s), %d DISTINCT frames per GPU cycled through the steps, "
-                "random-init weights" % (args.data, nb * args.batch),
+                "random-init weights%s" % (args.data, nb * args.batch,
+                                           "; INPUTS IN PINNED HOST MEMORY (--host-input): every step includes its PCIe copy"
+                                           if args.host_input else ""),
         "config": {"workload": "%s: full 3DSSD SA backbone (3dssd.yaml rows 1-6), %d-pt frames, batch=%d per GPU"
                                % (tag, points, args.batch),
                    "frames_per_step_per_gpu": args.batch, "data": args.data, "pool_frames_per_gpu": nb * args.batch,
+                   "inputs": "pinned host memory, copied per step (PCIe-inclusive)" if args.host_input else "resident in HBM",
                    "executor": args.executor, "slots": pipe.nslots, "streams_used": pipe.streams_used(),
                    "hw_queues": P.hw_queues(), "hip_graphs": use_graphs,
                    "batches_per_replay": C, "frames_per_launch": fpl, "package_sizes": pipe.sizes,
@@ -915,6 +925,7 @@ def main():
     ap.add_argument("--allow-knobs", action="store_true", help="run although SA_* / SA3D_* environment variables are set (recorded in the line)")
     ap.add_argument("--allow-shared-device", action="store_true",
                     help="--gpus N with fewer than N GPUs visible: ranks share devices (functional check of the multi-rank path)")
+    ap.add_argument("--host-input", action="store_true", help="frame pool in pinned host memory: every step pays its host->device copy (PCIe-inclusive rate; not the headline)")
     ap.add_argument("--gather", type=int, default=None, help="after the timed region all-gather every rank's last batch of outputs and check rank order by sha1 (default: on when --gpus > 1)")
     ap.add_argument("--launch-check", action="store_true", help="exercise only the launch path (works without a GPU)")
     args = ap.parse_args()

@@ -22,6 +22,7 @@ P
 echo "== bench 20 steps (the driver's command)"; timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_20steps.json 2> $OUT/bench_20steps.err; show 20steps
 echo "== bench default"; timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; show default
 for i in 2 3; do timeout 300 python bench.py --no-cpu-baseline --no-other-executor --profile-iters 0 --verify 0 | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('default again', d['value'], d['ms_per_step'])"; done
+timeout 600 python bench.py --host-input --no-cpu-baseline --no-other-executor --profile-iters 0 > $OUT/bench_host_input.json 2> $OUT/bench_host_input.err; show host_input
 for v in dup10 dense rings64; do timeout 600 python bench.py --data $v --no-cpu-baseline --no-other-executor > $OUT/bench_$v.json 2> $OUT/bench_$v.err; show $v; done
 timeout 600 python bench.py --gpus 2 --allow-shared-device --steps 64 --warmup 16 --no-cpu-baseline --no-other-executor > $OUT/bench_2ranks_shared.json 2> $OUT/bench_2ranks_shared.err; show 2ranks_shared
 timeout 600 python bench.py --workload configs2 --no-cpu-baseline > $OUT/bench_configs2.json 2> $OUT/bench_configs2.err; show configs2
