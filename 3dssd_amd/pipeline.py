@@ -152,7 +152,7 @@ class SAPipeline:
     def __init__(self, arch, params, device="cuda:0", batch=8, points=16384, channels=4, streams=None,
                  graphs=True, max_translate_range=(-3.0, -2.0, -3.0), aggregation_sa_feature=True, net=None,
                  precision=None, check_overflow=True, coalesce=1, mode="staged", timeline=False, linear_graphs=None,
-                 main_streams=MAIN_STREAMS):
+                 main_streams=MAIN_STREAMS, sampler_streams=1):
         """arch / params as for SABackbone.  mode / coalesce: module docstring.  `streams`: the number of slots --
         packages in the ring for mode="staged" (default 4), slots = HIP streams for mode="slots" (default 16).
         graphs=False launches eagerly on the same streams (frames whose layer-1 sampler cannot be captured).
@@ -161,7 +161,8 @@ class SAPipeline:
         captured graph is one linear chain and its replay needs no internal branch stream -- the default for
         mode="staged" (with branches the three streams + two branch streams share ROCm's default 4 hardware queues and
         block one another: 10.8 k instead of 16.2 k frames/s, profiles/r04_sweep_queues.txt); mode="slots" defaults to
-        the branch form (15.7 k against 14.6 k on 16 queues).  main_streams: streams stage B alternates between."""
+        the branch form (15.7 k against 14.6 k on 16 queues).  main_streams / sampler_streams: streams the two stages
+        alternate between (2 / 1 by default: a second sampler stream was measured)."""
         self.device = torch.device(device)
         T.require(self.device.type == "cuda", "SAPipeline needs a GPU: the HIP path has no CPU fallback")
         T.require(mode in ("staged", "slots"), "SAPipeline mode must be 'staged' or 'slots'")
@@ -170,6 +171,8 @@ class SAPipeline:
             linear_graphs = mode == "staged"
         self.linear_graphs = bool(linear_graphs)
         self.n_main = max(1, int(main_streams))
+        # frames above 16384 points: their multi-workgroup sampler must stay on ONE stream (csrc/fps_coop.hip)
+        self.n_samp = 1 if int(points) > 16384 else max(1, int(sampler_streams))
         self.net = net if net is not None else SABackbone(arch, params, self.device, max_translate_range,
                                                            aggregation_sa_feature, precision,
                                                            dfps_side_stream=5 if linear_graphs else None)
@@ -204,14 +207,15 @@ class SAPipeline:
         dev = self.device
         shape = (self.batch * self.coalesce, self.points, self.channels)
         if self.mode == "staged":
-            self.sampler_stream = torch.cuda.Stream(device=dev)
+            self.sampler_streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_samp)]
+            self.sampler_stream = self.sampler_streams[0]
             self.main_streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_main)]
         self.slots = []
         for i in range(self.nslots):
             s = _Slot()
             s.pipe, s.index, s.graphs, s.lists = self, i, {}, {}
             if self.mode == "staged":
-                s.stream_a, s.stream_b = self.sampler_stream, self.main_streams[i % self.n_main]
+                s.stream_a, s.stream_b = self.sampler_streams[i % self.n_samp], self.main_streams[i % self.n_main]
             else:
                 s.stream_a = s.stream_b = torch.cuda.Stream(device=dev)
             s.inp = torch.zeros(shape, dtype=torch.float32, device=dev)

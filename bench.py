@@ -536,7 +536,7 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
     P = pkg("pipeline")
     pipe = P.SAPipeline(arch, params, dev, batch=args.batch, points=points, channels=4, streams=max(1, args.streams),
                         graphs=use_graphs, max_translate_range=cfgs.KITTI_MAX_TRANSLATE_RANGE,
-                        coalesce=max(1, args.coalesce), mode=args.executor, linear_graphs=args.linear_graphs, main_streams=args.main_streams)
+                        coalesce=max(1, args.coalesce), mode=args.executor, linear_graphs=args.linear_graphs, main_streams=args.main_streams, sampler_streams=args.sampler_streams)
     C = pipe.coalesce
     net = pipe.net
     # this rank's frame pool: global frame f -> rank f mod world (weak scaling: `batch` frames per GPU per step);
@@ -916,6 +916,7 @@ def main():
     ap.add_argument("--coalesce", type=int, default=None, help="batches per package (frames per replay = batch x coalesce)")
     ap.add_argument("--linear-graphs", type=int, default=None, help="1: the F-FPS || D-FPS launch on the capturing stream (captured graphs are linear chains; default for staged), 0: on a helper-stream branch (default for slots)")
     ap.add_argument("--main-streams", type=int, default=2, help="staged executor: streams stage B alternates between")
+    ap.add_argument("--sampler-streams", type=int, default=1, help="staged executor: streams stage A alternates between")
     ap.add_argument("--hw-queues", type=int, default=None, help="GPU_MAX_HW_QUEUES for this run (default: unset for staged, = --streams for slots)")
     ap.add_argument("--verify", type=int, default=None, help="batches re-run through the pipeline and compared with eager (0: skip)")
     ap.add_argument("--profile-iters", type=int, default=3)
