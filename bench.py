@@ -459,7 +459,8 @@ def overlap_probe(pipe, run, k):
     busy = sum(max(0.0, min(e, t1) - max(s, t0)) * f for s, e, f in iv)
     spans = [e - s for s, e, _ in iv]
     done = [e for e in ends if t0 <= e <= t1]
-    return {"steps": k, "packages": len(iv), "package_span_ms_mean": round(sum(spans) / len(spans), 3),
+    return {"steps": k, "packages": len(iv), "window_ms": round(ends[-1] - iv[0][0], 3),
+            "package_span_ms_mean": round(sum(spans) / len(spans), 3),
             "package_span_ms_min": round(min(spans), 3), "package_span_ms_max": round(max(spans), 3),
             "steps_in_flight_mean": round(busy / (t1 - t0), 2),
             "ms_between_completions": round((t1 - t0) / max(len(done) - 1, 1), 4),
@@ -670,6 +671,11 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
                    "timed_window_ms": round(window_ms, 3), "one_package_alone_ms": round(latency_ms, 3),
                    "ramp_dominated": bool(window_ms < 20.0 * latency_ms),
                    "host_issue_ms_per_step": round(host_issue_ms, 3),
+                   # the same K steps again, untimed, right after the timed region (device-side window of their packages): a
+                   # timed region that was slow for a reason outside the kernels shows as a ratio well above 1
+                   "probe_window_ms": overlap["window_ms"] if overlap else None,
+                   "timed_over_probe": round(window_ms / overlap["window_ms"], 3) if overlap and overlap["window_ms"] > 0 and
+                                       overlap["steps"] == args.steps else None,
                    "steps_in_flight_mean": overlap["steps_in_flight_mean"] if overlap else None,
                    "ms_between_completions": overlap["ms_between_completions"] if overlap else None,
                    "priming": primed, "sclk_mhz": clocks,

@@ -458,6 +458,30 @@ def case_pooling(rng):
     return None
 
 
+def case_ffps_fly(rng):
+    # F-FPS without the matrix (csrc/ffps_fly.hip) against the HIP matrix path on the same rows (itself fuzzed against the
+    # oracle by case_sqdist / case_fps_dist): random range inside a larger tensor, lattice features (ties), duplicates
+    n = int(rng.choice([1024, 2048, 4096]))
+    b, pad = int(rng.integers(1, 5)), int(rng.integers(0, 300))
+    m = int(rng.integers(1, 200))
+    xyz = cloud(rng, b, n + pad, 3, dup=float(rng.choice([0, 0.2])))
+    feat = rng.normal(0, 1, (b, n + pad, 64)).astype(np.float32)
+    if rng.integers(0, 2):
+        feat = np.round(feat * 2) / 2
+        xyz = np.round(xyz * 2) / 2
+    start = int(rng.integers(0, pad + 1))
+    tx, tf = t(xyz), t(feat)
+    out = torch.full((b, m), -1, dtype=torch.int32, device=dev)
+    ws = torch.empty((int(N.lib().sa_ffps_fly_ws_bytes(b, n)) + 7) // 8, dtype=torch.int64, device=dev)
+    st = N.lib().sa_ffps_fly_ex(b, n, 64, m, tx.data_ptr() + 12 * start, 3 * (n + pad), tf.data_ptr() + 256 * start, 64 * (n + pad),
+                                ws.data_ptr(), out.data_ptr(), m, start, None, 0, N.current_stream())
+    if st != 0:
+        return "ffps_fly status %d" % st
+    cat = torch.cat([tx[:, start:start + n], tf[:, start:start + n]], 2).contiguous()
+    ref = S.farthest_point_sample_with_distance(m, M.calc_square_dist(cat, cat, norm=False)) + start
+    return eq("ffps_fly", out, ref.cpu().numpy(), (b, n, m, start))
+
+
 def case_prob_iou(rng):
     E = pkg("utils.tf_ops.evaluation.tf_evaluate")
     k = int(rng.integers(1, 200))
@@ -472,7 +496,7 @@ def case_prob_iou(rng):
 
 
 CASES = [case_fps, case_fps, case_fps_dist, case_fps_preidx, case_gather, case_ball, case_ball, case_sqdist, case_mlp, case_mlp,
-         case_mlp, case_interp, case_boxes, case_misc, case_pooling, case_prob_iou, case_vote_tail]
+         case_mlp, case_interp, case_boxes, case_misc, case_pooling, case_prob_iou, case_vote_tail, case_ffps_fly]
 
 
 def main():
