@@ -391,6 +391,8 @@ class SAPipeline:
             if tl:
                 marks.append(r.event)
                 self._timeline.append((s.index, r.fill, marks))
+                if len(self._timeline) > 4096:            # a caller that never collects: keep the newest
+                    del self._timeline[:2048]
         s.last_event = r.event
         r.launched = True
         if s is self.slots[self._next]:
