@@ -391,8 +391,13 @@ def launch_check(args, sh):
     frames = sh.frames_of_rank(0, args.batch * world, rank, world)
     sh.barrier()
     t_max, total = sh.reduce_timing(1.0 + rank, len(frames))
+    # the result gather of configs[3] on stand-in outputs of the real shapes, every rank's different (rank order is checked
+    # by digest): the same call the timed workloads make after their timed region
+    dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1)) if torch.cuda.is_available() else torch.device("cpu")
+    gathered = sh.gather_check(torch.full((args.batch, 256, 3), float(rank), device=dev),
+                               torch.full((args.batch, 256, 512), 0.5 + rank, device=dev))
     if rank == 0:
-        print(json.dumps({"launch_check": True, "n_gpus": world, "frames_total": total, "t_max": t_max}))
+        print(json.dumps({"launch_check": True, "n_gpus": world, "frames_total": total, "t_max": t_max, "gather": gathered}))
     sh.barrier()
 
 

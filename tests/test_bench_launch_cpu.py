@@ -22,6 +22,9 @@ def test_self_spawn_launches_the_requested_number_of_ranks():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["launch_check"] is True and line["n_gpus"] == 2
     assert line["frames_total"] == 16 and line["t_max"] == 2.0      # 8 frames per rank; max over ranks of 1 + rank
+    g = line["gather"]                                              # configs[3]'s result gather, [8,256,3] + [8,256,512] per rank
+    assert g["ranks_seen"] == 2 and g["rank_order_ok"] is True and g["distinct_rank_digests"] == 2
+    assert g["bytes_gathered"] == 2 * 8 * 256 * (3 + 512) * 4
 
 
 def test_more_gpus_than_visible_fails_loudly():
