@@ -155,7 +155,7 @@ class SAPipeline:
                  main_streams=MAIN_STREAMS, sampler_streams=1):
         """arch / params as for SABackbone.  mode / coalesce: module docstring.  `streams`: the number of slots --
         packages in the ring for mode="staged" (default 4), slots = HIP streams for mode="slots" (default 16).
-        graphs=False launches eagerly on the same streams (frames whose layer-1 sampler cannot be captured).
+        graphs=False launches eagerly on the same streams (same throughput with large packages, more host work).
         timeline=True records HIP timing events around every package (`timeline()`).  linear_graphs=True issues the
         F-FPS || D-FPS launch of the 'FS' layers on the capturing stream instead of a helper-stream branch, so that a
         captured graph is one linear chain and its replay needs no internal branch stream -- the default for

@@ -3,19 +3,23 @@
 
     python bench.py --gpus N --steps K --warmup W            (N > 1 without torchrun: spawns the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
-    python bench.py --data default|dup10|dense               (sensitivity of the data-dependent kernels)
-    python bench.py --workload configs2|configs4             (the other single-GPU configurations of BASELINE.json)
+    python bench.py --data default|dup10|dense|rings64       (sensitivity of the data-dependent kernels)
+    python bench.py --workload configs2|configs4|group       (the other single-GPU configurations of BASELINE.json)
+    python bench.py --executor staged|slots                  (3dssd_amd/pipeline.py: default staged)
 
 A "step" is one batch of 8 DIFFERENT frames per GPU through the backbone, device-resident in and out: step i takes
-frames 8i .. 8i+7 (mod --pool, default 160 distinct frames per GPU) from a resident pool.  The executor is the
-package's own (3dssd_amd/pipeline.py, SAPipeline): --streams slots, each a HIP stream with a captured hipGraph and its
-own static input / intermediate / output buffers; a step = one block copy of the batch into the slot's input buffer +
-one graph replay, both inside the timed region.  (The layer-1 D-FPS is a serial chain that keeps one CU per frame
-busy: throughput comes from batches in flight.)  The timed region is bracketed by barrier + synchronize on both sides
-and all K steps complete inside it.  After it, --verify batches go through the same pipeline again and every output is
-compared bit for bit with the eager single-stream result of the same batch.  Rank 0 prints ONE JSON line: `roofline`
-describes the kernel with the largest share of GPU time, `stages` every C-ABI call, `cpu_baseline` the CPU oracle timed
-on this host on a bounded sample of the same workload.
+frames 8i .. 8i+7 (mod --pool, default 256 distinct frames per GPU) from a resident pool.  The executor is the
+package's own (3dssd_amd/pipeline.py, SAPipeline): a step = one block copy of the batch into a static input buffer;
+16 consecutive batches form a package that runs as two captured hipGraphs on three HIP streams (layer-1 sampling stage
+on a sampler stream, the rest on one of two main streams) -- all inside the timed region.  (The layer-1 D-FPS is a
+serial chain that keeps one CU per frame busy: throughput comes from the sampling stage of one package running beside
+the chip-filling kernels of others.)  Before the warm-up steps the executor is primed (every slot replayed twice,
+>= 150 ms of work), independent of --warmup.  The timed region is bracketed by barrier + synchronize on both sides and
+all K steps complete inside it.  After it, --verify batches go through the same pipeline again and every output is
+compared bit for bit with the eager single-stream result of the same batch.  Rank 0 prints ONE JSON line: `config`
+carries the executor and what decides a short run (queues, priming, the device-side timeline of the timed packages),
+`roofline` describes the kernel with the largest share of GPU time, `stages` every C-ABI call, `cpu_baseline` the CPU
+oracle timed on this host on a bounded sample of the same workload.
 """
 import argparse
 import hashlib
