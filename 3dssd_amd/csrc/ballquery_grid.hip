@@ -206,13 +206,34 @@ __global__ __launch_bounds__(kQWaves * 64) void bq_grid_query_kernel(int n, int 
             rc[r] = in ? e - s : 0;
         }
         const int c01 = rc[0] + rc[1], T = c01 + rc[2];
-        for (int base = 0; base < T; base += 64) {
+        // The walk is software-pipelined (round 5): a step's chain is sorted[pos] -> point -> distance, two dependent
+        // global round trips that the LDS list updates and ballots of the loop body keep the compiler from overlapping.
+        // So the candidate INDEX of step s+2 and the POINT of step s+1 are requested before step s is evaluated: a
+        // frame whose balls hold hundreds of points (ring-structured sweeps, synthetic.py rings64: 4.5 steps per query
+        // on average, 100+ on dense frames) pays one round trip per step instead of two; a one-step query is unchanged.
+        auto cand_index = [&](int base) -> int {           // lane's candidate of the step at `base` (clamped past T)
             const int j = base + lane;
-            const bool valid = j < T;
-            const int jj = valid ? j : 0;
+            const int jj = j < T ? j : 0;
             const int pos = jj < rc[0] ? rs[0] + jj : (jj < c01 ? rs[1] + (jj - rc[0]) : rs[2] + (jj - c01));
-            const int k = sorted[pos];
-            const float dx = x2 - P[k * 3 + 0], dy = y2 - P[k * 3 + 1], dz = z2 - P[k * 3 + 2];
+            return sorted[pos];
+        };
+        int k0 = 0, k1 = 0;
+        float px = 0.0f, py = 0.0f, pz = 0.0f;
+        if (T > 0) {
+            k0 = cand_index(0);
+            k1 = cand_index(64);
+            px = P[k0 * 3 + 0]; py = P[k0 * 3 + 1]; pz = P[k0 * 3 + 2];
+        }
+        for (int base = 0; base < T; base += 64) {
+            const bool valid = base + lane < T;
+            const int k = k0;
+            const float cxp = px, cyp = py, czp = pz;
+            // requests for the next two steps (addresses stay inside the frame's arrays: cand_index clamps)
+            const int k2 = cand_index(base + 128);
+            px = P[k1 * 3 + 0]; py = P[k1 * 3 + 1]; pz = P[k1 * 3 + 2];
+            k0 = k1;
+            k1 = k2;
+            const float dx = x2 - cxp, dy = y2 - cyp, dz = z2 - czp;
             const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));   // as ballquery.hip
             if (__ballot(valid && d2 < B.thi_max) == 0ull) continue;
 #pragma unroll

@@ -36,6 +36,7 @@ after it -- a ticket raises for ITS package only.  Nothing here is a collective:
 one pipeline and its share of the frames (sharding.py).
 """
 import os
+import time
 import warnings
 
 import torch
@@ -187,6 +188,11 @@ class SAPipeline:
         self.graphs = bool(graphs)
         self.record_timeline = bool(timeline)
         self._timeline = []
+        # host-side diagnostics: `host_trace` = a list the issuing calls append (call site, perf_counter_ns) to, or None;
+        # `_ev_pool` = events created ahead of time (reserve_events) so that a measured region creates none
+        self.host_trace = None
+        self._ev_pool = []
+        self._idle_events = []
         self._next = 0
         self.submitted = 0
         self._flags = torch.zeros(_FLAG_RING, dtype=torch.int32).pin_memory()
@@ -287,6 +293,24 @@ class SAPipeline:
         def __exit__(self, *exc):
             self.v.overflow = self.saved
 
+    # ------------------------------------------------------------------------------------------------ diagnostics
+    def _stamp(self, site):
+        tr = self.host_trace
+        if tr is not None:
+            tr.append((site, time.perf_counter_ns()))
+
+    def reserve_events(self, n):
+        """Create `n` HIP events now (timing-capable: usable for either purpose), to be handed out by the next launches
+        instead of creating them on the way."""
+        with torch.cuda.device(self.device):
+            while len(self._ev_pool) < n:
+                self._ev_pool.append(torch.cuda.Event(enable_timing=True))
+
+    def _event(self, timing):
+        if self._ev_pool:
+            return self._ev_pool.pop()
+        return torch.cuda.Event(enable_timing=timing)
+
     # ------------------------------------------------------------------------------------------------ use
     def submit(self, batch, out=None, sync_source=True):
         """Enqueue one batch [B, points, channels] fp32 (device tensor; a pinned host tensor is copied
@@ -297,6 +321,7 @@ class SAPipeline:
         T.require(isinstance(batch, torch.Tensor) and tuple(batch.shape) == (self.batch, self.points, self.channels),
                   "SAPipeline.submit expects a [%d,%d,%d] tensor" % (self.batch, self.points, self.channels))
         T.require(batch.dtype == torch.float32, "SAPipeline.submit expects fp32 (got %s)" % batch.dtype)
+        self._stamp("submit:enter")
         s = self.slots[self._next]
         r = s.round
         if r is None or r.launched:          # a new round of this slot: earlier tickets of the slot are now stale
@@ -318,6 +343,7 @@ class SAPipeline:
                     N.copy_blocks([(batch, dst, self.batch, self.points, self.channels)])
                 else:
                     dst.copy_(batch, non_blocking=True)
+        self._stamp("submit:copy_blocks")
         if out is not None:
             for o in out:
                 if o.is_cuda:
@@ -338,6 +364,8 @@ class SAPipeline:
             return
         B = self.batch
         tl = self.record_timeline
+        stamp = self._stamp
+        stamp("launch:enter")
         size = r.size = min(z for z in self.sizes if z >= r.fill)
         view = s.inp[:size * B]
         with torch.cuda.device(self.device):
@@ -346,6 +374,7 @@ class SAPipeline:
             with torch.cuda.stream(a):
                 if tl:
                     marks.append(self._mark(a))
+                    stamp("launch:mark_reached")
                 if r.fill < size:
                     k = size - r.fill
                     s.inp[r.fill * B:size * B].view(k, B, self.points, self.channels).copy_(
@@ -356,19 +385,23 @@ class SAPipeline:
             if staged:
                 if s.last_event is not None:
                     a.wait_event(s.last_event)            # stage B of the slot's previous round still reads stage A's outputs
+                    stamp("launch:wait_prev_round")
                 with torch.cuda.stream(a):
                     if ga is not None:
                         ga.replay()
                     else:
                         gen = self.net.forward_staged(view)
                         next(gen)
-                    ev = torch.cuda.Event(enable_timing=tl)
+                    stamp("launch:stage_A")
+                    ev = self._event(tl)
                     ev.record(a)
                     if tl:
                         marks.append(ev)
                 b.wait_event(ev)
+                stamp("launch:event_A_to_B")
             with torch.cuda.stream(b):
                 s.overflow.zero_()
+                stamp("launch:zero_flag")
                 if gb is not None:
                     gb.replay()
                 else:
@@ -385,9 +418,12 @@ class SAPipeline:
                 for part, (ox, of) in r.outs:
                     N.copy_blocks([(xl[-1][part * B:(part + 1) * B], ox, B, xl[-1].shape[1], 3),
                                    (fl[-1][part * B:(part + 1) * B], of, B, fl[-1].shape[1], fl[-1].shape[2])])
+                stamp("launch:stage_B")
                 self._flags[r.flag:r.flag + 1].copy_(s.overflow, non_blocking=True)
-                r.event = torch.cuda.Event(enable_timing=tl)
+                stamp("launch:flag_copy")
+                r.event = self._event(tl)
                 r.event.record(b)
+                stamp("launch:event_done")
             if tl:
                 marks.append(r.event)
                 self._timeline.append((s.index, r.fill, marks))
@@ -398,17 +434,17 @@ class SAPipeline:
         if s is self.slots[self._next]:
             self._next = (self._next + 1) % self.nslots
 
-    @staticmethod
-    def _mark(stream):
-        ev = torch.cuda.Event(enable_timing=True)
+    def _mark(self, stream):
+        ev = self._event(True)
         ev.record(stream)
         return ev
 
     def timeline(self, base, clear=True):
         """[(slot, batches, [ms since `base` ...])] of the packages launched since the last call (timeline=True):
         reached-by-its-stream, (stage A complete,) package complete -- device-side times from HIP events.  `base` is a
-        timing event recorded before them; call after a synchronize."""
-        out = [(i, fill, [round(base.elapsed_time(e), 3) for e in marks]) for i, fill, marks in self._timeline]
+        timing event recorded before them; call after a synchronize.  base=None only discards what was recorded."""
+        out = [] if base is None else [(i, fill, [round(base.elapsed_time(e), 3) for e in marks])
+                                      for i, fill, marks in self._timeline]
         if clear:
             self._timeline = []
         return out
@@ -430,6 +466,24 @@ class SAPipeline:
         for s in self.slots:
             s.stream_a.synchronize()
             s.stream_b.synchronize()
+
+    def wait_idle(self):
+        """drain() without a spinning host thread: one blocking HIP event (hipEventBlockingSync) per executor stream,
+        recorded behind everything issued so far and waited for asleep.  A host that shares its cores -- or runs under a
+        CPU quota -- keeps them free while the GPU works."""
+        self.flush()
+        streams = []
+        for s in self.slots:
+            for st in (s.stream_a, s.stream_b):
+                if all(st is not t for t in streams):
+                    streams.append(st)
+        if len(self._idle_events) < len(streams):
+            with torch.cuda.device(self.device):
+                self._idle_events = [torch.cuda.Event(blocking=True) for _ in streams]
+        for st, ev in zip(streams, self._idle_events):
+            ev.record(st)
+        for ev in self._idle_events[:len(streams)]:
+            ev.synchronize()
 
     def streams_used(self):
         """HIP streams the executor issues on (the helper branch inside the captured graphs not counted)."""

@@ -27,6 +27,22 @@ def test_self_spawn_launches_the_requested_number_of_ranks():
     assert g["bytes_gathered"] == 2 * 8 * 256 * (3 + 512) * 4
 
 
+def test_eight_rank_launch_rendezvous_partition_and_gather():
+    # the 8-GPU node's launch path without the hardware -- `bench.py --gpus 8 --launch-check` spawns 8
+    # processes (gloo here, RCCL on the GPU box), they rendezvous on 127.0.0.1, every rank takes its f mod 8 share of the
+    # frames (configs[3]: batch 64 over 8 GPUs = 8 per rank), and the result gather sees all 8 ranks in rank order.
+    r = _run("--gpus", "8", "--launch-check", "--cpu-affinity", "auto")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["launch_check"] is True and line["n_gpus"] == 8
+    assert line["frames_total"] == 64 and line["t_max"] == 8.0      # max over ranks of 1 + rank
+    assert line["frames_per_rank"] == [8] * 8 and line["partition_ok"] is True
+    g = line["gather"]
+    assert g["ranks_seen"] == 8 and g["rank_order_ok"] is True and g["distinct_rank_digests"] == 8
+    assert g["bytes_gathered"] == 8 * 8 * 256 * (3 + 512) * 4
+    assert len(set(line["cores"])) == min(8, os.cpu_count() or 1)    # --cpu-affinity auto: ranks on different cores
+
+
 def test_more_gpus_than_visible_fails_loudly():
     import torch
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
