@@ -1166,52 +1166,70 @@ __global__ void vote_translate_kernel(long total, const float *__restrict__ xyz,
     }
 }
 
-// ---- row plan (mlp_plan.h): ball -> ceil(clamp(cnt, 1, ns) / 8) granules of 8 rows -------------------------------
-// Packing is "next fit" into 32-row tiles (4 granules): a ball of <= 4 granules never straddles a tile boundary (the
-// rest of the tile is padded with invalid entries), so its maximum is complete inside one wave and is written with a
-// plain store; only balls of more than 32 distinct rows are split (atomic max on a row zeroed here).  Next fit is a
-// sequential rule; it is evaluated in parallel as a scan over FUNCTIONS phase -> (phase, advance) (phase = fill of
-// the current tile, 0..3): a thread folds its 8 balls for each of the 4 start phases, waves scan by composition.
+// ---- row plan (mlp_plan.h): ball -> ceil(clamp(cnt, 1, ns) / GR) granules of GR rows (GR = 8, or 4) ----------------
+// Packing is "next fit" into 32-row tiles (GPT = 32 / GR granules): a ball of <= GPT granules never straddles a tile
+// boundary (the rest of the tile is padded with invalid entries), so its maximum is complete inside one wave and is
+// written with a plain store; only balls of more than 32 distinct rows are split (atomic max on a row zeroed here).
+// Next fit is a sequential rule; it is evaluated in parallel as a scan over FUNCTIONS phase -> (phase, advance) (phase =
+// fill of the current tile, 0..GPT-1): a thread folds its 8 balls for each of the GPT start phases, waves scan by
+// composition.
 constexpr int kPlanThreads = 512, kPlanBallsPerThread = 8;
 constexpr int kPlanChunk = kPlanThreads * kPlanBallsPerThread;      // 4096 balls per workgroup
 
-struct PlanFn { int t[4]; };     // t[p] = advance << 2 | end phase, for start phase p
-__device__ __forceinline__ int plan_fn_at(const PlanFn &f, int p) {
-    return p == 0 ? f.t[0] : (p == 1 ? f.t[1] : (p == 2 ? f.t[2] : f.t[3]));
+template <int GPT> struct PlanFn { int t[GPT]; };     // t[p] = advance << SH | end phase, for start phase p
+template <int GPT> struct PlanSh { static constexpr int SH = GPT == 4 ? 2 : 3; };
+template <int GPT>
+__device__ __forceinline__ int plan_fn_at(const PlanFn<GPT> &f, int p) {
+    int v = f.t[0];
+#pragma unroll
+    for (int i = 1; i < GPT; ++i) v = p == i ? f.t[i] : v;
+    return v;
 }
 // first a, then b
-__device__ __forceinline__ PlanFn plan_fn_compose(const PlanFn &a, const PlanFn &b) {
-    PlanFn c;
+template <int GPT>
+__device__ __forceinline__ PlanFn<GPT> plan_fn_compose(const PlanFn<GPT> &a, const PlanFn<GPT> &b) {
+    constexpr int SH = PlanSh<GPT>::SH;
+    PlanFn<GPT> c;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int x = a.t[p], y = plan_fn_at(b, x & 3);
-        c.t[p] = (((x >> 2) + (y >> 2)) << 2) | (y & 3);
+    for (int p = 0; p < GPT; ++p) {
+        const int x = a.t[p], y = plan_fn_at<GPT>(b, x & (GPT - 1));
+        c.t[p] = (((x >> SH) + (y >> SH)) << SH) | (y & (GPT - 1));
     }
     return c;
 }
+// state (advance << SH | phase) followed by function y
+template <int GPT>
+__device__ __forceinline__ int plan_state_apply(int st, int y) {
+    constexpr int SH = PlanSh<GPT>::SH;
+    return (((st >> SH) + (y >> SH)) << SH) | (y & (GPT - 1));
+}
 // one ball of g granules placed from phase ph: returns the padding in front of it; updates ph
+template <int GPT>
 __device__ __forceinline__ int plan_place(int g, int &ph) {
     int pad = 0;
-    if (g <= 4 && ph + g > 4) { pad = 4 - ph; ph = 0; }
-    ph = (ph + g) & 3;
+    if (g <= GPT && ph + g > GPT) { pad = GPT - ph; ph = 0; }
+    ph = (ph + g) & (GPT - 1);
     return pad;
 }
+template <int GPT>
 __device__ __forceinline__ int plan_granules_of(const int *cnt, int ball, int nballs, int ns, int dense, int &rows) {
+    constexpr int GR = 32 / GPT;
     if (ball >= nballs) return 0;
     int c = cnt[ball];
     c = c < 1 ? 1 : (c > ns ? ns : c);
     if (dense) c = ns;
     rows += c;
-    return (c + 7) >> 3;
+    return (c + GR - 1) / GR;
 }
 // inclusive scan by composition over the 64 lanes of a wave
-__device__ __forceinline__ PlanFn plan_wave_scan(PlanFn incl, int lane) {
+template <int GPT>
+__device__ __forceinline__ PlanFn<GPT> plan_wave_scan(PlanFn<GPT> incl, int lane) {
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        PlanFn o;
+        PlanFn<GPT> o;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) o.t[p] = __shfl_up(incl.t[p], d);
-        if (lane >= d) incl = plan_fn_compose(o, incl);
+        for (int p = 0; p < GPT; ++p) o.t[p] = __shfl_up(incl.t[p], d);
+        if (lane >= d) incl = plan_fn_compose<GPT>(o, incl);
     }
     return incl;
 }
@@ -1220,18 +1238,19 @@ __device__ __forceinline__ PlanFn plan_wave_scan(PlanFn incl, int lane) {
 // the chunk (granules placed so far, fill of the open tile) is a function of all earlier balls.  Two launches, no
 // atomics, no flags to reset between calls, the same plan on every run:
 //   mlp_plan_summary_kernel   workgroup (chunk, scale) folds its 4096 balls into ONE phase -> (phase, advance) function
-//                             (+ distinct rows, split balls) and stores the six words in the scale's scratch;
+//                             (+ distinct rows, split balls) and stores the words in the scale's scratch;
 //   mlp_plan_kernel           composes the summaries of the chunks in front of it (a thread folds a run of them, a
 //                             wave scan and an 8-entry serial composition give the total) and packs its chunk.
 // History: until round 3 one workgroup per scale walked its chunks one after the other (61 us for layer1's 3 x 32 768
 // balls); then every workgroup re-folded all BALLS in front of it -- quadratic, 22 us per call at 8 frames but 50 us at
 // the 32 frames of a coalesced replay (pipeline.py), 0.2 ms of plans per replay.
 constexpr int kPlanMaxScales = 4;
-constexpr int kPlanSumInts = 8;      // per chunk: t[0..3] (advance << 2 | end phase for start phase p), rows, split balls
+constexpr int kPlanSumInts = 12;     // per chunk: t[0..7] (advance << SH | end phase for start phase p), rows, split balls, 2 unused
 struct PlanJob {
     const int *cnt;
     int *hdr, *gran, *sum;
     int ns, out_off, N;
+    int gr4;                         // 1: granules of 4 rows (8 per tile), 0: of 8 rows (4 per tile)
 };
 struct PlanJobs {
     PlanJob j[kPlanMaxScales];
@@ -1239,70 +1258,74 @@ struct PlanJobs {
     float *out;
 };
 
-// this thread's 8 balls of the chunk: granules, distinct rows, and their fold for the four start phases
-__device__ __forceinline__ PlanFn plan_fold_thread(const PlanJob &job, int ball0, int nballs, int dense,
-                                                   int (&g)[kPlanBallsPerThread], int &rows, int &nsp) {
+// this thread's 8 balls of the chunk: granules, distinct rows, and their fold for the GPT start phases
+template <int GPT>
+__device__ __forceinline__ PlanFn<GPT> plan_fold_thread(const PlanJob &job, int ball0, int nballs, int dense,
+                                                        int (&g)[kPlanBallsPerThread], int &rows, int &nsp) {
+    constexpr int SH = PlanSh<GPT>::SH;
 #pragma unroll
     for (int k = 0; k < kPlanBallsPerThread; ++k) {
-        g[k] = plan_granules_of(job.cnt, ball0 + k, nballs, job.ns, dense, rows);
-        nsp += g[k] > 4;
+        g[k] = plan_granules_of<GPT>(job.cnt, ball0 + k, nballs, job.ns, dense, rows);
+        nsp += g[k] > GPT;
     }
-    PlanFn f;
+    PlanFn<GPT> f;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < GPT; ++p) {
         int ph = p, adv = 0;
 #pragma unroll
         for (int k = 0; k < kPlanBallsPerThread; ++k)
-            if (g[k] > 0) { adv += plan_place(g[k], ph); adv += g[k]; }
-        f.t[p] = (adv << 2) | ph;
+            if (g[k] > 0) { adv += plan_place<GPT>(g[k], ph); adv += g[k]; }
+        f.t[p] = (adv << SH) | ph;
     }
     return f;
 }
 
-__global__ __launch_bounds__(kPlanThreads) void mlp_plan_summary_kernel(PlanJobs J) {
+template <int GPT>
+__device__ __forceinline__ void plan_summary_body(const PlanJobs &J, const PlanJob &job, int (*wfn)[8], int (*wsum)[2]) {
     constexpr int NWV = kPlanThreads / 64;
-    __shared__ int wfn[NWV][4];
-    __shared__ int wsum[NWV][2];
-    const PlanJob job = J.j[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int chunk0 = blockIdx.x * kPlanChunk;
-    if (chunk0 + kPlanChunk >= J.nballs) return;              // nobody reads the last chunk's summary
     int g[kPlanBallsPerThread], rows = 0, nsp = 0;
-    const PlanFn f = plan_fold_thread(job, chunk0 + tid * kPlanBallsPerThread, J.nballs, J.dense, g, rows, nsp);
-    const PlanFn incl = plan_wave_scan(f, lane);
+    const PlanFn<GPT> f = plan_fold_thread<GPT>(job, chunk0 + tid * kPlanBallsPerThread, J.nballs, J.dense, g, rows, nsp);
+    const PlanFn<GPT> incl = plan_wave_scan<GPT>(f, lane);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { rows += __shfl_xor(rows, d); nsp += __shfl_xor(nsp, d); }
     if (lane == 63) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) wfn[w][p] = incl.t[p];
+        for (int p = 0; p < GPT; ++p) wfn[w][p] = incl.t[p];
     }
     if (lane == 0) { wsum[w][0] = rows; wsum[w][1] = nsp; }
     __syncthreads();
-    if (tid < 4) {                                           // thread p: the chunk's function at start phase p
+    if (tid < GPT) {                                         // thread p: the chunk's function at start phase p
         int st = tid, r = 0, n = 0;
 #pragma unroll
         for (int i = 0; i < NWV; ++i) {
-            const int y = wfn[i][st & 3];
-            st = (((st >> 2) + (y >> 2)) << 2) | (y & 3);
+            st = plan_state_apply<GPT>(st, wfn[i][st & (GPT - 1)]);
             r += wsum[i][0]; n += wsum[i][1];
         }
         int *o = job.sum + (size_t)blockIdx.x * kPlanSumInts;
-        o[tid] = st - 0;                                     // advance << 2 | end phase (the start phase's 2 bits carry no advance)
-        if (tid == 0) { o[4] = r; o[5] = n; }
+        o[tid] = st;                                         // advance << SH | end phase (the start phase's bits carry no advance)
+        if (tid == 0) { o[8] = r; o[9] = n; }
     }
 }
 
-__global__ __launch_bounds__(kPlanThreads) void mlp_plan_kernel(PlanJobs J) {
-    constexpr int NWV = kPlanThreads / 64;
-    __shared__ int wfn[NWV][4];
-    __shared__ int wsum[NWV][2];
-    __shared__ int nsplit_s;
-    __shared__ int split_ball[kPlanChunk];
+__global__ __launch_bounds__(kPlanThreads) void mlp_plan_summary_kernel(PlanJobs J) {
+    __shared__ int wfn[kPlanThreads / 64][8];
+    __shared__ int wsum[kPlanThreads / 64][2];
     const PlanJob job = J.j[blockIdx.y];
+    if (blockIdx.x * kPlanChunk + kPlanChunk >= J.nballs) return;   // nobody reads the last chunk's summary
+    if (job.gr4) plan_summary_body<8>(J, job, wfn, wsum);
+    else plan_summary_body<4>(J, job, wfn, wsum);
+}
+
+template <int GPT>
+__device__ __forceinline__ void plan_pack_body(const PlanJobs &J, const PlanJob &job, int (*wfn)[8], int (*wsum)[2],
+                                               int &nsplit_s, int *split_ball) {
+    constexpr int NWV = kPlanThreads / 64;
+    constexpr int SH = PlanSh<GPT>::SH;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nballs = J.nballs;
     const int chunk0 = blockIdx.x * kPlanChunk;
-    if (chunk0 >= nballs) return;
     const bool last_chunk = chunk0 + kPlanChunk >= nballs;
     if (tid == 0) nsplit_s = 0;
 
@@ -1313,32 +1336,34 @@ __global__ __launch_bounds__(kPlanThreads) void mlp_plan_kernel(PlanJobs J) {
         const int nprev = blockIdx.x;
         const int per = (nprev + kPlanThreads - 1) / kPlanThreads;
         const int c0 = tid * per, c1 = min(c0 + per, nprev);
-        PlanFn f;
+        PlanFn<GPT> f;
         int rows = 0, nsp = 0;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) f.t[p] = p;
+        for (int p = 0; p < GPT; ++p) f.t[p] = p;
         for (int c = c0; c < c1; ++c) {
             const int *o = job.sum + (size_t)c * kPlanSumInts;
-            const int4 t4 = *(const int4 *)o;
-            const int2 r2 = *(const int2 *)(o + 4);
-            PlanFn h;
-            h.t[0] = t4.x; h.t[1] = t4.y; h.t[2] = t4.z; h.t[3] = t4.w;
-            f = plan_fn_compose(f, h);
+            PlanFn<GPT> h;
+#pragma unroll
+            for (int p = 0; p < GPT; p += 4) {
+                const int4 t4 = *(const int4 *)(o + p);
+                h.t[p] = t4.x; h.t[p + 1] = t4.y; h.t[p + 2] = t4.z; h.t[p + 3] = t4.w;
+            }
+            const int2 r2 = *(const int2 *)(o + 8);
+            f = plan_fn_compose<GPT>(f, h);
             rows += r2.x; nsp += r2.y;
         }
-        const PlanFn incl = plan_wave_scan(f, lane);
+        const PlanFn<GPT> incl = plan_wave_scan<GPT>(f, lane);
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) { rows += __shfl_xor(rows, d); nsp += __shfl_xor(nsp, d); }
         if (lane == 63) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) wfn[w][p] = incl.t[p];
+            for (int p = 0; p < GPT; ++p) wfn[w][p] = incl.t[p];
         }
         if (lane == 0) { wsum[w][0] = rows; wsum[w][1] = nsp; }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NWV; ++i) {
-            const int y = wfn[i][base & 3];
-            base = (((base >> 2) + (y >> 2)) << 2) | (y & 3);
+            base = plan_state_apply<GPT>(base, wfn[i][base & (GPT - 1)]);
             rows_before += wsum[i][0];
             nsplit_before += wsum[i][1];
         }
@@ -1348,41 +1373,39 @@ __global__ __launch_bounds__(kPlanThreads) void mlp_plan_kernel(PlanJobs J) {
     // ---- this chunk
     const int ball0 = chunk0 + tid * kPlanBallsPerThread;
     int g[kPlanBallsPerThread], rows = 0, nsp_unused = 0;
-    const PlanFn f = plan_fold_thread(job, ball0, nballs, J.dense, g, rows, nsp_unused);
-    const PlanFn incl = plan_wave_scan(f, lane);
+    const PlanFn<GPT> f = plan_fold_thread<GPT>(job, ball0, nballs, J.dense, g, rows, nsp_unused);
+    const PlanFn<GPT> incl = plan_wave_scan<GPT>(f, lane);
     int rsum = rows;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) rsum += __shfl_xor(rsum, d);
     if (lane == 63) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) wfn[w][p] = incl.t[p];
+        for (int p = 0; p < GPT; ++p) wfn[w][p] = incl.t[p];
     }
     if (lane == 0) wsum[w][0] = rsum;
     __syncthreads();
     int st = base, bend = base, rows_chunk = 0;       // state in front of this wave / behind the chunk
 #pragma unroll
     for (int i = 0; i < NWV; ++i) {
-        const int y = wfn[i][bend & 3];
-        bend = (((bend >> 2) + (y >> 2)) << 2) | (y & 3);
+        bend = plan_state_apply<GPT>(bend, wfn[i][bend & (GPT - 1)]);
         if (i < w) st = bend;
         rows_chunk += wsum[i][0];
     }
     {
-        PlanFn excl;                                    // exclusive prefix of this thread inside its wave
+        PlanFn<GPT> excl;                               // exclusive prefix of this thread inside its wave
 #pragma unroll
-        for (int p = 0; p < 4; ++p) { const int v = __shfl_up(incl.t[p], 1); excl.t[p] = lane == 0 ? p : v; }
-        const int y = plan_fn_at(excl, st & 3);
-        st = (((st >> 2) + (y >> 2)) << 2) | (y & 3);
+        for (int p = 0; p < GPT; ++p) { const int v = __shfl_up(incl.t[p], 1); excl.t[p] = lane == 0 ? p : v; }
+        st = plan_state_apply<GPT>(st, plan_fn_at<GPT>(excl, st & (GPT - 1)));
     }
-    int pos = st >> 2, ph = st & 3;
+    int pos = st >> SH, ph = st & (GPT - 1);
 #pragma unroll
     for (int k = 0; k < kPlanBallsPerThread; ++k) {
         if (g[k] > 0) {
             const int ball = ball0 + k;
-            const int pad = plan_place(g[k], ph);
+            const int pad = plan_place<GPT>(g[k], ph);
             for (int j = 0; j < pad; ++j) job.gran[pos + j] = -1;
             pos += pad;
-            const int split = g[k] > 4 ? 1 : 0;
+            const int split = g[k] > GPT ? 1 : 0;
             for (int j = 0; j < g[k]; ++j) job.gran[pos + j] = (ball << 7) | (j << 1) | split;
             pos += g[k];
             if (split) split_ball[atomicAdd(&nsplit_s, 1)] = ball;
@@ -1397,10 +1420,21 @@ __global__ __launch_bounds__(kPlanThreads) void mlp_plan_kernel(PlanJobs J) {
     }
     // header (the workgroup of the last chunk): granules padded to whole tiles with invalid entries, split balls, rows
     if (last_chunk && tid == 0) {
-        const int used = bend >> 2, total = (used + 3) & ~3;
+        const int used = bend >> SH, total = (used + GPT - 1) & ~(GPT - 1);
         for (int q = used; q < total; ++q) job.gran[q] = -1;
-        job.hdr[0] = total; job.hdr[1] = nsplit_before + nsp; job.hdr[2] = rows_before + rows_chunk; job.hdr[3] = 0;
+        job.hdr[0] = total; job.hdr[1] = nsplit_before + nsp; job.hdr[2] = rows_before + rows_chunk; job.hdr[3] = 32 / GPT;
     }
+}
+
+__global__ __launch_bounds__(kPlanThreads) void mlp_plan_kernel(PlanJobs J) {
+    __shared__ int wfn[kPlanThreads / 64][8];
+    __shared__ int wsum[kPlanThreads / 64][2];
+    __shared__ int nsplit_s;
+    __shared__ int split_ball[kPlanChunk];
+    const PlanJob job = J.j[blockIdx.y];
+    if (blockIdx.x * kPlanChunk >= J.nballs) return;
+    if (job.gr4) plan_pack_body<8>(J, job, wfn, wsum, nsplit_s, split_ball);
+    else plan_pack_body<4>(J, job, wfn, wsum, nsplit_s, split_ball);
 }
 
 int roundup(int x, int q) { return (x + q - 1) / q * q; }
@@ -1411,25 +1445,32 @@ int roundup(int x, int q) { return (x + q - 1) / q * q; }
 int sa_rowwave_try(int b, int n, int m, int ns, int c, const float *xyz, const float *feat, const float *new_xyz,
                    const int *idx, const int *cnt, int nl, const int *dims, const void *const *wpack,
                    const float *const *bias, float *out, int out_stride, int out_off, const int *plan_hdr,
-                   const int *plan_gran, long max_tiles, int fp16, int *overflow, hipStream_t stream, int *st);
+                   const int *plan_gran, long max_tiles, int fp16, int gr4, int dry, int *overflow, hipStream_t stream, int *st);
 
 // mlp_wide128.hip: the widest fp16 scales on 128-row items (a weight fragment feeds four MFMA tiles)
 int sa_wide128_try(int b, int n, int m, int ns, int c, const float *xyz, const float *feat, const float *new_xyz,
                    const int *idx, const int *cnt, int nl, const int *dims, const void *const *wpack,
                    const float *const *bias, float *out, int out_stride, int out_off, const int *plan_hdr,
-                   const int *plan_gran, long max_tiles, int fp16, int force, int *overflow, hipStream_t stream, int *st);
+                   const int *plan_gran, long max_tiles, int fp16, int force, int dry, int *overflow, hipStream_t stream, int *st);
 
-// Upper bound of the plan length: next fit never leaves two consecutive tiles with a combined fill <= 4 granules, so
-// the list is shorter than twice the granules (+ the padding of the last tile).
+// Upper bound of the plan length in granules of 8 rows: next fit never leaves two consecutive tiles with a combined fill
+// <= one tile, so the list is shorter than twice the granules (+ the padding of the last tile).  (max + 3) / 4 bounds
+// the TILES of a plan of either granule size: a 4-row plan of the same balls never has more tiles than the 8-row bound
+// (ceil(ns / 4) <= 2 ceil(ns / 8)).
 static long sa_plan_max_granules(long nballs, int ns) {
     const long g = nballs * ((ns + 7) / 8);
     return (ns <= 8 ? g : 2 * g) + 8;
+}
+// ... and in granules of 4 rows: what the entry list of a scale's scratch is sized for (either granule size fits)
+static long sa_plan_max_entries(long nballs, int ns) {
+    const long g = nballs * ((ns + 3) / 4);
+    return (ns <= 4 ? g : 2 * g) + 16;
 }
 
 // ints in front of the chunk summaries of a scale's scratch: header + one int per granule of the densest plan, 16-byte
 // aligned
 static size_t sa_plan_sum_offset_ints(long nballs, int ns) {
-    return ((size_t)sa::kPlanHeaderInts + (size_t)sa_plan_max_granules(nballs, ns) + 8 + 3) & ~(size_t)3;
+    return ((size_t)sa::kPlanHeaderInts + (size_t)sa_plan_max_entries(nballs, ns) + 8 + 3) & ~(size_t)3;
 }
 // Bytes of caller-owned scratch sa_group_mlp_max needs for the row plan of one scale (header + one int per granule
 // of the densest plan + the summaries of its 4096-ball chunks).
@@ -1478,10 +1519,12 @@ static bool use_gemm_chain(int b, int m, int ns, int c, int nl, const int *dims,
 // Row plans of ALL scales of an SA layer (two launches: chunk summaries, then the packing; workgroups = chunks x scales).  cnt[i]: pts_cnt of scale i
 // [b, m]; ws[i]: scratch of sa_group_mlp_max_ws_bytes(b, m, ns[i]) bytes; out / out_stride / out_off[i] / nout[i]:
 // where scale i's pooled channels go (rows of balls with more than 32 distinct rows are zeroed here).  The
-// sa_group_mlp_max calls of the layer then pass the same ws[i] and flags | 2.
-extern "C" int sa_group_mlp_plan(int b, int m, int nscale, const int *ns, const int *const *cnt, void *const *ws,
-                                 float *out, int out_stride, const int *out_off, const int *nout, int flags,
-                                 hipStream_t stream) {
+// sa_group_mlp_max calls of the layer then pass the same ws[i] and flags | 2.  scale_flags (may be null): bit 6 (64) of
+// scale_flags[i] asks for granules of 4 rows for scale i (mlp_plan.h; ask sa_group_mlp_granule_rows which scales take
+// them) -- the same bit then goes into that scale's flags of sa_group_mlp_max / sa_group_mlp_max_layer.
+extern "C" int sa_group_mlp_plan2(int b, int m, int nscale, const int *ns, const int *const *cnt, void *const *ws,
+                                  float *out, int out_stride, const int *out_off, const int *nout, int flags,
+                                  const int *scale_flags, hipStream_t stream) {
     if (b <= 0 || m <= 0 || nscale < 1 || nscale > kPlanMaxScales || !ns || !cnt || !ws || !out || !out_off || !nout)
         return SA_ERR_INVALID;
     const long nballs = (long)b * m;
@@ -1489,15 +1532,49 @@ extern "C" int sa_group_mlp_plan(int b, int m, int nscale, const int *ns, const 
     PlanJobs J{};
     for (int i = 0; i < nscale; ++i) {
         if (ns[i] <= 0 || !cnt[i] || !ws[i] || nout[i] <= 0) return SA_ERR_INVALID;
-        if (ns[i] > 8 * sa::kPlanMaxOrd) return SA_ERR_UNSUPPORTED;
+        const int gr4 = scale_flags && (scale_flags[i] & 64) ? 1 : 0;
+        if (ns[i] > (gr4 ? 4 : 8) * sa::kPlanMaxOrd) return SA_ERR_UNSUPPORTED;
         J.j[i].cnt = cnt[i]; J.j[i].hdr = (int *)ws[i]; J.j[i].gran = (int *)ws[i] + sa::kPlanHeaderInts;
         J.j[i].sum = (int *)ws[i] + sa_plan_sum_offset_ints(nballs, ns[i]);
-        J.j[i].ns = ns[i]; J.j[i].out_off = out_off[i]; J.j[i].N = nout[i];
+        J.j[i].ns = ns[i]; J.j[i].out_off = out_off[i]; J.j[i].N = nout[i]; J.j[i].gr4 = gr4;
     }
     J.nballs = (int)nballs; J.dense = flags & 1; J.out_stride = out_stride; J.out = out;
     launch_plan(J, nscale, stream);
     SA_CHECK_LAUNCH();
     return SA_OK;
+}
+extern "C" int sa_group_mlp_plan(int b, int m, int nscale, const int *ns, const int *const *cnt, void *const *ws,
+                                 float *out, int out_stride, const int *out_off, const int *nout, int flags,
+                                 hipStream_t stream) {
+    return sa_group_mlp_plan2(b, m, nscale, ns, cnt, ws, out, out_stride, out_off, nout, flags, nullptr, stream);
+}
+
+// which kernel family takes one scale with these flags (the dispatch order of sa_group_mlp_max, nothing launched):
+// the row-wave kernels of mlp_rowwave.hip read plans of either granule size and are fastest on 4-row granules;
+// everything else reads 8-row plans only
+static bool scale_takes_rowwave(int b, int n, int m, int ns, int c, int nl, const int *dims, const void *const *wpack,
+                                size_t ws_bytes, int flags) {
+    const bool fp16 = (flags & 4) != 0;
+    const float *const bias3[3] = {nullptr, nullptr, nullptr};
+    if (flags & 1) return false;                                      // dense A/B plans stay on 8-row granules
+    if (nl != 3 || ns > 4 * sa::kPlanMaxOrd) return false;
+    if (use_gemm_chain(b, m, ns, c, nl, dims, ws_bytes, flags)) return false;
+    const long max_tiles = (sa_plan_max_granules((long)b * m, ns) + 3) / 4;
+    int st = SA_OK;
+    if (fp16 && !(flags & 8) && ((flags & 32) || (long)b * m * ns >= 4096) &&
+        sa_wide128_try(b, n, m, ns, c, nullptr, (const float *)wpack, nullptr, nullptr, nullptr, nl, dims, wpack, bias3, nullptr, 0, 0,
+                       nullptr, nullptr, max_tiles, 1, (flags & 32) ? 1 : 0, 1, nullptr, nullptr, &st))
+        return false;
+    return sa_rowwave_try(b, n, m, ns, c, nullptr, nullptr, nullptr, nullptr, nullptr, nl, dims, wpack, bias3, nullptr, 0, 0,
+                          nullptr, nullptr, max_tiles, fp16 ? 1 : 0, 1, 1, nullptr, nullptr, &st) != 0;
+}
+// Rows per granule (4 or 8) the plan of this scale should be built with: 4 when a row-wave kernel will take the scale
+// (pass flags | 64 to sa_group_mlp_plan2 and to the MLP call then), 8 otherwise.  wpack: the scale's packed layers (the
+// streamed kernels need them back to back); ws_bytes: size of the scale's scratch; flags: as for sa_group_mlp_max.
+extern "C" int sa_group_mlp_granule_rows(int b, int n, int m, int ns, int c, int nl, const int *dims, const void *const *wpack,
+                                         size_t ws_bytes, int flags) {
+    if (b <= 0 || n <= 0 || m <= 0 || ns <= 0 || c < 0 || nl < 1 || nl > kMaxLayers || !dims || !wpack) return 8;
+    return scale_takes_rowwave(b, n, m, ns, c, nl, dims, wpack, ws_bytes, flags) ? 4 : 8;
 }
 
 // One scale of an SA layer.  Layer l: wpack[l] (device, fragment-packed hi/lo bf16, see header),
@@ -1527,16 +1604,29 @@ extern "C" int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float 
     const long max_tiles = (gmax + 3) / 4;
     if (max_tiles > 0x0FFFFFFFl) return SA_ERR_UNSUPPORTED;
     int *hdr = (int *)ws, *gran = hdr + sa::kPlanHeaderInts;
+    // granule size: a plan built by the caller (flags bit 1) has the size its flags say (bit 6 = 4 rows); the plan of this
+    // call is built for the kernel that will take the scale.  SA_MLP_GR4 = 0 (tuning build): 8-row granules everywhere.
+    static const int gr4_knob = SA_KNOB("SA_MLP_GR4", 1);
+    const bool gr4 = (flags & 2) ? (flags & 64) != 0
+                                 : (gr4_knob != 0 && scale_takes_rowwave(b, n, m, ns, c, nl, dims, wpack, ws_bytes, flags));
     // ---- the row plan of this call (unless sa_group_mlp_plan built the plans of the whole layer already)
     if (!(flags & 2)) {
         PlanJobs J{};
         J.j[0].cnt = cnt; J.j[0].hdr = hdr; J.j[0].gran = gran; J.j[0].ns = ns; J.j[0].out_off = out_off; J.j[0].N = dims[nl];
+        J.j[0].gr4 = gr4 ? 1 : 0;
         J.j[0].sum = hdr + sa_plan_sum_offset_ints(nballs, ns);
         J.nballs = (int)nballs; J.dense = flags & 1; J.out_stride = out_stride; J.out = out;
         launch_plan(J, 1, stream);
         SA_CHECK_LAUNCH();
     }
     const bool fp16 = (flags & 4) != 0;
+    if (gr4) {                                  // 4-row granules: only the row-wave kernels read them
+        int st = SA_OK;
+        if (sa_rowwave_try(b, n, m, ns, c, xyz, feat, new_xyz, idx, cnt, nl, dims, wpack, bias, out, out_stride,
+                           out_off, hdr, gran, max_tiles, fp16 ? 1 : 0, 1, 0, overflow, stream, &st))
+            return st;
+        return SA_ERR_UNSUPPORTED;
+    }
     if (use_gemm_chain(b, m, ns, c, nl, dims, ws_bytes, flags)) {
         const int *hdr_c = hdr, *gran_c = gran;
         void *scratch = (char *)ws + plan_bytes_aligned(b, m, ns);
@@ -1546,13 +1636,13 @@ extern "C" int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float 
     if (fp16 && !(flags & 8) && ((flags & 32) || (long)b * m * ns >= 4096)) {   // the widest scales on 96-row items (mlp_wide128.hip)
         int st = SA_OK;
         if (sa_wide128_try(b, n, m, ns, c, xyz, feat, new_xyz, idx, cnt, nl, dims, wpack, bias, out, out_stride, out_off,
-                           hdr, gran, max_tiles, 1, (flags & 32) ? 1 : 0, overflow, stream, &st))
+                           hdr, gran, max_tiles, 1, (flags & 32) ? 1 : 0, 0, overflow, stream, &st))
             return st;
     }
     {
         int st = SA_OK;
         if (sa_rowwave_try(b, n, m, ns, c, xyz, feat, new_xyz, idx, cnt, nl, dims, wpack, bias, out, out_stride,
-                           out_off, hdr, gran, max_tiles, fp16 ? 1 : 0, overflow, stream, &st))
+                           out_off, hdr, gran, max_tiles, fp16 ? 1 : 0, 0, 0, overflow, stream, &st))
             return st;
     }
     const int abytes = fp16 ? 2 : 4;               // LDS bytes per activation channel (one fp16 plane / hi + lo bf16)
@@ -1645,7 +1735,7 @@ int sa_rowwave_try_layer(int b, int n, int m, const int *ns, int c, const float 
                          const float *new_xyz, const int *const *idx, const int *const *cnt, const int *dims,
                          const void *const *wpack, const float *const *bias, float *out, int out_stride,
                          const int *out_off, const int *const *plan_hdr, const int *const *plan_gran,
-                         const long *max_tiles, const int *fp16, int *overflow, hipStream_t stream, int *st);
+                         const long *max_tiles, const int *fp16, int gr4, int *overflow, hipStream_t stream, int *st);
 
 // All scales of one SA layer (layers_util.py:134-181): scale i has nsample ns[i], index / count tensors idx[i] /
 // cnt[i], layer widths dims[i*(nl+1) ..], weights wpack[i*nl ..] / bias[i*nl ..], output slice out_off[i], plan
@@ -1674,10 +1764,11 @@ extern "C" int sa_group_mlp_max_layer(int nscale, int b, int n, int m, const int
             max_tiles[i] = (sa_plan_max_granules((long)b * m, ns[i]) + 3) / 4;
             fp16[i] = (flags[i] & 4) ? 1 : 0;
         }
+        ok = ok && (flags[0] & 64) == (flags[1] & 64) && (flags[0] & 64) == (flags[2] & 64);   // one granule size for the launch
         if (ok) {
             int st = SA_OK;
             if (sa_rowwave_try_layer(b, n, m, ns, c, xyz, feat, new_xyz, idx, cnt, dims, wpack, bias, out, out_stride,
-                                     out_off, hdr, gran, max_tiles, fp16, overflow, stream, &st))
+                                     out_off, hdr, gran, max_tiles, fp16, (flags[0] & 64) ? 1 : 0, overflow, stream, &st))
                 return st;
         }
     }

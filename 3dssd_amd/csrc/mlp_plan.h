@@ -19,20 +19,28 @@
 //                     index; after the last layer the granule maxima of a ball's run inside the tile are combined
 //                     with wave-uniform branches and written (plain store, or atomic max for split balls).
 // `dense` plans (every ball gets ceil(ns/8) granules) reproduce the old behaviour for A/B measurements.
+//
+// Round 5: granules of FOUR rows (GR = 4, eight per tile) for the scales the row-wave kernels of mlp_rowwave.hip take.
+// On KITTI-like frames the inner bands of layer 1 / layer 2 hold 1.0-1.7 points per ball: eight-row granules evaluate
+// 4.7-8x the distinct rows there, four-row granules half of that.  A four-row granule is one lane half of a register
+// quad of the D layout (rows 8q .. 8q+3 in the lower half, 8q+4 .. 8q+7 in the upper one), so its maximum is the same
+// three v_max and the same v_permlane32_swap -- without the final max across the halves.  hdr[3] of a plan says which
+// granule it was built with; the kernels of mlp.hip / mlp_wide128.hip / mlp_gemm.hip read eight-row plans only.
 #pragma once
 #include "sa_common.h"
 
 namespace sa {
 
-constexpr int kPlanHeaderInts = 4;     // [0] granules, [1] split balls, [2] distinct rows, [3] unused
-constexpr int kPlanMaxOrd = 64;        // ordinal field: 6 bits -> nsample <= 512
+constexpr int kPlanHeaderInts = 4;     // [0] granules, [1] split balls, [2] distinct rows, [3] rows per granule (8 or 4)
+constexpr int kPlanMaxOrd = 64;        // ordinal field: 6 bits -> nsample <= 512 (8-row granules), <= 256 (4-row)
 
 __device__ __forceinline__ int plan_entry(const int *gran, int ngran, int G) { return G < ngran ? gran[G] : -1; }
 __device__ __forceinline__ int plan_ball(int e) { return e >> 7; }
 // sample index of row j (0..7) of the granule; rows past nsample repeat sample 0 (idx rows are already padded with
 // the first hit up to nsample by the ball query)
+template <int GR = 8>
 __device__ __forceinline__ int plan_sample(int e, int j, int ns) {
-    const int s = ((e >> 1) & (kPlanMaxOrd - 1)) * 8 + j;
+    const int s = ((e >> 1) & (kPlanMaxOrd - 1)) * GR + j;
     return (e < 0 || s >= ns) ? 0 : s;
 }
 
@@ -49,17 +57,34 @@ __device__ __forceinline__ void granule_max(const plan_f32x16 &a, float (&qm)[4]
     }
 }
 
-// ent[], cn[]: the tile's four plan entries and their balls' counts, WAVE-UNIFORM (SGPRs): every branch below is scalar.
-// Lanes 0..31 hold output channel c of the tile; writes relu(max + bias) (0 for empty balls, layers_util.py:178-181).
-__device__ __forceinline__ void pool_write_tile(float (&qm)[4], const int (&ent)[4], const int (&cn)[4], float bias_c,
+// the 4-row form: qm[2q + h] = maximum over rows 8q + 4h .. 8q + 4h + 3 (register quad q of lane half h), in EVERY lane
+__device__ __forceinline__ void granule_max4(const plan_f32x16 &a, float (&qm)[8]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float a0 = fmax_nn(a[4 * q], a[4 * q + 1]);
+        const float a1 = fmax_nn(a[4 * q + 2], a[4 * q + 3]);
+        const float x = fmax_nn(a0, a1);
+        // v_permlane32_swap(x, x): [0] = the lower half's value in both halves, [1] = the upper half's
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+        qm[2 * q] = __uint_as_float(sw[0]);
+        qm[2 * q + 1] = __uint_as_float(sw[1]);
+    }
+}
+
+// ent[], cn[]: the tile's NG plan entries (4 of 8 rows or 8 of 4 rows) and their balls' counts, WAVE-UNIFORM (SGPRs): every
+// branch below is scalar.  Lanes 0..31 hold output channel c of the tile; writes relu(max + bias) (0 for empty balls,
+// layers_util.py:178-181).
+template <int NG>
+__device__ __forceinline__ void pool_write_tile(float (&qm)[NG], const int (&ent)[NG], const int (&cn)[NG], float bias_c,
                                                 int c, int N, float *out, int out_stride, int out_off, int lane) {
 #pragma unroll
-    for (int g = 1; g < 4; ++g)
+    for (int g = 1; g < NG; ++g)
         if (ent[g] >= 0 && ent[g - 1] >= 0 && plan_ball(ent[g]) == plan_ball(ent[g - 1])) qm[g] = fmax_nn(qm[g], qm[g - 1]);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < NG; ++g) {
         if (ent[g] < 0) continue;
-        const bool last = g == 3 || ent[g < 3 ? g + 1 : 3] < 0 || plan_ball(ent[g < 3 ? g + 1 : 3]) != plan_ball(ent[g]);
+        const bool last = g == NG - 1 || ent[g < NG - 1 ? g + 1 : NG - 1] < 0 ||
+                          plan_ball(ent[g < NG - 1 ? g + 1 : NG - 1]) != plan_ball(ent[g]);
         if (!last) continue;
         if (lane < 32 && c < N) {
             float v = qm[g] + bias_c;

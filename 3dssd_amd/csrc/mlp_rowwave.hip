@@ -108,12 +108,15 @@ struct RowRef { int pt, ball, cnt, ent; };   // source point (flat index), ball,
 // requested one tile earlier than the index (load_plan_ent, then row_ref_of on the next iteration): requested together,
 // the index load waited a full memory round trip for the entry at every tile -- 20-40 % of a wave's time in the narrow
 // scales (tools/rw_phase_prof.py).
+// GR: rows per granule of the plan (8, or 4 since round 5: mlp_plan.h); a tile holds 32 / GR entries.
+template <int GR>
 __device__ __forceinline__ int load_plan_ent(const RwParams &P, int ngran, int tile, int row) {
-    return sa::plan_entry(P.gran, ngran, tile * 4 + (row >> 3));
+    return sa::plan_entry(P.gran, ngran, tile * (32 / GR) + row / GR);
 }
+template <int GR>
 __device__ __forceinline__ RowRef row_ref_of(const RwParams &P, int ent, int row) {
     const int ball = ent >= 0 ? sa::plan_ball(ent) : 0;
-    const int s = sa::plan_sample(ent, row & 7, P.ns);
+    const int s = sa::plan_sample<GR>(ent, row & (GR - 1), P.ns);
     const int a_raw = P.idx[(unsigned)(ball * P.ns + s)];
     const int c = P.cnt[(unsigned)ball];
     int frame;
@@ -130,8 +133,26 @@ __device__ __forceinline__ RowRef row_ref_of(const RwParams &P, int ent, int row
     r.pt = frame * P.n + (c > 0 ? a_raw : 0);               // layers_util.py:157-159
     return r;
 }
+template <int GR>
 __device__ __forceinline__ RowRef load_row_ref(const RwParams &P, int ngran, int tile, int row) {
-    return row_ref_of(P, load_plan_ent(P, ngran, tile, row), row);
+    return row_ref_of<GR>(P, load_plan_ent<GR>(P, ngran, tile, row), row);
+}
+// the tile's plan entries and ball counts, wave-uniform (rows 0, GR, 2 GR, ...), and the pooled write of one column tile
+template <int GR>
+__device__ __forceinline__ void tile_entries(const RowRef &cur, int (&ent)[32 / GR], int (&cn)[32 / GR]) {
+#pragma unroll
+    for (int g = 0; g < 32 / GR; ++g) {
+        ent[g] = __builtin_amdgcn_readlane(cur.ent, GR * g);
+        cn[g] = __builtin_amdgcn_readlane(cur.cnt, GR * g);
+    }
+}
+template <int GR>
+__device__ __forceinline__ void pool_tile(const f32x16 &acc, const int (&ent)[32 / GR], const int (&cn)[32 / GR], float bias_c,
+                                          int c, const RwParams &P, int lane) {
+    float qm[32 / GR];
+    if constexpr (GR == 8) sa::granule_max(acc, qm);
+    else sa::granule_max4(acc, qm);
+    sa::pool_write_tile<32 / GR>(qm, ent, cn, bias_c, c, P.N3, P.out, P.out_stride, P.out_off, lane);
 }
 
 // Relative coordinates (and, for C == 1, the single feature channel) of this lane's row.
@@ -250,7 +271,7 @@ __device__ __forceinline__ void hidden_layer(const uint4 *W, const float *bias, 
 
 // KS0: k-steps of the gathered input; (NT1, KS1), (NT2, KS2): output tiles of hidden layer 1 / 2 and the
 // k-steps the next layer reads of them; NT3: output tiles of the last layer.  NW waves per workgroup.
-template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF>
+template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF, int GR>
 __device__ __forceinline__ void rw_body(const RwParams &P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int nW0 = NT1 * KS0 * 128, nW1 = NT2 * KS1 * 128, nW2 = NT3 * KS2 * 128;   // uint4 counts
@@ -259,7 +280,7 @@ __device__ __forceinline__ void rw_body(const RwParams &P) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ngran = __builtin_amdgcn_readfirstlane(P.hdr[0]);
-    const int ntiles = (ngran + 3) >> 2;
+    const int ntiles = (ngran + 32 / GR - 1) / (32 / GR);
     int gstride;                                         // XCD x takes a contiguous eighth of every pass over the tiles
     const int bx = sa::xcd_block(blockIdx.x, gridDim.x, (ntiles + NW - 1) / NW, gstride);
     if (bx < 0 || bx * NW >= ntiles) return;             // persistent grid sized for the densest plan: no work, no copy
@@ -305,14 +326,14 @@ __device__ __forceinline__ void rw_body(const RwParams &P) {
     advance(te);
 
     float raw[KS0][8];
-    RowRef cur = load_row_ref(P, ngran, tc, row);
+    RowRef cur = load_row_ref<GR>(P, ngran, tc, row);
     {
         const RowTail tl = load_row_tail<TAILF>(P, cur);
 #pragma unroll
         for (int ks = 0; ks < KS0; ++ks) load_group(P, cur, tl, 2 * ks + half, raw[ks]);
     }
-    RowRef nxt = load_row_ref(P, ngran, tf, row);
-    int ent_i = load_plan_ent(P, ngran, ti, row);
+    RowRef nxt = load_row_ref<GR>(P, ngran, tf, row);
+    int ent_i = load_plan_ent<GR>(P, ngran, ti, row);
 
     for (bool more = true; more;) {
         more = tc + nwaves < ntiles;
@@ -320,13 +341,9 @@ __device__ __forceinline__ void rw_body(const RwParams &P) {
         uint4 h0[KS0], l0[KS0];
 #pragma unroll
         for (int ks = 0; ks < KS0; ++ks) split8(raw[ks], h0[ks], l0[ks]);
-        // the tile's four plan entries and ball counts, wave-uniform (rows 0, 8, 16, 24)
-        int ent[4], cn[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            ent[g] = __builtin_amdgcn_readlane(cur.ent, 8 * g);
-            cn[g] = __builtin_amdgcn_readlane(cur.cnt, 8 * g);
-        }
+        // the tile's plan entries and ball counts, wave-uniform (rows 0, GR, 2 GR, ...)
+        int ent[32 / GR], cn[32 / GR];
+        tile_entries<GR>(cur, ent, cn);
         RW_COUNT();
         RW_TICK(1)
         // ---- loads of the next tile (features) and of the one after (indices), then pin them above the math
@@ -336,8 +353,8 @@ __device__ __forceinline__ void rw_body(const RwParams &P) {
 #pragma unroll
             for (int ks = 0; ks < KS0; ++ks) load_group(P, cur, tl, 2 * ks + half, raw[ks]);
         }
-        nxt = row_ref_of(P, ent_i, row);                 // tile ti: its entry arrived during the previous tile
-        ent_i = load_plan_ent(P, ngran, te, row);
+        nxt = row_ref_of<GR>(P, ent_i, row);             // tile ti: its entry arrived during the previous tile
+        ent_i = load_plan_ent<GR>(P, ngran, te, row);
         advance(tc);
         advance(tf);
         advance(ti);
@@ -377,10 +394,8 @@ __device__ __forceinline__ void rw_body(const RwParams &P) {
 #pragma unroll
             for (int tt = 0; tt < TG; ++tt) {
                 if (ct0 + tt < NT3) {
-                    float qm[4];
-                    sa::granule_max(acc[tt], qm);
                     const int c = (ct0 + tt) * 32 + (lane & 31);
-                    sa::pool_write_tile(qm, ent, cn, b2[c], c, P.N3, P.out, P.out_stride, P.out_off, lane);
+                    pool_tile<GR>(acc[tt], ent, cn, b2[c], c, P, lane);
                 }
             }
         }
@@ -388,9 +403,9 @@ __device__ __forceinline__ void rw_body(const RwParams &P) {
     }
     RW_FLUSH(gw)
 }
-template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF>
+template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF, int GR>
 __global__ __launch_bounds__(NW * 64, WPE) void mlp_rw_kernel(RwParams P) {
-    rw_body<KS0, NT1, KS1, NT2, KS2, NT3, NW, WPE, TAILF>(P);
+    rw_body<KS0, NT1, KS1, NT2, KS2, NT3, NW, WPE, TAILF, GR>(P);
 }
 
 // =====================================================================================================
@@ -513,7 +528,7 @@ __device__ __forceinline__ void load_bias_tile(const float *bias, int ct, int ha
 // PR: operand precision (3 = split bf16, 1 = fp16, see mlp.hip); CPP: chunks per pass (a divisor of the k-step tiles
 // of the scale); PF: 1 = the next tile's rows are requested right after this tile's last layer (two or more tiles per
 // wave), 0 = at the top of the pass (one tile per wave: nothing to prefetch, 17 x 8 registers less).
-template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF, int DEPTH, int PR, int CPP, int PF>
+template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF, int DEPTH, int PR, int CPP, int PF, int GR>
 __device__ __forceinline__ void rs_body(const RwParams &P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KT0 = NT1 * KS0, KT1 = NT2 * KS1, KT2 = NT3 * KS2, TOT = KT0 + KT1 + KT2;
@@ -532,7 +547,7 @@ __device__ __forceinline__ void rs_body(const RwParams &P) {
     X.w = w; X.lane = lane; X.abase = 0;
 
     const int ngran = __builtin_amdgcn_readfirstlane(P.hdr[0]);
-    const int ntiles = (ngran + 3) >> 2;
+    const int ntiles = (ngran + 32 / GR - 1) / (32 / GR);
     int gstride;                                         // XCD x takes a contiguous eighth of every pass over the tiles
     const int bx = sa::xcd_block(blockIdx.x, gridDim.x, (ntiles + NW - 1) / NW, gstride);
     if (bx < 0 || bx * NW >= ntiles) return;             // persistent grid sized for the densest plan
@@ -550,7 +565,7 @@ __device__ __forceinline__ void rs_body(const RwParams &P) {
 
     // ---- prologue: chunk 0 into slot 0, chunks 1 .. DEPTH staged; first tile's rows and features
     rs_issue_chunk<PC, NW, PPW>(P, X, stage[0], 0);
-    RowRef cur = load_row_ref(P, ngran, tc, row);
+    RowRef cur = load_row_ref<GR>(P, ngran, tc, row);
     rs_store_stage<PC, NW, PPW>(X, stage[0], 0);
 #pragma unroll
     for (int k = 1; k <= DEPTH; ++k) rs_issue_chunk<PC, NW, PPW>(P, X, stage[k % DEPTH], k % CPP);
@@ -560,8 +575,8 @@ __device__ __forceinline__ void rs_body(const RwParams &P) {
 #pragma unroll
         for (int ks = 0; ks < KS0; ++ks) load_group(P, cur, tl, 2 * ks + half, raw[ks]);
     }
-    RowRef nxt = load_row_ref(P, ngran, tf, row);
-    int ent_f = load_plan_ent(P, ngran, tf + nwaves, row);      // the entry of the tile after `nxt`: one tile ahead of its index
+    RowRef nxt = load_row_ref<GR>(P, ngran, tf, row);
+    int ent_f = load_plan_ent<GR>(P, ngran, tf + nwaves, row);  // the entry of the tile after `nxt`: one tile ahead of its index
     sa::f16_guard_t det = 0;                 // fp16 range guard (mlp_act.h), scalar registers
 
     RW_TICK(0)
@@ -575,12 +590,8 @@ __device__ __forceinline__ void rs_body(const RwParams &P) {
         uint4 h0[KS0], l0[KS0];
 #pragma unroll
         for (int ks = 0; ks < KS0; ++ks) to_planes<PR>(raw[ks], h0[ks], l0[ks], det);
-        int ent[4], cn[4];                       // the tile's plan entries / ball counts, wave-uniform
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            ent[g] = __builtin_amdgcn_readlane(cur.ent, 8 * g);
-            cn[g] = __builtin_amdgcn_readlane(cur.cnt, 8 * g);
-        }
+        int ent[32 / GR], cn[32 / GR];           // the tile's plan entries / ball counts, wave-uniform
+        tile_entries<GR>(cur, ent, cn);
         RW_TICK(1)
 
         // ---- hidden layer 0
@@ -610,10 +621,8 @@ __device__ __forceinline__ void rs_body(const RwParams &P) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) ae[r] = 0.0f;
             rs_tile_mma<KS2, G, PR, NW, PPW, DEPTH, CPP, false>(P, X, stage, h2, l2, KT0 + KT1 + ct * KS2, ae);
-            float qm[4];
-            sa::granule_max(ae, qm);
             const int c = ct * 32 + (lane & 31);
-            sa::pool_write_tile(qm, ent, cn, b2[c], c, P.N3, P.out, P.out_stride, P.out_off, lane);
+            pool_tile<GR>(ae, ent, cn, b2[c], c, P, lane);
         }
         RW_TICK(4)
         // ---- the next tile's rows: issued here, converted at the top of the next iteration (the other wave of
@@ -626,32 +635,32 @@ __device__ __forceinline__ void rs_body(const RwParams &P) {
 #pragma unroll
             for (int ks = 0; ks < KS0; ++ks) load_group(P, cur, tl, 2 * ks + half, raw[ks]);
         }
-        nxt = row_ref_of(P, ent_f, row);
-        ent_f = load_plan_ent(P, ngran, tf + nwaves, row);
+        nxt = row_ref_of<GR>(P, ent_f, row);
+        ent_f = load_plan_ent<GR>(P, ngran, tf + nwaves, row);
         RW_TICK(5)
     }
     if (PR == 1) sa::f16_overflow_report(det, P.ovf, lane);
     RW_FLUSH(gw)
 }
-template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF, int DEPTH, int PR, int CPP, int PF>
+template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF, int DEPTH, int PR, int CPP, int PF, int GR>
 __global__ __launch_bounds__(NW * 64, WPE) void mlp_rs_kernel(RwParams P) {
-    rs_body<KS0, NT1, KS1, NT2, KS2, NT3, NW, WPE, TAILF, DEPTH, PR, CPP, PF>(P);
+    rs_body<KS0, NT1, KS1, NT2, KS2, NT3, NW, WPE, TAILF, DEPTH, PR, CPP, PF, GR>(P);
 }
 
 // ---- all scales of an SA layer in ONE launch: blockIdx.y picks the scale (its own parameters, its own shape).  The
 //      scales of a layer are independent (same inputs, disjoint output slices), a launch costs ~2 us of throughput and
 //      these kernels run one or two tiles per wave, so three launches of 14-40 us become one of the longest's length.
 struct RwMulti { RwParams p[3]; };
-template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF>
+template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF, int GR>
 struct RwBody {
     static constexpr size_t lds = (size_t)(NT1 * KS0 + NT2 * KS1 + NT3 * KS2) * 2048 + (size_t)(NT1 + NT2 + NT3) * 128;
-    static __device__ __forceinline__ void run(const RwParams &P) { rw_body<KS0, NT1, KS1, NT2, KS2, NT3, NW, WPE, TAILF>(P); }
+    static __device__ __forceinline__ void run(const RwParams &P) { rw_body<KS0, NT1, KS1, NT2, KS2, NT3, NW, WPE, TAILF, GR>(P); }
 };
-template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int DEPTH, int PR, int CPP, int PF>
+template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int DEPTH, int PR, int CPP, int PF, int GR>
 struct RsBody {
     static constexpr size_t lds = (size_t)2 * (PR == 3 ? 2 : 1) * ((NT1 * KS0 + NT2 * KS1 + NT3 * KS2) / CPP) * 1024 +
                                   (size_t)(NT1 + NT2 + NT3) * 128;
-    static __device__ __forceinline__ void run(const RwParams &P) { rs_body<KS0, NT1, KS1, NT2, KS2, NT3, NW, WPE, 0, DEPTH, PR, CPP, PF>(P); }
+    static __device__ __forceinline__ void run(const RwParams &P) { rs_body<KS0, NT1, KS1, NT2, KS2, NT3, NW, WPE, 0, DEPTH, PR, CPP, PF, GR>(P); }
 };
 template <class B0, class B1, class B2, int NW, int WPE>
 __global__ __launch_bounds__(NW * 64, WPE) void mlp_multi_kernel(RwMulti M) {
@@ -674,10 +683,10 @@ int num_cus() {
     return n;
 }
 
-template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF>
+template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF, int GR>
 int launch_rw(const RwParams &P, long max_tiles, int wgs_per_cu, hipStream_t stream) {
     constexpr size_t lds = (size_t)(NT1 * KS0 + NT2 * KS1 + NT3 * KS2) * 2048 + (size_t)(NT1 + NT2 + NT3) * 128;
-    auto kern = mlp_rw_kernel<KS0, NT1, KS1, NT2, KS2, NT3, NW, WPE, TAILF>;
+    auto kern = mlp_rw_kernel<KS0, NT1, KS1, NT2, KS2, NT3, NW, WPE, TAILF, GR>;
     if (lds > 48 * 1024) {
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipGetLastError();
@@ -690,11 +699,11 @@ int launch_rw(const RwParams &P, long max_tiles, int wgs_per_cu, hipStream_t str
     return SA_OK;
 }
 
-template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF, int DEPTH, int PR, int CPP, int PF>
+template <int KS0, int NT1, int KS1, int NT2, int KS2, int NT3, int NW, int WPE, int TAILF, int DEPTH, int PR, int CPP, int PF, int GR>
 int launch_rs(const RwParams &P, long max_tiles, int wgs_per_cu, hipStream_t stream) {
     constexpr int G = (NT1 * KS0 + NT2 * KS1 + NT3 * KS2) / CPP;
     constexpr size_t lds = (size_t)2 * (PR == 3 ? 2 : 1) * G * 1024 + (size_t)(NT1 + NT2 + NT3) * 128;
-    auto kern = mlp_rs_kernel<KS0, NT1, KS1, NT2, KS2, NT3, NW, WPE, TAILF, DEPTH, PR, CPP, PF>;
+    auto kern = mlp_rs_kernel<KS0, NT1, KS1, NT2, KS2, NT3, NW, WPE, TAILF, DEPTH, PR, CPP, PF, GR>;
     if (lds > 48 * 1024) {
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipGetLastError();
@@ -773,11 +782,12 @@ static bool rowwave_contiguous(const ScaleSig &S, const void *const *wpack, int 
 
 // The three scales of a layer in one launch (mlp_multi_kernel) for the layer shapes of 3dssd.yaml; 0 when the layer
 // is not one of them (the caller then launches scale by scale).
+// gr4: the plans hold 4-row granules (mlp_plan.h; all three scales alike).
 int sa_rowwave_try_layer(int b, int n, int m, const int *ns, int c, const float *xyz, const float *feat,
                          const float *new_xyz, const int *const *idx, const int *const *cnt, const int *dims,
                          const void *const *wpack, const float *const *bias, float *out, int out_stride,
                          const int *out_off, const int *const *plan_hdr, const int *const *plan_gran,
-                         const long *max_tiles, const int *fp16, int *overflow, hipStream_t stream, int *st) {
+                         const long *max_tiles, const int *fp16, int gr4, int *overflow, hipStream_t stream, int *st) {
     static const bool on = SA_KNOB("SA_MLP_MULTI", 1) != 0;
     static const bool stream_enabled = SA_KNOB("SA_MLP_ROWSTREAM", 1) != 0;
     if (!on) return 0;
@@ -788,47 +798,52 @@ int sa_rowwave_try_layer(int b, int n, int m, const int *ns, int c, const float 
         if (!rowwave_scale(b, n, m, ns[i], c, xyz, feat, new_xyz, idx[i], cnt[i], 3, dims + 4 * i, wpack + 3 * i,
                            bias + 3 * i, out, out_stride, out_off[i], plan_hdr[i], plan_gran[i], max_tiles[i], overflow, P[i], S[i]))
             return 0;
+        if (gr4 && ns[i] > 4 * sa::kPlanMaxOrd) return 0;
         mt[i] = max_tiles[i];
     }
     const bool all16 = fp16[0] && fp16[1] && fp16[2], none16 = !fp16[0] && !fp16[1] && !fp16[2];
     if (none16 && c == 1 && sig_is(S[0], 1, 1, 1, 1, 1, 1) && sig_is(S[1], 1, 1, 1, 1, 1, 1) && sig_is(S[2], 1, 1, 2, 1, 2, 2)) {
-        typedef RwBody<1, 1, 1, 1, 1, 1, 4, 4, 1> A;                    // layer1: 4 -> 16 -> 16 -> 32 (x2), 4 -> 32 -> 32 -> 64
-        typedef RwBody<1, 1, 2, 1, 2, 2, 4, 4, 1> Bq;
-        *st = launch_multi<A, A, Bq, 4, 4>(P, mt, 4, stream);
+        // layer1: 4 -> 16 -> 16 -> 32 (x2), 4 -> 32 -> 32 -> 64
+        if (gr4) *st = launch_multi<RwBody<1, 1, 1, 1, 1, 1, 4, 4, 1, 4>, RwBody<1, 1, 1, 1, 1, 1, 4, 4, 1, 4>, RwBody<1, 1, 2, 1, 2, 2, 4, 4, 1, 4>, 4, 4>(P, mt, 4, stream);
+        else *st = launch_multi<RwBody<1, 1, 1, 1, 1, 1, 4, 4, 1, 8>, RwBody<1, 1, 1, 1, 1, 1, 4, 4, 1, 8>, RwBody<1, 1, 2, 1, 2, 2, 4, 4, 1, 8>, 4, 4>(P, mt, 4, stream);
         return 1;
     }
     if (none16 && c != 1 && sig_is(S[0], 5, 2, 4, 2, 4, 4) && sig_is(S[1], 5, 2, 4, 2, 4, 4) && sig_is(S[2], 5, 2, 4, 3, 6, 4)) {
-        typedef RwBody<5, 2, 4, 2, 4, 4, 8, 2, 0> A;                    // layer2: 67 -> 64 -> 64 -> 128 (x2), 67 -> 64 -> 96 -> 128
-        typedef RwBody<5, 2, 4, 3, 6, 4, 8, 2, 0> Bq;
-        *st = launch_multi<A, A, Bq, 8, 2>(P, mt, 1, stream);
+        // layer2: 67 -> 64 -> 64 -> 128 (x2), 67 -> 64 -> 96 -> 128
+        if (gr4) *st = launch_multi<RwBody<5, 2, 4, 2, 4, 4, 8, 2, 0, 4>, RwBody<5, 2, 4, 2, 4, 4, 8, 2, 0, 4>, RwBody<5, 2, 4, 3, 6, 4, 8, 2, 0, 4>, 8, 2>(P, mt, 1, stream);
+        else *st = launch_multi<RwBody<5, 2, 4, 2, 4, 4, 8, 2, 0, 8>, RwBody<5, 2, 4, 2, 4, 4, 8, 2, 0, 8>, RwBody<5, 2, 4, 3, 6, 4, 8, 2, 0, 8>, 8, 2>(P, mt, 1, stream);
         return 1;
     }
     if (all16 && stream_enabled && c != 1 && sig_is(S[0], 9, 4, 8, 4, 8, 8) && sig_is(S[1], 9, 4, 8, 6, 12, 8) &&
         sig_is(S[2], 9, 4, 8, 8, 16, 8) && rowwave_contiguous(S[0], wpack, 1) && rowwave_contiguous(S[1], wpack + 3, 1) &&
         rowwave_contiguous(S[2], wpack + 6, 1)) {
-        typedef RsBody<9, 4, 8, 4, 8, 8, 8, 2, 2, 1, 12, 1> A;          // layer3, fp16
-        typedef RsBody<9, 4, 8, 6, 12, 8, 8, 2, 2, 1, 12, 1> Bq;
-        typedef RsBody<9, 4, 8, 8, 16, 8, 8, 2, 2, 1, 12, 1> Cq;
-        *st = launch_multi<A, Bq, Cq, 8, 2>(P, mt, 1, stream);
+        // layer3, fp16
+        if (gr4) *st = launch_multi<RsBody<9, 4, 8, 4, 8, 8, 8, 2, 2, 1, 12, 1, 4>, RsBody<9, 4, 8, 6, 12, 8, 8, 2, 2, 1, 12, 1, 4>, RsBody<9, 4, 8, 8, 16, 8, 8, 2, 2, 1, 12, 1, 4>, 8, 2>(P, mt, 1, stream);
+        else *st = launch_multi<RsBody<9, 4, 8, 4, 8, 8, 8, 2, 2, 1, 12, 1, 8>, RsBody<9, 4, 8, 6, 12, 8, 8, 2, 2, 1, 12, 1, 8>, RsBody<9, 4, 8, 8, 16, 8, 8, 2, 2, 1, 12, 1, 8>, 8, 2>(P, mt, 1, stream);
         return 1;
     }
     return 0;
 }
 
+// gr4: the plan holds 4-row granules.  dry: only say whether an instantiation would take the shape (nothing launched).
 int sa_rowwave_try(int b, int n, int m, int ns, int c, const float *xyz, const float *feat, const float *new_xyz,
                    const int *idx, const int *cnt, int nl, const int *dims, const void *const *wpack,
                    const float *const *bias, float *out, int out_stride, int out_off, const int *plan_hdr,
-                   const int *plan_gran, long max_tiles, int fp16, int *overflow, hipStream_t stream, int *st) {
+                   const int *plan_gran, long max_tiles, int fp16, int gr4, int dry, int *overflow, hipStream_t stream, int *st) {
     RwParams P;
     ScaleSig S;
     if (!rowwave_scale(b, n, m, ns, c, xyz, feat, new_xyz, idx, cnt, nl, dims, wpack, bias, out, out_stride, out_off,
                        plan_hdr, plan_gran, max_tiles, overflow, P, S))
         return 0;
+    if (gr4 && ns > 4 * sa::kPlanMaxOrd) return 0;
     const int KS0 = S.KS0, NT1 = S.NT1, KS1 = S.KS1, NT2 = S.NT2, KS2 = S.KS2, NT3 = S.NT3;
 #define SA_RW(K0, N1, K1, N2, K2, N3_, NW_, WPE_, WGS)                                              \
     if (!fp16 && KS0 == K0 && NT1 == N1 && KS1 == K1 && NT2 == N2 && KS2 == K2 && NT3 == N3_) {             \
-        *st = c == 1 ? launch_rw<K0, N1, K1, N2, K2, N3_, NW_, WPE_, 1>(P, max_tiles, WGS, stream)             \
-                     : launch_rw<K0, N1, K1, N2, K2, N3_, NW_, WPE_, 0>(P, max_tiles, WGS, stream);            \
+        if (dry) { *st = SA_OK; return 1; }                                                         \
+        if (gr4) *st = c == 1 ? launch_rw<K0, N1, K1, N2, K2, N3_, NW_, WPE_, 1, 4>(P, max_tiles, WGS, stream)   \
+                              : launch_rw<K0, N1, K1, N2, K2, N3_, NW_, WPE_, 0, 4>(P, max_tiles, WGS, stream);  \
+        else *st = c == 1 ? launch_rw<K0, N1, K1, N2, K2, N3_, NW_, WPE_, 1, 8>(P, max_tiles, WGS, stream)       \
+                          : launch_rw<K0, N1, K1, N2, K2, N3_, NW_, WPE_, 0, 8>(P, max_tiles, WGS, stream);      \
         return 1;                                                                                   \
     }
     SA_RW(1, 1, 1, 1, 1, 1, 4, 4, 4)      // 4 -> 16 -> 16 -> 32      (layer1 scales 0/1, configs[0])
@@ -842,7 +857,9 @@ int sa_rowwave_try(int b, int n, int m, int ns, int c, const float *xyz, const f
     static const bool stream_enabled = SA_KNOB("SA_MLP_ROWSTREAM", 1) != 0;
 #define SA_RS(K0, N1, K1, N2, K2, N3_, NW_, WPE_, WGS, D_, PR_, CPP_, PF_)                              \
     if (stream_enabled && contiguous && c != 1 && (PR_ == 1) == (fp16 != 0) && KS0 == K0 && NT1 == N1 && KS1 == K1 && NT2 == N2 && KS2 == K2 && NT3 == N3_) { \
-        *st = launch_rs<K0, N1, K1, N2, K2, N3_, NW_, WPE_, 0, D_, PR_, CPP_, PF_>(P, max_tiles, WGS, stream); \
+        if (dry) { *st = SA_OK; return 1; }                                                         \
+        *st = gr4 ? launch_rs<K0, N1, K1, N2, K2, N3_, NW_, WPE_, 0, D_, PR_, CPP_, PF_, 4>(P, max_tiles, WGS, stream) \
+                  : launch_rs<K0, N1, K1, N2, K2, N3_, NW_, WPE_, 0, D_, PR_, CPP_, PF_, 8>(P, max_tiles, WGS, stream); \
         return 1;                                                                                   \
     }
     // split bf16: 8 waves (2 per SIMD, 256 registers each), 1 workgroup per CU; staging depth as the register budget

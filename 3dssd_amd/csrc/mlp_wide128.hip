@@ -339,7 +339,7 @@ int r128_roundup(int x, int q) { return (x + q - 1) / q * q; }
 int sa_wide128_try(int b, int n, int m, int ns, int c, const float *xyz, const float *feat, const float *new_xyz,
                    const int *idx, const int *cnt, int nl, const int *dims, const void *const *wpack,
                    const float *const *bias, float *out, int out_stride, int out_off, const int *plan_hdr,
-                   const int *plan_gran, long max_tiles, int fp16, int force, int *overflow, hipStream_t stream, int *st) {
+                   const int *plan_gran, long max_tiles, int fp16, int force, int dry, int *overflow, hipStream_t stream, int *st) {
     if (!fp16 || nl != 3 || c < 8 || (c & 7) || !feat) return 0;
     if (dims[1] != 32 * kNW || (dims[2] & 31) || dims[2] > 512 || dims[2] < 128 || dims[3] < 32 * 2 * kNW || dims[3] > 2048) return 0;
     // measured on layer4 of 3dssd.yaml: 259-256-512-1024 96 -> 88 us against group_mlp_wide_kernel's 105; 259-256-256-512
@@ -362,6 +362,7 @@ int sa_wide128_try(int b, int n, int m, int ns, int c, const float *xyz, const f
     P.strideB = dims[1] * 2 + 16;
     const size_t lds = (size_t)kRows * (P.strideA + P.strideB);
     if (lds > 160 * 1024) return 0;
+    if (dry) { *st = SA_OK; return 1; }          // the shape would be taken (nothing launched)
     (void)hipFuncSetAttribute((const void *)group_mlp_wide128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipGetLastError();
     const long nitems = (max_tiles + kRT - 1) / kRT;

@@ -43,6 +43,7 @@ SIGNATURES = {
     "sa_group_mlp_max": [_c_int] * 5 + [_vp] * 5 + [_c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp,
                          ctypes.c_size_t, _c_int, _vp, _vp],
     "sa_group_mlp_plan": [_c_int] * 3 + [_vp, _vp, _vp, _vp, _c_int, _vp, _vp, _c_int, _vp],
+    "sa_group_mlp_plan2": [_c_int] * 3 + [_vp, _vp, _vp, _vp, _c_int, _vp, _vp, _c_int, _vp, _vp],
     "sa_dense": [_c_long, _c_int, _c_int, _vp, _vp, _vp, _c_int, _vp, _vp],
     "sa_decode_anchor_free": [_c_int] * 4 + [_vp] * 7,
     "sa_boxes_to_bev": [_c_long, _vp, _vp, _vp],
@@ -109,6 +110,8 @@ def lib():
         h.sa_group_mlp_gemm_ws_bytes.restype = ctypes.c_size_t
         h.sa_calc_square_dist_ws_bytes.argtypes = [_c_int] * 5
         h.sa_calc_square_dist_ws_bytes.restype = ctypes.c_size_t
+        h.sa_group_mlp_granule_rows.argtypes = [_c_int] * 6 + [_vp, _vp, ctypes.c_size_t, _c_int]   # returns 4 or 8
+        h.sa_group_mlp_granule_rows.restype = _c_int
         h.sa_ffps_fly_ws_bytes.argtypes = [_c_int] * 2
         h.sa_ffps_fly_ws_bytes.restype = ctypes.c_size_t
         h.sa_host_crc32c.argtypes = [_vp, ctypes.c_size_t, ctypes.c_uint32]          # host helper: returns the CRC

@@ -47,6 +47,7 @@ AGGREGATION_SA_FEATURE = True
 DFPS_SIDE_STREAM = 6
 PLAN_LOG = None     # set to a list to collect (b, m, nsample, MACs per row, plan tensor) of every fused-MLP call
 MLP_PLAN_FLAGS = 0  # sa_group_mlp_max flag bit 0 (all nsample rows instead of the distinct ones), A/B measurements
+MLP_GRANULE4 = True  # row plans in granules of 4 rows for the scales the row-wave kernels take (csrc/mlp_plan.h; flag bit 6); False: 8 rows everywhere (A/B)
 GRID_BALL_QUERY_MIN_N = 2048
 MLP_GEMM_CHAIN = False  # True: eligible fp16 scales (layer4) run as three large-tile GEMM launches (flags bit 4); measured slower
 MAX_TRANSLATE_RANGE = (-3.0, -2.0, -3.0)
@@ -461,10 +462,21 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
             offs.append(acc)
             acc += ls[-1].N
         have_plans = nscale <= 4
+        base_flags = [MLP_PLAN_FLAGS | (16 if MLP_GEMM_CHAIN else 0) | (2 if have_plans else 0) | W.scale_flags(ls) for ls in layers]
+        if have_plans and MLP_GRANULE4:
+            # granule size per scale: 4 rows where a row-wave kernel will take the scale (the library says which), else 8
+            for i, ls in enumerate(layers):
+                d_ = (ctypes.c_int * (len(ls) + 1))(*([c_feat + 3] + [l.N for l in ls]))
+                wp_ = (ctypes.c_void_p * len(ls))(*[l.w.data_ptr() for l in ls])
+                if lib.sa_group_mlp_granule_rows(bs, n_all, m, int(nsample_list[i]), c_feat, len(ls), d_, wp_, plans[i][1], base_flags[i]) == 4:
+                    base_flags[i] |= 64
+            if nscale == 3 and len({f & 64 for f in base_flags}) != 1:      # the one-launch layer kernels want one granule size
+                base_flags = [f & ~64 for f in base_flags]
         if have_plans:
-            st = lib.sa_group_mlp_plan(bs, m, nscale, nsa, cntp, (ctypes.c_void_p * nscale)(*[p[0].data_ptr() for p in plans]),
-                                       new_points_concat.data_ptr(), ctot, (ctypes.c_int * nscale)(*offs),
-                                       (ctypes.c_int * nscale)(*[ls[-1].N for ls in layers]), MLP_PLAN_FLAGS, stream)
+            st = lib.sa_group_mlp_plan2(bs, m, nscale, nsa, cntp, (ctypes.c_void_p * nscale)(*[p[0].data_ptr() for p in plans]),
+                                        new_points_concat.data_ptr(), ctot, (ctypes.c_int * nscale)(*offs),
+                                        (ctypes.c_int * nscale)(*[ls[-1].N for ls in layers]), MLP_PLAN_FLAGS,
+                                        (ctypes.c_int * nscale)(*base_flags), stream)
             N.check(st, "group_mlp_plan")
         # ---- the grouped MLPs of all scales: ONE C-ABI call per layer (one launch for the three-scale layers of the
         #      reference configuration: the scales are independent, every launch costs ~2 us of throughput)
@@ -483,7 +495,7 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
                 new_points_concat.data_ptr(), ctot, (ctypes.c_int * k)(*[offs[i] for i in live]),
                 (ctypes.c_void_p * k)(*[plans[i][0].data_ptr() for i in live]),
                 (ctypes.c_ulong * k)(*[plans[i][1] for i in live]),
-                (ctypes.c_int * k)(*[MLP_PLAN_FLAGS | (16 if MLP_GEMM_CHAIN else 0) | (2 if have_plans else 0) | W.scale_flags(layers[i]) for i in live]),
+                (ctypes.c_int * k)(*[base_flags[i] for i in live]),
                 vs.overflow.data_ptr(), stream)
             N.check(st, "group_mlp_max_layer")
         else:                                                               # scales of different depth: one by one
@@ -497,8 +509,7 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
                                           points.data_ptr(), new_xyz.data_ptr(), idx_list[i].data_ptr(),
                                           cnt_list[i].data_ptr(), nl, dims, wp, bp,
                                           new_points_concat.data_ptr(), ctot, offs[i], plans[i][0].data_ptr(), plans[i][1],
-                                          MLP_PLAN_FLAGS | (16 if MLP_GEMM_CHAIN else 0) | (2 if have_plans else 0) | W.scale_flags(ls),
-                                          vs.overflow.data_ptr(), stream)
+                                          base_flags[i], vs.overflow.data_ptr(), stream)
                 N.check(st, "group_mlp_max")
         if PLAN_LOG is not None:                                            # bench.py: rows evaluated per scale
             for i in live:

@@ -636,8 +636,8 @@ def overlap_probe(pipe, run, k):
 
 def mlp_row_stats(net, batches):
     """Rows of the grouped tensor per step: nominal (m x nsample, what the reference's conv2d evaluates), distinct
-    (sum of clamp(cnt, 1, ns)) and evaluated (8-row granules of the plan), from the plan headers of eager steps over
-    `batches` (mean per step)."""
+    (sum of clamp(cnt, 1, ns)) and evaluated (the plan's granules of 8 or 4 rows), from the plan headers of eager steps
+    over `batches` (mean per step)."""
     lu = pkg("utils.layers_util")
     nominal = distinct = evaluated = 0
     fl_nom = fl_eval = 0.0
@@ -650,9 +650,10 @@ def mlp_row_stats(net, batches):
             h = plan[:4].cpu().tolist()
             nominal += b * m * ns
             distinct += h[2]
-            evaluated += h[0] * 8
+            gr = h[3] or 8                                   # rows per granule of this plan (csrc/mlp_plan.h: 8 or 4)
+            evaluated += h[0] * gr
             fl_nom += 2.0 * b * m * ns * macs
-            fl_eval += 2.0 * h[0] * 8 * macs
+            fl_eval += 2.0 * h[0] * gr * macs
     k = max(len(batches), 1)
     return dict(nominal=nominal // k, distinct=distinct // k, evaluated=evaluated // k,
                 frames=int(batches[0].shape[0]) if len(batches) else 0,

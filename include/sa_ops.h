@@ -158,7 +158,8 @@ int sa_query_ball_point_grid(int b, int n, int m, int nbands, const float *rmin,
  * result bit for bit, a fraction of the work on KITTI-like clouds (3dssd_amd/csrc/mlp_plan.h).  ws: caller-owned
  * device scratch of sa_group_mlp_max_ws_bytes(b, m, ns) bytes (the per-call row plan: header, one entry per 8-row
  * granule of the densest plan, one summary per 4096 balls).  flags bit 0: evaluate all
- * nsample rows of every ball instead (A/B measurements); bit 1: the plan in ws was built by sa_group_mlp_plan;
+ * nsample rows of every ball instead (A/B measurements); bit 1: the plan in ws was built by sa_group_mlp_plan (bit 6
+ * with it: by sa_group_mlp_plan2 in 4-row granules);
  * bit 2: wpack[] holds single-plane fp16 fragments and the scale runs one fp16 MFMA pass per k-step (fp32
  * accumulate) instead of the three split-bf16 passes -- chosen per scale by the host (utils/weights.py).
  * bit 3 (8): keep the 64-row / streamed fused kernels where the 96-row kernel of csrc/mlp_wide128.hip would be taken
@@ -184,6 +185,18 @@ unsigned long sa_group_mlp_gemm_ws_bytes(int b, int m, int ns, int c, int nl, co
  * flags | 2 (plan already built). */
 int sa_group_mlp_plan(int b, int m, int nscale, const int *ns, const int *const *cnt, void *const *ws, float *out,
                       int out_stride, const int *out_off, const int *nout, int flags, sa_stream_t stream);
+/* The same with a granule size per scale: bit 6 (64) of scale_flags[i] builds scale i's plan in granules of FOUR rows
+ * instead of eight (half the padding on balls of 1-4 distinct rows: the inner bands of layer 1 / layer 2 on KITTI-like
+ * frames).  Only the row-wave kernels read such plans: ask sa_group_mlp_granule_rows() which scales they take, and pass
+ * the same bit 6 in that scale's flags to sa_group_mlp_max / sa_group_mlp_max_layer (a scale whose flags say "4 rows"
+ * but which no row-wave kernel can take returns -3).  scale_flags == NULL: eight rows everywhere (= sa_group_mlp_plan). */
+int sa_group_mlp_plan2(int b, int m, int nscale, const int *ns, const int *const *cnt, void *const *ws, float *out,
+                       int out_stride, const int *out_off, const int *nout, int flags, const int *scale_flags,
+                       sa_stream_t stream);
+/* 4 or 8: the granule size the plan of this scale should be built with (4 = a row-wave kernel of mlp_rowwave.hip will
+ * take it under these flags; nothing is launched).  wpack: the scale's packed layers; ws_bytes: its scratch size. */
+int sa_group_mlp_granule_rows(int b, int n, int m, int ns, int c, int nl, const int *dims, const void *const *wpack,
+                              unsigned long ws_bytes, int flags);
 int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float *xyz, const float *feat,
                      const float *new_xyz, const int *idx, const int *cnt, int nl, const int *dims,
                      const void *const *wpack, const float *const *bias, float *out, int out_stride,

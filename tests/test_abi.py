@@ -43,7 +43,7 @@ def test_extra_library_is_separate_and_complete():
 
 def test_ctypes_table_matches_header():
     native = pkg("utils._native")
-    non_status = ["sa_query_ball_point_grid_ws_bytes", "sa_calc_square_dist_ws_bytes", "sa_group_mlp_max_ws_bytes", "sa_group_mlp_gemm_ws_bytes", "sa_ffps_fly_ws_bytes", "sa_host_crc32c"]      # return a size / a checksum
+    non_status = ["sa_query_ball_point_grid_ws_bytes", "sa_calc_square_dist_ws_bytes", "sa_group_mlp_max_ws_bytes", "sa_group_mlp_gemm_ws_bytes", "sa_ffps_fly_ws_bytes", "sa_host_crc32c", "sa_group_mlp_granule_rows"]      # return a size / a checksum / a granule size
     assert sorted(list(native.SIGNATURES) + non_status) == sorted(_header_functions())
     native.lib()       # resolves every symbol and sets argtypes
 

@@ -223,3 +223,41 @@ def test_two_backbones_keep_their_own_settings(gpu):
         xs, fs, _ = e.value
     torch.cuda.synchronize()
     assert torch.equal(fs[-1], fa[-1]) and torch.equal(xs[-1], xa[-1])
+
+
+@pytest.mark.parametrize("variant", ["default", "rings64", "dense"])
+def test_four_row_granules_change_the_rows_evaluated_not_the_results(gpu, variant):
+    # round 5 (csrc/mlp_plan.h): the row plans of the scales the row-wave kernels take are built in granules of 4 rows
+    # (layers_util.MLP_GRANULE4).  The maximum over a ball's distinct rows does not depend on how they are packed into
+    # tiles: every output of the backbone must be BIT-identical to the 8-row form, on sparse, ring-structured and
+    # all-balls-full frames (split balls of more than 32 rows included), while the evaluated rows drop.
+    cfgs, syn = pkg("configs"), pkg("synthetic")
+    lu, B = pkg("utils.layers_util"), pkg("backbone")
+    arch = cfgs.KITTI_3DSSD_ARCH
+    net = B.SABackbone(arch, syn.random_backbone_params(arch), gpu, cfgs.KITTI_MAX_TRANSLATE_RANGE)
+    pts = torch.from_numpy(np.stack([syn.frame_of(variant, f, 16384) for f in range(3)])).to(gpu)
+
+    def run(flag):
+        lu.MLP_GRANULE4, lu.PLAN_LOG = flag, []
+        try:
+            xl, fl, il = net(pts)
+            torch.cuda.synchronize()
+            hdrs = [p[4][:4].cpu().tolist() for p in lu.PLAN_LOG]
+        finally:
+            lu.MLP_GRANULE4, lu.PLAN_LOG = True, None
+        return [t.clone() for t in fl], [None if t is None else t.clone() for t in il], hdrs
+
+    f8, i8, h8 = run(False)
+    f4, i4, h4 = run(True)
+    assert all(h[3] == 8 for h in h8)
+    assert [h[3] for h in h4] == [4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 8]      # layer1-3 x 3 scales, layer4 scale 0; the 96-row kernel keeps 8
+    for a, b in zip(i8, i4):
+        assert (a is None and b is None) or torch.equal(a, b)
+    for a, b in zip(f8, f4):
+        assert torch.equal(a, b)
+    rows8 = sum(h[0] * h[3] for h in h8)
+    rows4 = sum(h[0] * h[3] for h in h4)
+    distinct = sum(h[2] for h in h4)
+    assert distinct == sum(h[2] for h in h8) and distinct <= rows4 <= rows8
+    if variant == "default":
+        assert rows4 < 0.72 * rows8                                     # 1.0-1.7 points per ball in the inner bands: padding halves
