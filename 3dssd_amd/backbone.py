@@ -11,19 +11,22 @@ from .utils.weights import VariableStore
 
 class SABackbone:
     def __init__(self, arch, params, device="cuda:0", max_translate_range=(-3.0, -2.0, -3.0),
-                 aggregation_sa_feature=True, precision=None, dfps_side_stream=None, ffps_fly=None):
+                 aggregation_sa_feature=True, precision=None, dfps_side_stream=None, ffps_fly=None, coop_capture=False):
         """precision: None = per-scale rule of utils/weights.py (fp16 one-pass on the wide scales, split bf16 elsewhere),
         "bf16x3" = split bf16 everywhere (~1e-5 of fp32, no range limit), "fp16" = one pass wherever the weights fit.
         dfps_side_stream: where the F-FPS || D-FPS launch of an 'FS' layer is issued (layers_util.DFPS_SIDE_STREAM; None =
         its default 6, a helper-stream branch; 5 = on the issuing stream, which keeps a captured graph linear).
         ffps_fly: F-FPS without the distance matrix where the shape allows it (layers_util.FFPS_FLY; csrc/ffps_fly.hip --
-        all calls of a process on one stream at a time)."""
+        all calls of a process on one stream at a time: direct single-stream callers only).
+        coop_capture: frames of more than 16384 points may launch their multi-workgroup layer-1 sampler plainly under
+        hipGraph capture (sa_fps_ex3 flag bit 0) -- only for a caller that keeps those launches on ONE stream (the staged
+        executor sets it for its own network); default: a capture takes the single-workgroup kernels."""
         self.device = torch.device(device)
         self.variables = params if isinstance(params, VariableStore) else VariableStore(params, self.device, precision)
         # per instance (round 3 wrote them into layers_util's module attributes: two backbones shared the last value)
         self.settings = {"aggregation_sa_feature": bool(aggregation_sa_feature),
                          "max_translate_range": tuple(float(v) for v in max_translate_range),
-                         "dfps_side_stream": dfps_side_stream, "ffps_fly": ffps_fly}
+                         "dfps_side_stream": dfps_side_stream, "ffps_fly": ffps_fly, "coop_capture": bool(coop_capture)}
         self.layers = [LayerBuilder(i, False, arch, variables=self.variables, settings=self.settings)
                        for i in range(len(arch))]
 

@@ -37,7 +37,8 @@ class LayerBuilder:
         vote_ctr = xyz_list[self.vote_ctr_index] if self.vote_ctr_index != -1 else None
         return sample_layer(xyz_list[self.xyz_index[0]], feature_list[self.feature_index[0]], self.fps_sample_range_list,
                             self.fps_method_list, self.npoint_list, former_fps_idx, vote_ctr, self.radius_list,
-                            self.settings.get("dfps_side_stream"), self.settings.get("ffps_fly"))
+                            self.settings.get("dfps_side_stream"), self.settings.get("ffps_fly"),
+                            bool(self.settings.get("coop_capture")))
 
     def build_layer(self, xyz_list, feature_list, fps_idx_list, bn_decay=None, output_dict=None, presampled=None):
         xyz_input = [xyz_list[i] for i in self.xyz_index]
@@ -52,7 +53,7 @@ class LayerBuilder:
                 self.scope, self.dilated_group, vote_ctr, self.aggregation_channel,
                 variables=self.variables, aggregation_sa_feature=self.settings.get("aggregation_sa_feature"),
                 presampled=presampled, dfps_side_stream=self.settings.get("dfps_side_stream"),
-                ffps_fly=self.settings.get("ffps_fly"))
+                ffps_fly=self.settings.get("ffps_fly"), coop_capture=bool(self.settings.get("coop_capture")))
             xyz_list.append(new_xyz)
             feature_list.append(new_points)
             fps_idx_list.append(new_fps_idx)

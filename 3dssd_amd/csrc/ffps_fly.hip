@@ -14,7 +14,7 @@
 // over channels ascending from 0 as the oracle's / csrc/sqdist.hip's -- bit-identical rows).  The arg-max goes
 // wave -> workgroup (LDS, one barrier) -> frame: every workgroup publishes {max | pick | tie key} and the squared
 // norm of its candidate in two 8-byte words (agent-scope atomic stores) and polls its partners' words (agent-scope
-// atomic loads; bounded, traps instead of hanging); the winner's row is then read from the (static) input.
+// atomic loads; bounded: a workgroup that gives up raises the sticky error word of sa_common.h and returns); the winner's row is then read from the (static) input.
 //
 // Semantics = farthest_point_sample_with_distance on that matrix, exactly: thread t of the reference owns
 // k = t, t + 1024, ... and keeps its first strict maximum, lower lane / wave wins a tie, i.e. ties go to the lowest
@@ -46,6 +46,7 @@ struct FlyArgs {
     int *out; int out_stride, idx_off;
     float *ctr; long ctr_bs;               // picked xyz rows [b, ., 3] (or null)
     int n, m, gshift;
+    int *err_word;                         // sticky error word (sa_common.h), may be null
 };
 
 template <int C1>
@@ -154,7 +155,10 @@ __global__ __launch_bounds__(kT) void ffps_fly_kernel(FlyArgs A) {
             wv = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const bool okw = ((((unsigned)wv) >> 16) & 0xFFFFu) == (unsigned)it;
             if (__ballot(okw || lane >= nw) == ~0ull) break;
-            if (++spins > kMaxSpin) __builtin_trap();      // partners lost: abort loudly instead of hanging
+            if (++spins > kMaxSpin) {                      // partners lost: sticky error word + leave (sa_common.h)
+                sa::coop_raise(A.err_word, sa::kCoopErrFfps);
+                return;
+            }
             __builtin_amdgcn_s_sleep(1);
         }
         const bool isval = lane < nw && (lane & 1) == 0;   // even lanes: {max | pick | key}, odd: {|candidate|^2 | pick}
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(kT) void ffps_fly_kernel(FlyArgs A) {
     }
 }
 
-int g_cap64 = 0;   // resident workgroups of ffps_fly_kernel<64> (0 = not yet queried, < 0 = unusable)
+int g_cap64 = 0;   // resident workgroups of ffps_fly_kernel<64> (0 = not yet queried, < 0 = unusable); atomic accesses
 
 }  // namespace
 
@@ -199,18 +203,22 @@ extern "C" int sa_ffps_fly_ex(int b, int n, int c1, int m, const float *xyz, lon
     int gshift = 0;
     while ((kPW << gshift) < n) ++gshift;
     const int G = 1 << gshift;
-    if (g_cap64 == 0) {
+    int *err_word = sa::coop_error_word();
+    if (err_word && __atomic_load_n(err_word, __ATOMIC_RELAXED) != 0) return SA_ERR_PARTNERS;   // sticky: an earlier launch lost partners
+    int cap = __atomic_load_n(&g_cap64, __ATOMIC_ACQUIRE);
+    if (cap == 0) {                                         // first use (two threads may both query: same answer)
         int dev = 0, cus = 0, per_cu = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)ffps_fly_kernel<64>, kT, 0) != hipSuccess)
-            g_cap64 = -1;
+            cap = -1;
         else
-            g_cap64 = cus * per_cu > 0 ? cus * per_cu : -1;
+            cap = cus * per_cu > 0 ? cus * per_cu : -1;
         (void)hipGetLastError();
+        __atomic_store_n(&g_cap64, cap, __ATOMIC_RELEASE);
     }
-    if (g_cap64 < G) return SA_ERR_UNSUPPORTED;
-    const int per_launch = g_cap64 / G;
+    if (cap < G) return SA_ERR_UNSUPPORTED;
+    const int per_launch = cap / G;
     if (hipMemsetAsync(workspace, 0, sa_ffps_fly_ws_bytes(b, n), stream) != hipSuccess) return SA_ERR_LAUNCH;
     for (int f0 = 0; f0 < b; f0 += per_launch) {
         const int nf = b - f0 < per_launch ? b - f0 : per_launch;
@@ -223,6 +231,7 @@ extern "C" int sa_ffps_fly_ex(int b, int n, int c1, int m, const float *xyz, lon
         A.out = out + (size_t)f0 * out_stride; A.out_stride = out_stride; A.idx_off = idx_off;
         A.ctr = ctr ? ctr + (size_t)f0 * ctr_bstride : nullptr; A.ctr_bs = ctr_bstride;
         A.n = n; A.m = m; A.gshift = gshift;
+        A.err_word = err_word;
         hipLaunchKernelGGL(ffps_fly_kernel<64>, dim3(nf * G), dim3(kT), 0, stream, A);
         SA_CHECK_LAUNCH();
     }

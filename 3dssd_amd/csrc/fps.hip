@@ -444,14 +444,16 @@ extern "C" int sa_fps_bucket_ex2(int b, int n, int m, const float *inp, long in_
                                  int idx_off, float *ctr, long ctr_bstride, hipStream_t stream);
 
 extern "C" int sa_fps_coop_ex(int b, int n, int c, int m, const float *inp, float *temp, int *out, int out_stride,
-                              int idx_off, hipStream_t stream);
+                              int idx_off, int capture_ok, hipStream_t stream);
 
 // in_bstride: elements between frames of inp (0 = dense n*c); ctr / ctr_bstride: when ctr is non-null the picked rows
 // (c == 3) are also written to ctr + frame * ctr_bstride + 3 * i -- the gather_point of layers_util.py:116-119.
 // Both extras need the register-resident c == 3 kernels (n <= 16384): SA_ERR_UNSUPPORTED otherwise, the caller then
 // slices / gathers with separate launches.
-extern "C" int sa_fps_ex2(int b, int n, int c, int m, const float *inp, long in_bstride, float *temp, int *out,
-                          int out_stride, int idx_off, float *ctr, long ctr_bstride, hipStream_t stream) {
+// flags bit 0: the caller keeps every multi-workgroup sampler launch of the process on ONE stream, so on a capturing
+// stream that kernel may be launched plainly (fps_coop.hip); without it a capture takes the single-workgroup kernels.
+extern "C" int sa_fps_ex3(int b, int n, int c, int m, const float *inp, long in_bstride, float *temp, int *out,
+                          int out_stride, int idx_off, float *ctr, long ctr_bstride, int flags, hipStream_t stream) {
     if (b <= 0 || n <= 0 || c <= 0 || m <= 0 || !inp || !out || out_stride < m) return SA_ERR_INVALID;
     const bool extras = (in_bstride != 0 && in_bstride != (long)n * c) || ctr != nullptr;
     // Layer-1 shape: the wave-bucket culled kernel (fps_bucket.hip), bit-identical output, ~1.4x faster than the
@@ -472,7 +474,7 @@ extern "C" int sa_fps_ex2(int b, int n, int c, int m, const float *inp, long in_
         if (extras) return SA_ERR_UNSUPPORTED;
         if (!temp) return SA_ERR_INVALID;
         // frames too large for one CU's registers/LDS: several cooperating workgroups per frame (fps_coop.hip)
-        const int rc = sa_fps_coop_ex(b, n, c, m, inp, temp, out, out_stride, idx_off, stream);
+        const int rc = sa_fps_coop_ex(b, n, c, m, inp, temp, out, out_stride, idx_off, flags & 1, stream);
         if (rc != SA_ERR_UNSUPPORTED) return rc;
         if (!launch_points_tiled(b, n, c, m, inp, temp, out, out_stride, idx_off, stream))
             hipLaunchKernelGGL(fps_generic_kernel<0>, dim3(b), dim3(kBlock), 0, stream, n, c, m, inp, temp,
@@ -482,9 +484,14 @@ extern "C" int sa_fps_ex2(int b, int n, int c, int m, const float *inp, long in_
     return SA_OK;
 }
 
+extern "C" int sa_fps_ex2(int b, int n, int c, int m, const float *inp, long in_bstride, float *temp, int *out,
+                          int out_stride, int idx_off, float *ctr, long ctr_bstride, hipStream_t stream) {
+    return sa_fps_ex3(b, n, c, m, inp, in_bstride, temp, out, out_stride, idx_off, ctr, ctr_bstride, 0, stream);
+}
+
 extern "C" int sa_fps_ex(int b, int n, int c, int m, const float *inp, float *temp, int *out,
                          int out_stride, int idx_off, hipStream_t stream) {
-    return sa_fps_ex2(b, n, c, m, inp, 0, temp, out, out_stride, idx_off, nullptr, 0, stream);
+    return sa_fps_ex3(b, n, c, m, inp, 0, temp, out, out_stride, idx_off, nullptr, 0, 0, stream);
 }
 
 extern "C" int sa_fps_bucket_ex(int b, int n, int m, const float *inp, int *out, int out_stride, int idx_off,

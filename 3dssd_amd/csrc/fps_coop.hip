@@ -19,7 +19,11 @@
 // eight XCDs, each XCD places its workgroups in its own order, and with two such grids interleaved by the dispatcher
 // XCD 0 can fill up with halves of grid X whose partners queue on XCD 1 behind halves of grid Y whose partners queue
 // on XCD 0 behind X.  One grid at a time cannot do that (the oldest incomplete frame is first in every queue).  The
-// poll is bounded and traps, so a violated assumption aborts the process instead of hanging the device.
+// plain launch under capture is therefore OPT-IN (capture_ok: the caller states that it keeps such launches on one
+// stream -- the staged executor does); without it a capturing stream gets SA_ERR_UNSUPPORTED and the caller's
+// single-workgroup kernels, which are safe on any number of streams.  The poll is bounded; a workgroup whose bound runs
+// out raises the sticky error word (sa_common.h coop_raise) and returns instead of trapping the process: the launch ends,
+// the frame's picks are garbage, and the next call -- or sa_coop_error_state() -- returns SA_ERR_PARTNERS.
 // Tried and dropped (measured, MI355X): keeping the G partners of a frame on one XCD (ids of one residue class mod 8,
 // verified in-kernel through HW_REG_XCC_ID) and exchanging the slots through that XCD's L2 instead of the
 // device-coherent sc1 path.  A plain / sc0 store is not seen by an sc0 load outside threadgroup-split mode (poll
@@ -48,7 +52,7 @@ constexpr unsigned kMaxSpin = 1u << 22;
 template <int C, int P>
 __global__ __launch_bounds__(kBlock) void fps_coop_kernel(int n, int m, int gshift, const float *__restrict__ inp,
                                                           unsigned long long *slots, int *__restrict__ out,
-                                                          int out_stride, int idx_off) {
+                                                          int out_stride, int idx_off, int *err_word, unsigned max_spin) {
     __shared__ float s_val[2][kWaves];
     __shared__ unsigned s_key[2][kWaves];
     const int G = 1 << gshift;
@@ -124,7 +128,10 @@ __global__ __launch_bounds__(kBlock) void fps_coop_kernel(int n, int m, int gshi
             wv = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const bool ok = (((unsigned)wv >> 16) & 0xFFFFu) == (unsigned)it;
             if (__ballot(ok) == ~0ull) break;
-            if (++spins > kMaxSpin) __builtin_trap();  // partners lost: abort loudly instead of hanging
+            if (++spins > max_spin) {                  // partners lost: sticky error + leave (every wave of the frame's
+                sa::coop_raise(err_word, sa::kCoopErrFps);   // workgroups runs into the same bound; a finished wave
+                return;                                //  no longer counts at the workgroup barrier)
+            }
             __builtin_amdgcn_s_sleep(1);
         }
         const float gv = __uint_as_float((unsigned)(wv >> 32));
@@ -151,10 +158,15 @@ Variant g_variants[] = {
 // Returns SA_OK when the cooperative kernel was launched for all b frames; SA_ERR_UNSUPPORTED when this shape /
 // stream state is not served (the caller then uses the single-workgroup kernels).  `temp` ([b,n] floats, the
 // reference's scratch, tf_sampling.cpp:149-155) holds the slots.
-extern "C" int sa_fps_coop_ex(int b, int n, int c, int m, const float *inp, float *temp, int *out, int out_stride,
-                              int idx_off, hipStream_t stream) {
+// capture_ok: on a CAPTURING stream launch plainly (the caller keeps every such launch of the process on one stream);
+// 0: a capturing stream gets SA_ERR_UNSUPPORTED.  orphan (tests only): launch one workgroup short, so that the last
+// frame's partners wait in vain; max_spin: the poll bound (0 = the default).
+static int fps_coop_launch(int b, int n, int c, int m, const float *inp, float *temp, int *out, int out_stride,
+                           int idx_off, int capture_ok, int orphan, unsigned max_spin, hipStream_t stream) {
     static const int enabled = SA_KNOB("SA_FPS_COOP", 1);
     if (!enabled || !temp || ((uintptr_t)temp & 7) || m > 65535 || n <= kBlock) return SA_ERR_UNSUPPORTED;
+    int *err_word = sa::coop_error_word();
+    if (err_word && __atomic_load_n(err_word, __ATOMIC_RELAXED) != 0) return SA_ERR_PARTNERS;   // sticky: an earlier launch lost partners
     Variant *v = nullptr;
     for (auto &cand : g_variants)
         if (cand.c == c) v = &cand;
@@ -169,20 +181,24 @@ extern "C" int sa_fps_coop_ex(int b, int n, int c, int m, const float *inp, floa
         (void)hipGetLastError();
         return SA_ERR_UNSUPPORTED;
     }
-    const bool capturing = cs != hipStreamCaptureStatusNone;   // -> plain launches (header comment)
-    if (v->cap == 0) {
+    const bool capturing = cs != hipStreamCaptureStatusNone;   // -> plain launches (header comment), opt-in
+    if (capturing && !capture_ok) return SA_ERR_UNSUPPORTED;
+    int cap = __atomic_load_n(&v->cap, __ATOMIC_ACQUIRE);
+    if (cap == 0) {                                     // first use (two threads may both query: same answer)
         int dev = 0, cus = 0, per_cu = 0, coop = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
             hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess || !coop ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, v->fn, kBlock, 0) != hipSuccess)
-            v->cap = -1;
+            cap = -1;
         else
-            v->cap = cus * per_cu > 0 ? cus * per_cu : -1;
+            cap = cus * per_cu > 0 ? cus * per_cu : -1;
         (void)hipGetLastError();
+        __atomic_store_n(&v->cap, cap, __ATOMIC_RELEASE);
     }
-    if (v->cap < G) return SA_ERR_UNSUPPORTED;
-    const int per_launch = v->cap / G;                  // frames per cooperative launch
+    if (cap < G) return SA_ERR_UNSUPPORTED;
+    const int per_launch = cap / G;                     // frames per cooperative launch
+    if (max_spin == 0) max_spin = kMaxSpin;
     // every frame of the call has its OWN slots (2 G words), zeroed by one memset in front of the first launch: the
     // consecutive launches of a large batch share nothing, so nothing depends on how a memset between two of them is
     // ordered (a shared region re-zeroed between the launches gave wrong picks in frames of the SECOND launch when the
@@ -194,15 +210,29 @@ extern "C" int sa_fps_coop_ex(int b, int n, int c, int m, const float *inp, floa
         unsigned long long *slots = slots0 + (size_t)f0 * 2 * G;
         const float *inp_f = inp + (size_t)f0 * n * c;
         int *out_f = out + (size_t)f0 * out_stride;
-        void *args[] = {&n, &m, &gshift, &inp_f, &slots, &out_f, &out_stride, &idx_off};
+        void *args[] = {&n, &m, &gshift, &inp_f, &slots, &out_f, &out_stride, &idx_off, &err_word, &max_spin};
         static const int plain_knob = SA_KNOB("SA_FPS_COOP_PLAIN", 0);
-        const bool plain = capturing || plain_knob;
-        const hipError_t le = plain ? hipLaunchKernel(v->fn, dim3(nf * G), dim3(kBlock), args, 0, stream)
-                                    : hipLaunchCooperativeKernel(v->fn, dim3(nf * G), dim3(kBlock), args, 0, stream);
+        const bool plain = capturing || plain_knob || orphan;
+        const int blocks = nf * G - ((orphan && f0 + nf >= b) ? 1 : 0);
+        const hipError_t le = plain ? hipLaunchKernel(v->fn, dim3(blocks), dim3(kBlock), args, 0, stream)
+                                    : hipLaunchCooperativeKernel(v->fn, dim3(blocks), dim3(kBlock), args, 0, stream);
         if (le != hipSuccess) {
             (void)hipGetLastError();
             return f0 == 0 ? SA_ERR_UNSUPPORTED : SA_ERR_LAUNCH;
         }
     }
     return SA_OK;
+}
+
+extern "C" int sa_fps_coop_ex(int b, int n, int c, int m, const float *inp, float *temp, int *out, int out_stride,
+                              int idx_off, int capture_ok, hipStream_t stream) {
+    return fps_coop_launch(b, n, c, m, inp, temp, out, out_stride, idx_off, capture_ok, 0, 0u, stream);
+}
+
+// TEST HOOK (tests/test_ops_gpu.py): the same launch with the last workgroup missing and a short poll bound, so that
+// the partners of the last frame give up -- the sticky error word must then be raised and the process must live.
+extern "C" int sa_debug_fps_coop_orphan(int b, int n, int c, int m, const float *inp, float *temp, int *out,
+                                        unsigned max_spin, hipStream_t stream) {
+    if (b <= 0 || n <= 0 || c <= 0 || m <= 0 || !inp || !temp || !out) return SA_ERR_INVALID;
+    return fps_coop_launch(b, n, c, m, inp, temp, out, m, 0, 0, 1, max_spin ? max_spin : 20000u, stream);
 }

@@ -1,8 +1,42 @@
 // Host-side helpers of the C ABI (no device code).
+//   sa::coop_error_word / sa_coop_error_state: the sticky error word of the multi-workgroup samplers (sa_common.h).
 //   sa_host_crc32c: CRC-32C (Castagnoli, reflected 0x82F63B78) as TensorFlow's tensor-bundle checkpoints use it for
 //   block and tensor checksums (3dssd_amd/utils/tf_checkpoint.py verifies multi-megabyte tensors through this).
 #include <stddef.h>
 #include <stdint.h>
+
+#include <mutex>
+
+#include "sa_common.h"
+
+namespace sa {
+int *coop_error_word() {
+    static int *word = nullptr;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void *p = nullptr;
+        // pinned + mapped: the device stores into it directly, the host reads it without a synchronisation
+        if (hipHostMalloc(&p, 64, hipHostMallocMapped) == hipSuccess && p) {
+            word = (int *)p;
+            *word = 0;
+        } else {
+            (void)hipGetLastError();
+        }
+    });
+    return word;
+}
+}  // namespace sa
+
+// The sticky word: 0 = fine; bit 0 = a multi-workgroup D-FPS (fps_coop.hip), bit 1 = an on-the-fly F-FPS (ffps_fly.hip)
+// gave up waiting for partner workgroups in some earlier launch -- the outputs of that launch are invalid.  reset != 0
+// clears it after reading.  (No synchronisation: a launch still in flight may raise it later.)
+extern "C" int sa_coop_error_state(int reset) {
+    int *w = sa::coop_error_word();
+    if (!w) return 0;
+    const int v = __atomic_load_n(w, __ATOMIC_RELAXED);
+    if (reset) __atomic_store_n(w, 0, __ATOMIC_RELAXED);
+    return v;
+}
 
 namespace {
 struct Crc32cTables {

@@ -1604,11 +1604,10 @@ extern "C" int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float 
     const long max_tiles = (gmax + 3) / 4;
     if (max_tiles > 0x0FFFFFFFl) return SA_ERR_UNSUPPORTED;
     int *hdr = (int *)ws, *gran = hdr + sa::kPlanHeaderInts;
-    // granule size: a plan built by the caller (flags bit 1) has the size its flags say (bit 6 = 4 rows); the plan of this
-    // call is built for the kernel that will take the scale.  SA_MLP_GR4 = 0 (tuning build): 8-row granules everywhere.
-    static const int gr4_knob = SA_KNOB("SA_MLP_GR4", 1);
-    const bool gr4 = (flags & 2) ? (flags & 64) != 0
-                                 : (gr4_knob != 0 && scale_takes_rowwave(b, n, m, ns, c, nl, dims, wpack, ws_bytes, flags));
+    // granule size: flags bit 6 = 4-row granules (opt-in: mlp_plan.h; only the row-wave kernels read such plans), for a
+    // plan built by the caller (flags bit 1) and for the plan of this call alike
+    const bool gr4 = (flags & 64) != 0;
+    if (gr4 && !(flags & 2) && !scale_takes_rowwave(b, n, m, ns, c, nl, dims, wpack, ws_bytes, flags & ~64)) return SA_ERR_UNSUPPORTED;
     // ---- the row plan of this call (unless sa_group_mlp_plan built the plans of the whole layer already)
     if (!(flags & 2)) {
         PlanJobs J{};

@@ -7,6 +7,7 @@
 #define SA_ERR_INVALID (-1)   // bad shape / attribute (the reference's OP_REQUIRES checks)
 #define SA_ERR_LAUNCH (-2)    // hipGetLastError() after a launch
 #define SA_ERR_UNSUPPORTED (-3)
+#define SA_ERR_PARTNERS (-4)  // a multi-workgroup sampler gave up waiting for its partner workgroups (sticky: sa_coop_error_state)
 
 #define SA_CHECK_LAUNCH()                                  \
     do {                                                   \
@@ -26,6 +27,18 @@
 #endif
 
 namespace sa {
+
+// ---- sticky error word of the multi-workgroup samplers (fps_coop.hip, ffps_fly.hip; defined in hostutil.hip) ----------
+// Their partner workgroups exchange words through memory and poll, which is only safe while all of them are resident.
+// A workgroup whose bounded poll runs out no longer traps (that killed the process): it raises this word -- one int in
+// pinned, device-visible host memory -- with a system-scope store and returns; everything that depends on it times out
+// the same way within a few hundred ms, the launch completes with garbage in the affected frames, and the NEXT call
+// of such a sampler (or sa_coop_error_state) reports SA_ERR_PARTNERS.  nullptr when the word could not be allocated.
+int *coop_error_word();
+constexpr int kCoopErrFps = 1, kCoopErrFfps = 2;
+__device__ __forceinline__ void coop_raise(int *word, int code) {
+    if (word) __hip_atomic_fetch_or(word, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // ---- DPP cross-lane moves (wave64, gfx9 encodings) ---------------------------------------
 // quad_perm(1,0,3,2)=0xB1  quad_perm(2,3,0,1)=0x4E  row_half_mirror=0x141  row_mirror=0x140

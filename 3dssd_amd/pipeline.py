@@ -12,8 +12,8 @@ pass (frames never interact: every kernel indexes its frame only).  Two ways to 
       hipGraphs: stage A = input split + layer-1 D-FPS + centres (SABackbone.forward_staged up to its yield) on the
       sampler stream S; stage B = everything else on one of two main streams M0 / M1, behind an event.  S runs
       stage A of package k+1 / k+2 while M0 / M1 run stage B of packages k / k+1.  The captured graphs are linear
-      chains (no helper-stream branch), so the executor needs exactly 3 hardware queues: ROCm's DEFAULT of 4 is
-      enough, no environment variable.  Measured (profiles/r04_sweep_queues.txt): the same throughput on 4, 8 and 16
+      chains (no helper-stream branch), so with the default one sampler + two main streams the executor needs 3
+      hardware queues: ROCm's DEFAULT of 4 is enough, no environment variable.  Measured (profiles/r04_sweep_queues.txt): the same throughput on 4, 8 and 16
       queues, and at least that of the 16-slot mode in the short and in the long run.
   mode="slots"  `streams` slots, each a HIP stream with one captured hipGraph of the whole backbone (rounds 2-3).
       Needs as many hardware queues as slots (`request_hw_queues(16)` BEFORE the HIP runtime starts), and collapses
@@ -114,6 +114,10 @@ class Ticket:
         self.wait()
         r = self._round
         pipe = r.slot.pipe
+        if N.lib().sa_coop_error_state(0) != 0:
+            raise RuntimeError("SA backbone: a multi-workgroup sampler launch gave up waiting for its partner workgroups "
+                               "(csrc/fps_coop.hip / ffps_fly.hip: such launches must stay on one stream) -- the results of "
+                               "the packages in flight are invalid; sa_coop_error_state(1) clears the sticky word")
         if pipe.check_overflow and int(pipe._flags[r.flag]) != 0:
             # fp16 scales guard their operand range (csrc/mlp_act.h): this round's own word, already on the host
             raise FloatingPointError(
@@ -174,9 +178,20 @@ class SAPipeline:
         self.n_main = max(1, int(main_streams))
         # frames above 16384 points: their multi-workgroup sampler must stay on ONE stream (csrc/fps_coop.hip)
         self.n_samp = 1 if int(points) > 16384 else max(1, int(sampler_streams))
+        # a caller's network: its multi-workgroup samplers (csrc/fps_coop.hip beyond 16384 points, csrc/ffps_fly.hip)
+        # spin on partner workgroups and must never be in flight on two streams -- the layer-2 sampler runs on the
+        # alternating main streams here, so a network built with ffps_fly is refused; the layer-1 sampler of large frames
+        # runs on the ONE sampler stream of mode="staged" only
+        if net is not None:
+            T.require(not net.settings.get("ffps_fly"),
+                      "SAPipeline cannot run a network built with ffps_fly=True: the on-the-fly F-FPS needs all its launches "
+                      "on one stream, the executor alternates that layer between streams (use the default matrix sampler)")
+            T.require(not net.settings.get("coop_capture") or (mode == "staged" and int(points) > 16384),
+                      "coop_capture is the staged executor's own setting for frames of more than 16384 points")
         self.net = net if net is not None else SABackbone(arch, params, self.device, max_translate_range,
                                                            aggregation_sa_feature, precision,
-                                                           dfps_side_stream=5 if linear_graphs else None)
+                                                           dfps_side_stream=5 if linear_graphs else None,
+                                                           coop_capture=(mode == "staged" and bool(graphs) and int(points) > 16384))
         self.check_overflow = bool(check_overflow)
         self.mode = mode
         self.batch, self.points, self.channels = int(batch), int(points), int(channels)
@@ -387,11 +402,13 @@ class SAPipeline:
                     a.wait_event(s.last_event)            # stage B of the slot's previous round still reads stage A's outputs
                     stamp("launch:wait_prev_round")
                 with torch.cuda.stream(a):
+                    s.overflow.zero_()                    # the round's fp16 range word, in front of BOTH stages (b waits for a)
                     if ga is not None:
                         ga.replay()
                     else:
                         gen = self.net.forward_staged(view)
-                        next(gen)
+                        with self._flag_word(s):
+                            next(gen)
                     stamp("launch:stage_A")
                     ev = self._event(tl)
                     ev.record(a)
@@ -400,7 +417,8 @@ class SAPipeline:
                 b.wait_event(ev)
                 stamp("launch:event_A_to_B")
             with torch.cuda.stream(b):
-                s.overflow.zero_()
+                if not staged:
+                    s.overflow.zero_()
                 stamp("launch:zero_flag")
                 if gb is not None:
                     gb.replay()

@@ -29,6 +29,9 @@ SIGNATURES = {
     "sa_group_mlp_max_layer": [_c_int] * 4 + [_vp, _c_int, _vp, _vp, _vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _vp,
                                _vp, _vp, _vp, _vp],
     "sa_fps_ex2": [_c_int] * 4 + [_vp, _c_long, _vp, _vp, _c_int, _c_int, _vp, _c_long, _vp],
+    "sa_fps_ex3": [_c_int] * 4 + [_vp, _c_long, _vp, _vp, _c_int, _c_int, _vp, _c_long, _c_int, _vp],
+    "sa_coop_error_state": [_c_int],
+    "sa_debug_fps_coop_orphan": [_c_int] * 4 + [_vp, _vp, _vp, ctypes.c_uint, _vp],
     "sa_fps_bucket_ex2": [_c_int] * 3 + [_vp, _c_long, _vp, _c_int, _c_int, _vp, _c_long, _vp],
     "sa_fps_with_distance_ex2": [_c_int] * 3 + [_vp, _vp, _vp, _c_int, _c_int, _vp, _c_long, _vp, _c_long, _vp],
     "sa_calc_square_dist_self_ws": [_c_int] * 4 + [_vp, _c_int, _vp, _c_int, _vp, _vp, _vp],
@@ -76,7 +79,9 @@ EXTRA_SIGNATURES = {
     "sa_calc_iou_match": [_c_int] + [_vp] * 5,
 }
 
-_ERRORS = {-1: "invalid argument", -2: "kernel launch failed (hipGetLastError)", -3: "unsupported size"}
+_ERRORS = {-1: "invalid argument", -2: "kernel launch failed (hipGetLastError)", -3: "unsupported size",
+           -4: "an earlier multi-workgroup sampler launch gave up waiting for partner workgroups (its outputs are invalid; "
+               "such launches must stay on one stream -- sa_coop_error_state(1) clears the sticky word)"}
 _LIB = None
 _EXTRA = None
 

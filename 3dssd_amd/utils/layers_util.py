@@ -47,14 +47,19 @@ AGGREGATION_SA_FEATURE = True
 DFPS_SIDE_STREAM = 6
 PLAN_LOG = None     # set to a list to collect (b, m, nsample, MACs per row, plan tensor) of every fused-MLP call
 MLP_PLAN_FLAGS = 0  # sa_group_mlp_max flag bit 0 (all nsample rows instead of the distinct ones), A/B measurements
-MLP_GRANULE4 = True  # row plans in granules of 4 rows for the scales the row-wave kernels take (csrc/mlp_plan.h; flag bit 6); False: 8 rows everywhere (A/B)
+# Row plans in granules of 4 rows for the scales the row-wave kernels take (csrc/mlp_plan.h; flag bit 6).  Built in round 5,
+# bit-identical, MEASURED and left off (profiles/r05_granule4_ab.txt, 128 frames per launch): on the sparse default frames
+# layer 1 / layer 2 run 18 % / 23 % faster (half the padding rows), layer 3 / 4 do not move (eight pooled entries per tile
+# cost what the saved tiles gave), the plan kernels cost 65 % more (an 8-phase next-fit scan, twice the entries) -- net
+# -65 us of 6.8 ms; on ring-structured frames (8-33 rows per ball) every layer is 1-8 % SLOWER.  Opt-in for sparse data.
+MLP_GRANULE4 = False
 GRID_BALL_QUERY_MIN_N = 2048
 MLP_GEMM_CHAIN = False  # True: eligible fp16 scales (layer4) run as three large-tile GEMM launches (flags bit 4); measured slower
 MAX_TRANSLATE_RANGE = (-3.0, -2.0, -3.0)
 # F-FPS without the distance matrix (csrc/ffps_fly.hip) where the shape allows it (64 feature channels, 1024 / 2048 /
 # 4096 points: layer 2 of 3dssd.yaml).  Several workgroups share a frame, so every call of a process must be on one
-# stream at a time: the staged executor (pipeline.py) turns it on for its own network and gives the stage a stream;
-# default off for direct callers.
+# stream at a time.  Opt-in for DIRECT single-stream callers only (SABackbone(ffps_fly=True)); the executor of pipeline.py
+# runs that layer's sampler on alternating main streams and refuses a network built with it.
 FFPS_FLY = False
 
 
@@ -197,10 +202,11 @@ def _side_stream(main, which=0):
     return _SIDE_STREAMS[key]
 
 
-def _dfps_into(npoint, xyz, start, end, out, col, ctr):
+def _dfps_into(npoint, xyz, start, end, out, col, ctr, coop_capture=False):
     """D-FPS on rows [start, end) of every frame (layers_util.py:97,106), read in place; indices (+ start) into
     out[:, col:col+npoint], the picked points into ctr[:, col:col+npoint] when given.  Returns True when the centres
-    were written."""
+    were written.  coop_capture: sa_fps_ex3 flag bit 0 -- frames beyond one workgroup's capacity may launch the
+    multi-workgroup sampler plainly under graph capture (the caller keeps all such launches on one stream)."""
     b, n_all, c = xyz.shape
     n = end - start
     dev = xyz.device
@@ -220,15 +226,15 @@ def _dfps_into(npoint, xyz, start, end, out, col, ctr):
         # frames that do not fit the register-resident kernels: dense copy of the range, scratch, separate gather
         src = xyz if (start == 0 and end == n_all) else xyz[:, start:end].contiguous()
         temp = torch.empty((b, n), dtype=torch.float32, device=dev)
-        st = lib.sa_fps_ex(b, n, c, npoint, src.data_ptr(), temp.data_ptr(), out.data_ptr() + 4 * col, out.shape[1],
-                           start, N.current_stream())
+        st = lib.sa_fps_ex3(b, n, c, npoint, src.data_ptr(), 0, temp.data_ptr(), out.data_ptr() + 4 * col, out.shape[1],
+                            start, None, 0, 1 if coop_capture else 0, N.current_stream())
         N.check(st, "farthest_point_sample")
     _run_chain(chain)
     return done[0]
 
 
 def sample_layer(xyz, points, fps_sample_range_list, fps_method_list, npoint_list, former_fps_idx, vote_ctr, radius_list,
-                 side_mode=None, ffps_fly=None):
+                 side_mode=None, ffps_fly=None, coop_capture=False):
     """The sampling half of pointnet_sa_module_msg (layers_util.py:84-119): range slicing, D-FPS / F-FPS / FS / identity
     per range, index offsets, the centres.  Returns (fps_idx [B,m] int32, new_xyz [B,m,3], sliced_points or None).
     side_mode: DFPS_SIDE_STREAM for this call (None: the module default)."""
@@ -317,7 +323,7 @@ def sample_layer(xyz, points, fps_sample_range_list, fps_method_list, npoint_lis
                 if st != _UNSUPPORTED:
                     N.check(st, "ffps_fly")
                     f_handled = dual_done = True
-                    ok_d = _dfps_into(dm, xyz, ds, de, fps_idx, dc, new_xyz)
+                    ok_d = _dfps_into(dm, xyz, ds, de, fps_idx, dc, new_xyz, coop_capture)
                     centres_ok = centres_ok and new_xyz is not None and ok_d
                     work = []
         if not dual_done and len(fparts) == 1 and len(dparts) == 1 and xyz.shape[2] == 3:
@@ -369,9 +375,9 @@ def sample_layer(xyz, points, fps_sample_range_list, fps_method_list, npoint_lis
             d_col = c0 + d_n if kind == "FS" else c0                        # 'FS': [F-FPS idx || D-FPS idx] (:96-98)
             if side is not None:
                 with torch.cuda.stream(side):
-                    centres_ok = _dfps_into(d_n, xyz, start, end, fps_idx, d_col, new_xyz) and centres_ok
+                    centres_ok = _dfps_into(d_n, xyz, start, end, fps_idx, d_col, new_xyz, coop_capture) and centres_ok
             else:
-                centres_ok = _dfps_into(d_n, xyz, start, end, fps_idx, d_col, new_xyz) and centres_ok
+                centres_ok = _dfps_into(d_n, xyz, start, end, fps_idx, d_col, new_xyz, coop_capture) and centres_ok
     if side_mode not in (2, 3) and not f_handled:                    # F-FPS parts (:94-96,102-104)
         centres_ok = ffps_all() and centres_ok
     if side is not None:
@@ -405,7 +411,7 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
                            fps_sample_range_list, fps_method_list, npoint_list, former_fps_idx,
                            use_attention, scope, dilated_group, vote_ctr=None, aggregation_channel=None,
                            debugging=False, epsilon=1e-5, variables=None, aggregation_sa_feature=None, presampled=None,
-                           dfps_side_stream=None, ffps_fly=None):
+                           dfps_side_stream=None, ffps_fly=None, coop_capture=False):
     """layers_util.py:59-189.  xyz (B,n,3), points (B,n,C) -> new_xyz (B,m,3), new_points (B,m,C'),
     fps_idx (B,m) int32.  aggregation_sa_feature: cfg.MODEL.NETWORK.AGGREGATION_SA_FEATURE (None: the module default);
     presampled = (fps_idx, new_xyz, sliced_points) of an earlier `sample_layer` call with the same arguments (the staged
@@ -422,7 +428,8 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
         fps_idx, new_xyz, sliced_points = presampled
     else:
         fps_idx, new_xyz, sliced_points = sample_layer(xyz, points, fps_sample_range_list, fps_method_list, npoint_list,
-                                                       former_fps_idx, vote_ctr, radius_list, dfps_side_stream, ffps_fly)
+                                                       former_fps_idx, vote_ctr, radius_list, dfps_side_stream, ffps_fly,
+                                                       coop_capture)
     m = new_xyz.shape[1]
     lib = N.lib()
     stream = N.current_stream()

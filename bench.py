@@ -76,7 +76,7 @@ class TimingProxy:
 
     def __getattr__(self, name):
         fn = getattr(self._real, name)
-        if not name.startswith("sa_") or name.endswith("_ws_bytes"):
+        if not name.startswith("sa_") or name.endswith(("_ws_bytes", "_rows", "_state")):       # host-side queries: no launch to time
             return fn
 
         def wrapped(*args):
@@ -457,16 +457,55 @@ def sclk_mhz(dev=None):
     return None
 
 
+def _cgroup_dirs():
+    """Directories of this process's cgroup (v2) from the leaf up to the mount point, those that exist."""
+    rel = ""
+    try:
+        for ln in open("/proc/self/cgroup"):
+            parts = ln.strip().split(":", 2)
+            if len(parts) == 3 and parts[0] == "0":
+                rel = parts[2].strip("/")
+    except Exception:  # noqa: BLE001
+        pass
+    out, cur = [], rel
+    while True:
+        d = os.path.join("/sys/fs/cgroup", cur) if cur else "/sys/fs/cgroup"
+        if os.path.isdir(d):
+            out.append(d)
+        if not cur:
+            break
+        cur = os.path.dirname(cur)
+    return out
+
+
 def _cgroup_cpu_stat():
-    """(nr_throttled, throttled_usec) of this process's cgroup (v2 cpu.stat / v1 cpu.stat), or None."""
-    for f in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat", "/sys/fs/cgroup/cpu,cpuacct/cpu.stat"):
+    """(nr_throttled, throttled_usec) of this process's cgroup: the deepest level that has the counters (v2 cpu.stat, or
+    the v1 files), or None."""
+    files = [os.path.join(d, "cpu.stat") for d in _cgroup_dirs()] + ["/sys/fs/cgroup/cpu/cpu.stat", "/sys/fs/cgroup/cpu,cpuacct/cpu.stat"]
+    for f in files:
         try:
             d = dict(ln.split() for ln in open(f).read().splitlines() if len(ln.split()) == 2)
+            if "nr_throttled" not in d:
+                continue
             t = int(d.get("throttled_usec", int(d.get("throttled_time", 0)) // 1000))
-            return int(d.get("nr_throttled", 0)), t
+            return int(d["nr_throttled"]), t
         except Exception:  # noqa: BLE001
             continue
     return None
+
+
+def cgroup_cpu_quota():
+    """The tightest CPU quota over this process's cgroup levels, in cores (cpu.max = "quota period"), or None (no limit)."""
+    best = None
+    for d in _cgroup_dirs():
+        try:
+            q, per = open(os.path.join(d, "cpu.max")).read().split()[:2]
+            if q != "max":
+                c = int(q) / float(per)
+                best = c if best is None else min(best, c)
+        except Exception:  # noqa: BLE001
+            continue
+    return best
 
 
 def _ioctl_trace():
@@ -559,9 +598,10 @@ def timed_region(sh, dev, run, steps, warmup, frames_per_step, prime=None, befor
     same brackets, repeated until its duration is stable) -> barrier + synchronize -> EXACTLY `steps` steps -> synchronize
     + barrier.  before() / after() run just outside the timed bracket.  The cyclic garbage collector is collected once and
     frozen BEFORE the rehearsals and stays off across the bracket (a generation-2 pass over a process that has imported
-    torch takes 35 ms -- longer than a 20-step window).  idle_wait(): an optional sleeping wait for the executor's streams
-    in front of the bracket's torch.cuda.synchronize() (which then returns at once): no host thread spins while the GPU
-    works."""
+    torch takes 35 ms -- longer than a 20-step window).  idle_wait(t0): an optional sleeping wait for the executor's
+    streams in front of the bracket's torch.cuda.synchronize() (which then returns at once): the host thread does not
+    spin while the GPU works (a process under a CPU quota is frozen for the rest of a 100 ms period once it has used the
+    quota up: measured, profiles/r05_stall_quota.txt)."""
     import gc
     primed = prime() if prime is not None else None
     run(warmup)
@@ -584,7 +624,7 @@ def timed_region(sh, dev, run, steps, warmup, frames_per_step, prime=None, befor
         if watch is not None:
             watch.issued()
         if idle_wait is not None:
-            idle_wait()
+            idle_wait(t0)
         torch.cuda.synchronize()
         sh.barrier()
         torch.cuda.synchronize()
@@ -763,13 +803,23 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
             run(C)
             n += C
             if n % (pipe.nslots * C) == 0:
-                (idle_wait or pipe.drain)()
+                (pipe.wait_idle if args.blocking_wait else pipe.drain)()
         pipe.drain()
         return {"batches": n, "packages": n // C, "wall_ms": round((time.perf_counter() - t0) * 1e3, 1),
                 "note": "untimed, before the warm-up steps: every slot replayed >= 2x on pool frames, >= 150 ms of work"}
 
     rehearsal = []
-    idle_wait = pipe.wait_idle if args.blocking_wait else None
+    cpu0 = (time.process_time(), time.perf_counter(), _cgroup_cpu_stat())
+
+    def sleeping_wait(t0):
+        # the host sleeps through most of the window it expects (0.8 x the fastest rehearsal), then waits for the
+        # executor's streams on blocking HIP events; the bracket's torch.cuda.synchronize() follows and returns at once
+        if rehearsal:
+            remain = 0.8e-3 * min(rehearsal) - (time.perf_counter() - t0)
+            if remain > 3e-4:
+                time.sleep(remain)
+        pipe.wait_idle()
+    idle_wait = sleeping_wait if args.blocking_wait else None
 
     def rehearse():
         # untimed dress rehearsals of the timed region: the SAME calls (K submits, the package sizes K produces, timing
@@ -791,7 +841,7 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
             t0 = time.perf_counter()
             run(args.steps)
             if idle_wait is not None:
-                idle_wait()
+                idle_wait(t0)
             torch.cuda.synchronize()
             rehearsal.append(round((time.perf_counter() - t0) * 1e3, 3))
             pipe.host_trace = None
@@ -812,6 +862,12 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
     t_max, frames_total, host_issue_ms, tickets, primed = timed_region(sh, dev, run, args.steps, args.warmup, args.batch,
                                                                        prime, before, after, rehearse, watch, idle_wait)
     host = watch.summary()
+    cg1 = _cgroup_cpu_stat()
+    host["cgroup_cpu_quota_cores"] = cgroup_cpu_quota()
+    if cpu0[2] is not None and cg1 is not None:          # prime + warm-up + rehearsals + timed region
+        host["cgroup_nr_throttled_since_priming"] = cg1[0] - cpu0[2][0]
+        host["cgroup_throttled_us_since_priming"] = cg1[1] - cpu0[2][1]
+    host["process_cpu_cores_since_priming"] = round((time.process_time() - cpu0[0]) / max(time.perf_counter() - cpu0[1], 1e-9), 2)
     packages = pipe.timeline(base[0])
     x_last, f_last = tickets[-1].result()
     assert f_last.shape == (args.batch, 256, 512) and x_last.shape == (args.batch, 256, 3)

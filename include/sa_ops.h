@@ -87,6 +87,21 @@ int sa_fps_bucket_stats(int b, int n, int m, const float *inp, int *out, unsigne
  * n <= 16384 / n <= 16384): SA_ERR_UNSUPPORTED otherwise. */
 int sa_fps_ex2(int b, int n, int c, int m, const float *inp, long in_bstride, float *temp, int *out, int out_stride,
                int idx_off, float *ctr, long ctr_bstride, sa_stream_t stream);
+/* sa_fps_ex2 with flags.  bit 0: frames that need the multi-workgroup sampler (n > 16384 or c != 3: csrc/fps_coop.hip)
+ * may launch it PLAINLY on a capturing stream -- the caller guarantees that all such launches of the process are issued on
+ * one stream (partner workgroups of two interleaved grids can wait for each other for ever).  Without the bit (and in
+ * sa_fps_ex / sa_fps_ex2 / sa_farthest_point_sample) a capturing stream gets the single-workgroup kernels, which are
+ * safe on any number of streams; eager calls use a cooperative launch either way. */
+int sa_fps_ex3(int b, int n, int c, int m, const float *inp, long in_bstride, float *temp, int *out, int out_stride,
+               int idx_off, float *ctr, long ctr_bstride, int flags, sa_stream_t stream);
+/* Sticky error word of the multi-workgroup samplers (sa_fps_ex* beyond one workgroup per frame, sa_ffps_fly_ex): 0 =
+ * fine; bit 0 / bit 1: a D-FPS / an on-the-fly F-FPS launch gave up waiting for partner workgroups (they were not all
+ * resident: the one-stream rule above was violated) -- that launch's outputs are invalid, and every further call of
+ * these samplers returns -4 until the word is cleared (reset != 0).  Reads host memory only: no synchronisation. */
+int sa_coop_error_state(int reset);
+/* Test hook: sa_fps_ex's multi-workgroup launch with the LAST workgroup missing and a short poll bound. */
+int sa_debug_fps_coop_orphan(int b, int n, int c, int m, const float *inp, float *temp, int *out, unsigned max_spin,
+                             sa_stream_t stream);
 int sa_fps_bucket_ex2(int b, int n, int m, const float *inp, long in_bstride, int *out, int out_stride, int idx_off,
                       float *ctr, long ctr_bstride, sa_stream_t stream);
 int sa_fps_with_distance_ex2(int b, int n, int m, const float *dist, float *temp, int *out, int out_stride,

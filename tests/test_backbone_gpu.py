@@ -227,8 +227,8 @@ def test_two_backbones_keep_their_own_settings(gpu):
 
 @pytest.mark.parametrize("variant", ["default", "rings64", "dense"])
 def test_four_row_granules_change_the_rows_evaluated_not_the_results(gpu, variant):
-    # round 5 (csrc/mlp_plan.h): the row plans of the scales the row-wave kernels take are built in granules of 4 rows
-    # (layers_util.MLP_GRANULE4).  The maximum over a ball's distinct rows does not depend on how they are packed into
+    # round 5 (csrc/mlp_plan.h): the row plans of the scales the row-wave kernels take can be built in granules of 4 rows
+    # (layers_util.MLP_GRANULE4; opt-in, see the measurement there).  The maximum over a ball's distinct rows does not depend on how they are packed into
     # tiles: every output of the backbone must be BIT-identical to the 8-row form, on sparse, ring-structured and
     # all-balls-full frames (split balls of more than 32 rows included), while the evaluated rows drop.
     cfgs, syn = pkg("configs"), pkg("synthetic")
@@ -238,13 +238,14 @@ def test_four_row_granules_change_the_rows_evaluated_not_the_results(gpu, varian
     pts = torch.from_numpy(np.stack([syn.frame_of(variant, f, 16384) for f in range(3)])).to(gpu)
 
     def run(flag):
+        default = lu.MLP_GRANULE4
         lu.MLP_GRANULE4, lu.PLAN_LOG = flag, []
         try:
             xl, fl, il = net(pts)
             torch.cuda.synchronize()
             hdrs = [p[4][:4].cpu().tolist() for p in lu.PLAN_LOG]
         finally:
-            lu.MLP_GRANULE4, lu.PLAN_LOG = True, None
+            lu.MLP_GRANULE4, lu.PLAN_LOG = default, None
         return [t.clone() for t in fl], [None if t is None else t.clone() for t in il], hdrs
 
     f8, i8, h8 = run(False)

@@ -213,3 +213,16 @@ def test_inputs_may_be_dropped_right_after_submit(gpu, pipe6):
         del t                                          # freed at once; the next .to(gpu) may get the same block
     for i, tk in enumerate(tickets):
         assert torch.equal(tk.result()[1], eager[i]), i
+
+
+def test_pipeline_refuses_a_network_whose_sampler_must_stay_on_one_stream(gpu):
+    # the on-the-fly F-FPS (csrc/ffps_fly.hip) spins on partner workgroups and needs all its launches
+    # on one stream; the executor alternates that layer between its main streams, so it refuses such a network instead of
+    # documenting a rule nothing enforced.
+    cfgs, syn = pkg("configs"), pkg("synthetic")
+    arch = cfgs.KITTI_3DSSD_ARCH
+    params = syn.random_backbone_params(arch)
+    net = pkg("backbone").SABackbone(arch, params, gpu, cfgs.KITTI_MAX_TRANSLATE_RANGE, ffps_fly=True)
+    for mode in ("staged", "slots"):
+        with pytest.raises(ValueError, match="ffps_fly"):
+            pkg("pipeline").SAPipeline(arch, params, gpu, batch=1, points=16384, streams=2, net=net, mode=mode, graphs=False)
