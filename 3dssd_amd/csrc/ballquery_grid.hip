@@ -27,7 +27,7 @@ namespace {
 constexpr int kNX = 128;                 // grid is kNX x kNX cells
 constexpr int kNC = kNX * kNX;
 constexpr int kMaxBands = 4;
-constexpr int kCap = 256;                // hits per band kept in LDS per query (more: cut down to the nsample smallest, in place)
+constexpr int kCap = 320;                // hits per band kept in LDS per query (more: cut down to the nsample smallest, in place); nsample <= kCap - 64 = 256 on this path
 constexpr int kQWaves = 4;               // waves (= queries in flight) per workgroup
 
 struct GBands {
@@ -41,8 +41,11 @@ struct GBands {
 
 __device__ __forceinline__ float wave_allmin_f(float x) { return -sa::wave_allmax(-x); }
 
-// workspace per frame: cell_start[kNC + 1] ints | sorted[n] ints | params[4] floats (minx, minz, inv, 0)
-__host__ __device__ __forceinline__ size_t ws_stride(int n) { return ((size_t)(kNC + 1) + n + 4 + 3) / 4 * 4; }
+// workspace per frame (in ints): cell_start[kNC + 1] (+3 padding) | sorted[n] float4 = (x, y, z, index bits) in cell
+// order | params[4] floats (minx, minz, inv, 0).  Round 5: the cell lists hold the POINTS, not their indices -- a query's
+// chain was bounds -> sorted index -> point (a scattered 12-byte gather); it is now bounds -> one coalesced 16-byte read.
+constexpr int kCellInts = kNC + 4;
+__host__ __device__ __forceinline__ size_t ws_stride(int n) { return (size_t)kCellInts + 4 * (size_t)n + 4; }
 
 __global__ __launch_bounds__(1024) void bq_grid_build_kernel(int n, float cell_min, const float *__restrict__ xyz1,
                                                              int *__restrict__ ws) {
@@ -52,7 +55,7 @@ __global__ __launch_bounds__(1024) void bq_grid_build_kernel(int n, float cell_m
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const float *p = xyz1 + (size_t)b * n * 3;
     int *cell_start = ws + (size_t)b * ws_stride(n);
-    int *sorted = cell_start + (kNC + 1);
+    float4 *sorted = (float4 *)(cell_start + kCellInts);
     float *params = (float *)(sorted + n);
 
     float mnx = 3e38f, mxx = -3e38f, mnz = 3e38f, mxz = -3e38f;
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(1024) void bq_grid_build_kernel(int n, float cell_m
         const int cx = min(kNX - 1, max(0, (int)((p[k * 3 + 0] - mnx) * inv)));
         const int cz = min(kNX - 1, max(0, (int)((p[k * 3 + 2] - mnz) * inv)));
         const int pos = atomicAdd(&s_cnt[cz * kNX + cx], 1);
-        sorted[pos] = k;
+        sorted[pos] = make_float4(p[k * 3 + 0], p[k * 3 + 1], p[k * 3 + 2], __int_as_float(k));
     }
 }
 
@@ -176,9 +179,8 @@ __global__ __launch_bounds__(kQWaves * 64) void bq_grid_query_kernel(int n, int 
     }
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // wave-uniform: the per-query loads are scalar
-    const float *P = xyz1 + (size_t)b * n * 3;
     const int *cell_start = ws + (size_t)b * ws_stride(n);
-    const int *sorted = cell_start + (kNC + 1);
+    const float4 *sorted = (const float4 *)(cell_start + kCellInts);
     const float *params = (const float *)(sorted + n);
     const float mnx = params[0], mnz = params[1], inv = params[2];
     int (*hits)[kCap] = s_hits[w];
@@ -206,33 +208,23 @@ __global__ __launch_bounds__(kQWaves * 64) void bq_grid_query_kernel(int n, int 
             rc[r] = in ? e - s : 0;
         }
         const int c01 = rc[0] + rc[1], T = c01 + rc[2];
-        // The walk is software-pipelined (round 5): a step's chain is sorted[pos] -> point -> distance, two dependent
-        // global round trips that the LDS list updates and ballots of the loop body keep the compiler from overlapping.
-        // So the candidate INDEX of step s+2 and the POINT of step s+1 are requested before step s is evaluated: a
-        // frame whose balls hold hundreds of points (ring-structured sweeps, synthetic.py rings64: 4.5 steps per query
-        // on average, 100+ on dense frames) pays one round trip per step instead of two; a one-step query is unchanged.
-        auto cand_index = [&](int base) -> int {           // lane's candidate of the step at `base` (clamped past T)
+        // Round 5: a step reads its 64 candidates (point + index, 16 bytes each, consecutive in the cell lists) with ONE
+        // coalesced load, requested one step ahead of its use: the LDS list updates and ballots of the loop body keep the
+        // compiler from overlapping the steps by itself.
+        auto cand = [&](int base) -> float4 {              // lane's candidate of the step at `base` (clamped past T)
             const int j = base + lane;
             const int jj = j < T ? j : 0;
             const int pos = jj < rc[0] ? rs[0] + jj : (jj < c01 ? rs[1] + (jj - rc[0]) : rs[2] + (jj - c01));
             return sorted[pos];
         };
-        int k0 = 0, k1 = 0;
-        float px = 0.0f, py = 0.0f, pz = 0.0f;
-        if (T > 0) {
-            k0 = cand_index(0);
-            k1 = cand_index(64);
-            px = P[k0 * 3 + 0]; py = P[k0 * 3 + 1]; pz = P[k0 * 3 + 2];
-        }
+        float4 nxt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (T > 0) nxt = cand(0);
         for (int base = 0; base < T; base += 64) {
             const bool valid = base + lane < T;
-            const int k = k0;
-            const float cxp = px, cyp = py, czp = pz;
-            // requests for the next two steps (addresses stay inside the frame's arrays: cand_index clamps)
-            const int k2 = cand_index(base + 128);
-            px = P[k1 * 3 + 0]; py = P[k1 * 3 + 1]; pz = P[k1 * 3 + 2];
-            k0 = k1;
-            k1 = k2;
+            const float4 cur = nxt;
+            if (base + 64 < T) nxt = cand(base + 64);       // (wave-uniform: a one-step query requests nothing ahead)
+            const int k = __float_as_int(cur.w);
+            const float cxp = cur.x, cyp = cur.y, czp = cur.z;
             const float dx = x2 - cxp, dy = y2 - cyp, dz = z2 - czp;
             const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));   // as ballquery.hip
             if (__ballot(valid && d2 < B.thi_max) == 0ull) continue;

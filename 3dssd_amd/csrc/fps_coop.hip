@@ -202,7 +202,7 @@ static int fps_coop_launch(int b, int n, int c, int m, const float *inp, float *
     // every frame of the call has its OWN slots (2 G words), zeroed by one memset in front of the first launch: the
     // consecutive launches of a large batch share nothing, so nothing depends on how a memset between two of them is
     // ordered (a shared region re-zeroed between the launches gave wrong picks in frames of the SECOND launch when the
-    // call was replayed from a hipGraph beside other streams' kernels -- round 4, tools/dbg_pipe.py)
+    // call was replayed from a hipGraph beside other streams' kernels -- round 4, tools/archive/dbg_pipe.py)
     unsigned long long *slots0 = (unsigned long long *)temp;
     if (hipMemsetAsync(slots0, 0, (size_t)b * 2 * G * sizeof(unsigned long long), stream) != hipSuccess) return SA_ERR_LAUNCH;
     for (int f0 = 0; f0 < b; f0 += per_launch) {

@@ -953,9 +953,21 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void dense128_kernel(DenseParams P
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, col = lane & 31;
     const LayerDesc &L = P.L;
-    const int ct = blockIdx.y * CT + (w % CT);                // this wave's column tile (host: NT % CT == 0)
+    // (row block, column block) of this workgroup.  The column blocks of one row block read the SAME 128 input rows: in
+    // launch order (x fastest) they were a whole pass over the rows apart and every column block fetched the input from
+    // HBM again -- 898 MB of counter traffic against 272 algorithmic at 32768 x 1536 -> 512 (profiles/r05_rooflines_128f).
+    // Now they are consecutive workgroups of ONE XCD (block L is observed to run on XCD L % 8, sa_common.h): they walk the
+    // row block's chunks together and the later ones hit that XCD's L2.  A wrong guess about placement only costs the saving.
+    int rb = blockIdx.x, cb = blockIdx.y;
+    if (gridDim.y > 1 && (gridDim.x & 7) == 0) {
+        const unsigned Lid = blockIdx.y * gridDim.x + blockIdx.x, per = 8u * gridDim.y;
+        const unsigned within = Lid % per;
+        rb = (int)((Lid / per) * 8u + (within & 7u));
+        cb = (int)(within >> 3);
+    }
+    const int ct = cb * CT + (w % CT);                        // this wave's column tile (host: NT % CT == 0)
     const int rt0 = (w / CT) * RT;                            // ... and its first row tile of the block
-    const long r0 = (long)blockIdx.x * 128;
+    const long r0 = (long)rb * 128;
     const int nch = L.K / kD128KC;                            // host: K % (64 * PD) == 0
 
     // this thread's (row, 8-channel group) items of a chunk: rows past the end read the last row, never stored

@@ -37,7 +37,9 @@ namespace sa {
 int *coop_error_word();
 constexpr int kCoopErrFps = 1, kCoopErrFfps = 2;
 __device__ __forceinline__ void coop_raise(int *word, int code) {
-    if (word) __hip_atomic_fetch_or(word, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // a plain system-scope store (not a fetch-or: an atomic RMW on host memory needs PCIe AtomicOps routing); two kinds of
+    // failure in flight at once would leave the later code -- non-zero either way
+    if (word) __hip_atomic_store(word, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---- DPP cross-lane moves (wave64, gfx9 encodings) ---------------------------------------

@@ -192,6 +192,8 @@ class SAPipeline:
                                                            aggregation_sa_feature, precision,
                                                            dfps_side_stream=5 if linear_graphs else None,
                                                            coop_capture=(mode == "staged" and bool(graphs) and int(points) > 16384))
+        if net is not None:                           # what the caller's network really does, not what was asked for here
+            self.linear_graphs = net.settings.get("dfps_side_stream") == 5
         self.check_overflow = bool(check_overflow)
         self.mode = mode
         self.batch, self.points, self.channels = int(batch), int(points), int(channels)

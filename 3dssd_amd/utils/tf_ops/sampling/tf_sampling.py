@@ -107,3 +107,11 @@ def farthest_point_sample_with_preidx(npoint, inp, preidx):
                                                          preidx.data_ptr(), temp.data_ptr(), out.data_ptr(),
                                                          N.current_stream()), "farthest_point_sample_with_preidx")
     return out
+
+
+def prob_sample(inp, inpr):
+    """tf_sampling.py:8-16 of the reference (inverse-CDF sampling).  It has NO caller in the reference (SURVEY.md section 2,
+    out of scope) and was removed from this library in round 4; the name stays so that code written against the
+    reference's module gets a clear error instead of an AttributeError at import."""
+    raise NotImplementedError("prob_sample is outside the set-abstraction path (no caller in the reference, SURVEY.md section 2): "
+                              "not provided by 3dssd_amd -- see DESIGN.md section 8")

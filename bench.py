@@ -45,7 +45,7 @@ MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 / fp16 MFMA
 VALU_F32_PEAK_TF = 157.3
 MAX_CLOCK_MHZ = 2400.0      # MI355X_MICROARCH.md "Max clock"; cycles_per_pick is quoted at this clock (DVFS runs lower)
 FPS_FLOP_PER_PAIR = 11      # 3 sub + 3 mul/fma + min + compare/select chain, SURVEY.md 8d (3c + 2 with c = 3)
-TRAFFIC_PROFILES = [os.path.join("profiles", "r04_traffic.json"), os.path.join("profiles", "r03_traffic.json")]
+TRAFFIC_PROFILES = [os.path.join("profiles", "r05_traffic.json"), os.path.join("profiles", "r04_traffic.json")]
 
 
 def pkg(name):
@@ -170,19 +170,28 @@ MFMA_CALLS = MLP_CALLS + ("sa_dense", "sa_vote_tail")
 
 def profile_stages(fn, iters):
     """Average duration of every C-ABI call of one step (`fn()`), measured live with events on the launch stream.
-    Eager launches on ONE stream: these are kernel durations, not the overlapped multi-stream step time."""
+    Eager launches on ONE stream: these are kernel durations, not the overlapped multi-stream step time.  Flop rates:
+    `tflops_nominal` divides the reference's m x nsample rows by the time; `tflops_executed` (grouped-MLP
+    calls) the rows the kernels really evaluate (plan headers: granules x rows per granule)."""
     if iters <= 0:
         return []
     native = pkg("utils._native")
+    lu = pkg("utils.layers_util")
     real = native.lib()
     proxy = TimingProxy(real)
     native._LIB = proxy
+    lu.PLAN_LOG = []
     try:
         for _ in range(iters):
             fn()
         torch.cuda.synchronize()
     finally:
         native._LIB = real
+        plan_log, lu.PLAN_LOG = lu.PLAN_LOG, None
+    executed = {}                                   # m of the layer -> executed flops per call (mean over the iterations)
+    for (b, m, ns, macs, plan) in plan_log:
+        h = plan[:4].cpu().tolist()
+        executed[m] = executed.get(m, 0.0) + 2.0 * h[0] * (h[3] or 8) * macs / iters
     agg = {}
     order = []
     for name, args, s, e in proxy.records:
@@ -201,8 +210,13 @@ def profile_stages(fn, iters):
         st = dict(kernel=d["kernel"], label=d["label"], calls_per_step=per_step_calls, avg_ms=round(ms, 5),
                   gflop=round(d["flops"] / 1e9, 4), mbytes=round(d["bytes"] / 1e6, 4))
         if ms > 0:
-            st["tflops"] = round(d["flops"] / ms / 1e9, 3)
+            st["tflops_nominal"] = round(d["flops"] / ms / 1e9, 3)
             st["gbs"] = round(d["bytes"] / ms / 1e6, 2)
+            if d["kernel"] in MLP_CALLS and " m=" in d["label"]:
+                m = int(d["label"].split(" m=")[1].split()[0])
+                if m in executed:
+                    st["gflop_executed"] = round(executed[m] / per_step_calls / 1e9, 4)
+                    st["tflops_executed"] = round(executed[m] / per_step_calls / ms / 1e9, 3)
         stages.append(st)
     return stages
 
@@ -287,7 +301,7 @@ def roofline_of(stage, frames, clock_mhz, evaluated_pairs=None):
     k = stage["kernel"]
     if k in MFMA_CALLS or k.startswith("sa_calc_square_dist"):
         peak = MFMA_BF16_PEAK_TF if not k.startswith("sa_calc_square_dist") else VALU_F32_PEAK_TF
-        a = stage.get("tflops", 0.0)
+        a = stage.get("tflops_executed", stage.get("tflops_nominal", 0.0))
         return dict(kernel=stage["label"], bound="mfma", achieved=a, peak=peak, unit="TFLOP/s",
                     frac=round(a / peak, 5), traffic=None)
     a = stage.get("gbs", 0.0)

@@ -105,3 +105,10 @@ def test_cpu_tensors_are_rejected_not_silently_computed():
         s.farthest_point_sample(4, torch.zeros((1, 16, 3)))
     with pytest.raises(ValueError, match="positive npoint"):
         s.farthest_point_sample(0, torch.zeros((1, 16, 3)))
+
+
+def test_prob_sample_name_exists_and_says_why_it_is_not_provided():
+    # code written against the reference's tf_sampling module must get a clear error, not an AttributeError
+    s = pkg("utils.tf_ops.sampling.tf_sampling")
+    with pytest.raises(NotImplementedError, match="outside the set-abstraction path"):
+        s.prob_sample(None, None)
