@@ -150,7 +150,8 @@ class Ticket:
 
 class _Slot:
     # graphs: {package size (batches): (stage-A graph or None, stage-B / whole graph)}; lists: {size: forward()'s lists}
-    __slots__ = ("pipe", "index", "stream_a", "stream_b", "inp", "overflow", "graphs", "lists", "round", "last_event")
+    __slots__ = ("pipe", "index", "stream_a", "stream_b", "inp", "overflow", "graphs", "lists", "round", "last_event",
+                 "copier", "inp_ptr")
 
 
 class SAPipeline:
@@ -212,6 +213,7 @@ class SAPipeline:
         self._idle_events = []
         self._next = 0
         self.submitted = 0
+        self._part_bytes = self.batch * self.points * self.channels * 4
         self._flags = torch.zeros(_FLAG_RING, dtype=torch.int32).pin_memory()
         self._flag_next = 0
         T.require(not (mode == "slots" and self.graphs and self.points > 16384),
@@ -242,6 +244,9 @@ class SAPipeline:
             else:
                 s.stream_a = s.stream_b = torch.cuda.Stream(device=dev)
             s.inp = torch.zeros(shape, dtype=torch.float32, device=dev)
+            s.inp_ptr = s.inp.data_ptr()
+            s.copier = N.BlockCopy(self.batch, self.points, self.channels, (self.points * self.channels, self.channels),
+                                   (self.points * self.channels, self.channels), s.stream_a.cuda_stream)
             s.overflow = torch.zeros(1, dtype=torch.int32, device=dev)
             s.round, s.last_event = None, None
             self.slots.append(s)
@@ -345,21 +350,29 @@ class SAPipeline:
             r = s.round = _Round(s, self._flag_next)
             self._flag_next = (self._flag_next + 1) % _FLAG_RING
         part = r.fill
-        dst = s.inp[part * self.batch:(part + 1) * self.batch]
         st = s.stream_a
-        with torch.cuda.device(self.device):
-            if batch.is_cuda:
-                T.require(batch.device == self.device, "batch lives on %s, the pipeline on %s" % (batch.device, self.device))
-                if sync_source:
-                    ev = torch.cuda.Event()
-                    ev.record(torch.cuda.current_stream(self.device))
-                    st.wait_event(ev)
-                batch.record_stream(st)       # the caller may drop `batch` now: its block is not reused before the copy ran
-            with torch.cuda.stream(st):
-                if batch.is_cuda and batch.stride(2) == 1:
-                    N.copy_blocks([(batch, dst, self.batch, self.points, self.channels)])
-                else:
-                    dst.copy_(batch, non_blocking=True)
+        fast = batch.is_cuda and batch.is_contiguous() and not sync_source
+        if fast:
+            # resident, dense, already complete: one C call on the slot's stream, descriptor and pointers prepared at
+            # set-up (no stream context, no event: 8 us of host time per batch instead of 25)
+            T.require(batch.device == self.device, "batch lives on %s, the pipeline on %s" % (batch.device, self.device))
+            batch.record_stream(st)           # the caller may drop `batch` now: its block is not reused before the copy ran
+            s.copier.copy(batch.data_ptr(), s.inp_ptr + part * self._part_bytes)
+        else:
+            dst = s.inp[part * self.batch:(part + 1) * self.batch]
+            with torch.cuda.device(self.device):
+                if batch.is_cuda:
+                    T.require(batch.device == self.device, "batch lives on %s, the pipeline on %s" % (batch.device, self.device))
+                    if sync_source:
+                        ev = torch.cuda.Event()
+                        ev.record(torch.cuda.current_stream(self.device))
+                        st.wait_event(ev)
+                    batch.record_stream(st)   # the caller may drop `batch` now: its block is not reused before the copy ran
+                with torch.cuda.stream(st):
+                    if batch.is_cuda and batch.stride(2) == 1:
+                        N.copy_blocks([(batch, dst, self.batch, self.points, self.channels)])
+                    else:
+                        dst.copy_(batch, non_blocking=True)
         self._stamp("submit:copy_blocks")
         if out is not None:
             for o in out:

@@ -155,15 +155,35 @@ def current_stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def copy_blocks(jobs):
+def copy_blocks(jobs, stream=None):
     """One launch for up to four strided block copies; jobs = [(src, dst, frames, rows, cols), ...] with src / dst
-    3-D fp32 views [frames, rows, >= cols] whose last dimension is dense (any frame / row strides)."""
+    3-D fp32 views [frames, rows, >= cols] whose last dimension is dense (any frame / row strides).  stream: a raw HIP
+    stream handle (default: torch's current stream)."""
     flat = []
     for src, dst, frames, rows, cols in jobs:
         assert src.stride(2) == 1 and dst.stride(2) == 1
         flat += [src.data_ptr(), dst.data_ptr(), frames, rows, cols, src.stride(0), src.stride(1), dst.stride(0), dst.stride(1)]
     arr = (ctypes.c_long * len(flat))(*flat)
-    check(lib().sa_copy_blocks(len(jobs), arr, current_stream()), "copy_blocks")
+    check(lib().sa_copy_blocks(len(jobs), arr, current_stream() if stream is None else stream), "copy_blocks")
+
+
+class BlockCopy:
+    """A one-job sa_copy_blocks call whose descriptor is built once and re-used (the executor's per-batch input copy: the
+    Python side of a submit was 25 us, most of it descriptor building and a stream context): copy(src_ptr, dst_ptr)."""
+    __slots__ = ("arr", "fn", "stream")
+
+    def __init__(self, frames, rows, cols, src_strides, dst_strides, stream):
+        self.arr = (ctypes.c_long * 9)(0, 0, frames, rows, cols, src_strides[0], src_strides[1], dst_strides[0], dst_strides[1])
+        self.fn = lib().sa_copy_blocks
+        self.stream = stream
+
+    def copy(self, src_ptr, dst_ptr):
+        a = self.arr
+        a[0] = src_ptr
+        a[1] = dst_ptr
+        st = self.fn(1, a, self.stream)
+        if st != 0:
+            check(st, "copy_blocks")
 
 
 def mlp_plan_ws(b, m, ns, device, c=None, dims=None):

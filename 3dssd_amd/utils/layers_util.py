@@ -53,7 +53,7 @@ MLP_PLAN_FLAGS = 0  # sa_group_mlp_max flag bit 0 (all nsample rows instead of t
 # cost what the saved tiles gave), the plan kernels cost 65 % more (an 8-phase next-fit scan, twice the entries) -- net
 # -65 us of 6.8 ms; on ring-structured frames (8-33 rows per ball) every layer is 1-8 % SLOWER.  Opt-in for sparse data.
 MLP_GRANULE4 = False
-GRID_BALL_QUERY_MIN_N = 2048
+GRID_BALL_QUERY_MIN_N = 1024   # round 5: the 1024-point frames of layer 3 through the grid too (120 -> 77 us per 128 frames; 512-point frames are faster brute force: 28 vs 42 us)
 MLP_GEMM_CHAIN = False  # True: eligible fp16 scales (layer4) run as three large-tile GEMM launches (flags bit 4); measured slower
 MAX_TRANSLATE_RANGE = (-3.0, -2.0, -3.0)
 # F-FPS without the distance matrix (csrc/ffps_fly.hip) where the shape allows it (64 feature channels, 1024 / 2048 /

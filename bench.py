@@ -93,7 +93,7 @@ class TimingProxy:
 def _algorithmic(name, a):
     """(flops, bytes, label) of one C-ABI call from its scalar arguments (SURVEY.md 8d conventions:
     inputs read once, outputs written once)."""
-    if name in ("sa_fps_ex", "sa_fps_ex2", "sa_farthest_point_sample"):
+    if name in ("sa_fps_ex", "sa_fps_ex2", "sa_fps_ex3", "sa_farthest_point_sample"):
         b, n, c, m = a[0:4]
         return (3 * c + 2) * b * (m - 1) * n, b * (n * c * 4 + m * 4), "fps n=%d->%d c=%d" % (n, m, c)
     if name in ("sa_fps_with_distance_ex", "sa_fps_with_distance_ex2"):
@@ -1012,7 +1012,7 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
         gflop_step = sum(s["gflop"] * s["calls_per_step"] for s in stages if s["kernel"] in MFMA_CALLS)
         mb_step = sum(s["mbytes"] * s["calls_per_step"] for s in stages)
         evaluated = None
-        if dom["kernel"] in ("sa_fps_ex", "sa_fps_ex2") and " c=3" in dom["label"]:
+        if dom["kernel"] in ("sa_fps_ex", "sa_fps_ex2", "sa_fps_ex3") and " c=3" in dom["label"]:
             m1 = int(dom["label"].split("->")[1].split()[0])
             evaluated = fps_bucket_evaluated(launch[0][:, :, :3].contiguous(), m1)
         line["roofline"] = roofline_of(dom, fpl, clock_mhz, evaluated)
