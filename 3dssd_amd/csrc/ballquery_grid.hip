@@ -265,13 +265,24 @@ __global__ __launch_bounds__(kQWaves * 64) void bq_grid_query_kernel(int n, int 
             } else {
                 // rank of every hit among the hits of this band; the nsample smallest indices fill slots 0..c-1
                 int kmin = 0x7FFFFFFF;
-                for (int h0 = 0; h0 < H; h0 += 64) {
-                    const int h = h0 + lane;
-                    const int k = h < H ? hits[i][h] : 0x7FFFFFFF;
+                if (H <= 64) {
+                    // the usual case: one hit per lane, the others' values broadcast through v_readlane (an SGPR) instead of
+                    // an LDS round trip per comparison -- the rank loop was a chain of H dependent LDS reads (~100 cycles
+                    // each: 54 per query on ring-structured frames, 128 on dense ones; round 5)
+                    const int k = lane < H ? hits[i][lane] : 0x7FFFFFFF;
                     int rank = 0;
-                    for (int j = 0; j < H; ++j) rank += hits[i][j] < k ? 1 : 0;
-                    if (h < H && rank < nsi) row[rank] = k;
-                    kmin = min(kmin, k);
+                    for (int j = 0; j < H; ++j) rank += __builtin_amdgcn_readlane(k, j) < k ? 1 : 0;
+                    if (lane < H && rank < nsi) row[rank] = k;
+                    kmin = k;
+                } else {
+                    for (int h0 = 0; h0 < H; h0 += 64) {
+                        const int h = h0 + lane;
+                        const int k = h < H ? hits[i][h] : 0x7FFFFFFF;
+                        int rank = 0;
+                        for (int j = 0; j < H; ++j) rank += hits[i][j] < k ? 1 : 0;
+                        if (h < H && rank < nsi) row[rank] = k;
+                        kmin = min(kmin, k);
+                    }
                 }
                 kmin = (int)sa::wave_allmin_u32((unsigned)kmin);
                 for (int l = c + lane; l < nsi; l += 64) row[l] = kmin;     // padding: the first hit
