@@ -165,10 +165,14 @@ __device__ __forceinline__ int keep_smallest(int *list, int H, int keep, int lan
     return tau;
 }
 
+// NB / DIL: number of bands and the dilated form as COMPILE-TIME constants (round 5).  The kernel is bound by the CU's one
+// scalar pipe (PMC at the layer-1 shape: 1 070 scalar + 1 000 vector instructions per query on ring-structured frames,
+// 0.65 scalar instructions per cycle and CU): every run-time band test and form select was scalar work per band and step.
+template <int NB, bool DIL>
 __global__ __launch_bounds__(kQWaves * 64) void bq_grid_query_kernel(int n, int m, const float *__restrict__ xyz1,
                                                                      const float *__restrict__ xyz2,
                                                                      const int *__restrict__ ws, GBands B) {
-    __shared__ int s_hits[kQWaves][kMaxBands][kCap];
+    __shared__ int s_hits[kQWaves][NB][kCap];
     int b = blockIdx.y, bx = blockIdx.x;
     if ((gridDim.x & 7) == 0 && (gridDim.y & 7) == 0) {
         // XCD-aware (block L is observed to run on XCD L % 8, sa_common.h): the queries of frame f run on XCD f % 8, whose L2
@@ -191,9 +195,9 @@ __global__ __launch_bounds__(kQWaves * 64) void bq_grid_query_kernel(int n, int 
         const int cx = min(kNX - 1, max(0, (int)((x2 - mnx) * inv)));
         const int cz = min(kNX - 1, max(0, (int)((z2 - mnz) * inv)));
         const int x_lo = max(cx - 1, 0), x_hi = min(cx + 1, kNX - 1);
-        int cnts[kMaxBands] = {0, 0, 0, 0};        // entries in the band's LDS list
-        int tot[kMaxBands] = {0, 0, 0, 0};         // hits of the band so far (pts_cnt = min(tot, nsample))
-        int tau[kMaxBands] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF};   // admission bound once a list was cut
+        int cnts[NB], tot[NB], tau[NB];            // entries in the band's LDS list | hits so far (pts_cnt = min(tot, nsample)) | admission bound once a list was cut
+#pragma unroll
+        for (int i = 0; i < NB; ++i) { cnts[i] = 0; tot[i] = 0; tau[i] = 0x7FFFFFFF; }
         // the three z-rows of the 3 x 3 neighbourhood are three index ranges of `sorted` (3 cells each, contiguous
         // in x).  Their bounds are fetched together and the candidates are walked as ONE flattened list, 64 per
         // step: per query the dependent chain is bounds -> sorted index -> point, once, instead of once per row.
@@ -229,15 +233,15 @@ __global__ __launch_bounds__(kQWaves * 64) void bq_grid_query_kernel(int n, int 
             const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));   // as ballquery.hip
             if (__ballot(valid && d2 < B.thi_max) == 0ull) continue;
 #pragma unroll
-            for (int i = 0; i < kMaxBands; ++i) {
-                if (i >= B.nbands) break;
-                const bool hit = valid && (B.dilated ? (d2 == 0.0f || (d2 >= B.tlo[i] && d2 < B.thi[i])) : (d2 < B.thi[i]));
+            for (int i = 0; i < NB; ++i) {
+                const bool hit = valid && (DIL ? (d2 == 0.0f || (d2 >= B.tlo[i] && d2 < B.thi[i])) : (d2 < B.thi[i]));
                 const unsigned long long hall = __ballot(hit);
                 if (hall != 0ull) {
                     tot[i] += (int)__popcll(hall);
                     const bool take = hit && k <= tau[i];                  // beyond the bound: cannot be among the nsample smallest
                     const unsigned long long hm = __ballot(take);
-                    const int at = cnts[i] + __popcll(hm & ((1ull << lane) - 1ull));
+                    // lanes below me that take: v_mbcnt (two VALU instructions; the shift-and-popcount form was 64-bit arithmetic)
+                    const int at = cnts[i] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u));
                     if (take) hits[i][at] = k;                             // at < kCap: the list had >= 64 free entries
                     cnts[i] += (int)__popcll(hm);
                     if (cnts[i] > kCap - 64) {                             // no room for another step: keep the nsample smallest
@@ -250,8 +254,7 @@ __global__ __launch_bounds__(kQWaves * 64) void bq_grid_query_kernel(int n, int 
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int i = 0; i < kMaxBands; ++i) {
-            if (i >= B.nbands) break;
+        for (int i = 0; i < NB; ++i) {
             const int nsi = B.ns[i];
             if (cnts[i] > nsi) {                                           // more entries than outputs: cut to the smallest
                 keep_smallest(hits[i], cnts[i], nsi, lane);
@@ -347,8 +350,20 @@ extern "C" int sa_query_ball_point_grid(int b, int n, int m, int nbands, const f
     SA_CHECK_LAUNCH();
     int gx = (m + kQWaves - 1) / kQWaves;
     if (gx > 4096) gx = 4096;
-    hipLaunchKernelGGL(bq_grid_query_kernel, dim3(gx, b), dim3(kQWaves * 64), 0, stream, n, m, xyz1, xyz2,
-                       (const int *)workspace, B);
+#define SA_BQ_LAUNCH(NB_, DIL_)                                                                                         \
+    hipLaunchKernelGGL((bq_grid_query_kernel<NB_, DIL_>), dim3(gx, b), dim3(kQWaves * 64), 0, stream, n, m, xyz1, xyz2, \
+                       (const int *)workspace, B)
+    switch (nbands * 2 + (dilated ? 1 : 0)) {
+        case 2: SA_BQ_LAUNCH(1, false); break;
+        case 3: SA_BQ_LAUNCH(1, true); break;
+        case 4: SA_BQ_LAUNCH(2, false); break;
+        case 5: SA_BQ_LAUNCH(2, true); break;
+        case 6: SA_BQ_LAUNCH(3, false); break;
+        case 7: SA_BQ_LAUNCH(3, true); break;
+        case 8: SA_BQ_LAUNCH(4, false); break;
+        default: SA_BQ_LAUNCH(4, true); break;
+    }
+#undef SA_BQ_LAUNCH
     SA_CHECK_LAUNCH();
     return SA_OK;
 }
