@@ -167,12 +167,22 @@ __device__ __forceinline__ int keep_smallest(int *list, int H, int keep, int lan
 
 // NB / DIL: number of bands and the dilated form as COMPILE-TIME constants (round 5).  The kernel is bound by the CU's one
 // scalar pipe (PMC at the layer-1 shape: 1 070 scalar + 1 000 vector instructions per query on ring-structured frames,
-// 0.65 scalar instructions per cycle and CU): every run-time band test and form select was scalar work per band and step.
+// 0.65 scalar instructions per cycle and CU): every run-time band test and form select was scalar work per band and step,
+// and so is the per-band bookkeeping (ballot -> branch -> popcount -> list append -> overflow test) when it runs for every
+// band at every 64-candidate step.  So a step only APPENDS its hits -- of any band -- to ONE list per query, as
+// `index | band mask << 27` (band membership is vector arithmetic on the lane's own d2: no ballots), and the per-band
+// lists with their in-place cut are fed from that list in batches: when it is nearly full, and at the end of the walk.
+// A query with 54 hits among 290 candidates (ring-structured frames) runs the per-band code once per band instead of
+// 4.5 times, a sparse one (1-10 hits) skips it for the bands that got nothing.
+constexpr int kListCap = 256;            // entries of the per-query hit list (flushed into the band lists beyond kListCap - 64)
+constexpr int kMaskShift = 27;           // host: n <= 2^27
+
 template <int NB, bool DIL>
-__global__ __launch_bounds__(kQWaves * 64) void bq_grid_query_kernel(int n, int m, const float *__restrict__ xyz1,
+__global__ __launch_bounds__(kQWaves * 64, 8) void bq_grid_query_kernel(int n, int m, const float *__restrict__ xyz1,
                                                                      const float *__restrict__ xyz2,
                                                                      const int *__restrict__ ws, GBands B) {
     __shared__ int s_hits[kQWaves][NB][kCap];
+    __shared__ int s_list[kQWaves][kListCap];
     int b = blockIdx.y, bx = blockIdx.x;
     if ((gridDim.x & 7) == 0 && (gridDim.y & 7) == 0) {
         // XCD-aware (block L is observed to run on XCD L % 8, sa_common.h): the queries of frame f run on XCD f % 8, whose L2
@@ -188,6 +198,7 @@ __global__ __launch_bounds__(kQWaves * 64) void bq_grid_query_kernel(int n, int 
     const float *params = (const float *)(sorted + n);
     const float mnx = params[0], mnz = params[1], inv = params[2];
     int (*hits)[kCap] = s_hits[w];
+    int *list = s_list[w];
 
     for (int q = bx * kQWaves + w; q < m; q += gridDim.x * kQWaves) {
         const size_t qi = (size_t)b * m + q;
@@ -198,9 +209,39 @@ __global__ __launch_bounds__(kQWaves * 64) void bq_grid_query_kernel(int n, int 
         int cnts[NB], tot[NB], tau[NB];            // entries in the band's LDS list | hits so far (pts_cnt = min(tot, nsample)) | admission bound once a list was cut
 #pragma unroll
         for (int i = 0; i < NB; ++i) { cnts[i] = 0; tot[i] = 0; tau[i] = 0x7FFFFFFF; }
+        int nlist = 0;                             // entries in the per-query hit list
+        // the hit list -> the per-band lists: band i takes the entries that carry its bit, 64 per step, with the same
+        // bookkeeping the walk used to do per candidate step (total count, admission bound, in-place cut when nearly full)
+        auto flush = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (int c0 = 0; c0 < nlist; c0 += 64) {
+                const bool live = c0 + lane < nlist;
+                const int e = live ? list[c0 + lane] : 0;
+                const int k = e & ((1 << kMaskShift) - 1);
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const bool hit = live && ((e >> (kMaskShift + i)) & 1) != 0;
+                    const unsigned long long hall = __ballot(hit);
+                    if (hall != 0ull) {
+                        tot[i] += (int)__popcll(hall);
+                        const bool take = hit && k <= tau[i];              // beyond the bound: cannot be among the nsample smallest
+                        const unsigned long long hm = __ballot(take);
+                        const int at = cnts[i] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u));
+                        if (take) hits[i][at] = k;                         // at < kCap: the list had >= 64 free entries
+                        cnts[i] += (int)__popcll(hm);
+                        if (cnts[i] > kCap - 64) {                         // no room for another step: keep the nsample smallest
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            tau[i] = keep_smallest(hits[i], cnts[i], B.ns[i], lane);
+                            cnts[i] = B.ns[i];
+                        }
+                    }
+                }
+            }
+            nlist = 0;
+        };
         // the three z-rows of the 3 x 3 neighbourhood are three index ranges of `sorted` (3 cells each, contiguous
         // in x).  Their bounds are fetched together and the candidates are walked as ONE flattened list, 64 per
-        // step: per query the dependent chain is bounds -> sorted index -> point, once, instead of once per row.
+        // step: per query the dependent chain is bounds -> cell list, once, instead of once per row.
         int rs[3], rc[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -212,9 +253,8 @@ __global__ __launch_bounds__(kQWaves * 64) void bq_grid_query_kernel(int n, int 
             rc[r] = in ? e - s : 0;
         }
         const int c01 = rc[0] + rc[1], T = c01 + rc[2];
-        // Round 5: a step reads its 64 candidates (point + index, 16 bytes each, consecutive in the cell lists) with ONE
-        // coalesced load, requested one step ahead of its use: the LDS list updates and ballots of the loop body keep the
-        // compiler from overlapping the steps by itself.
+        // a step reads its 64 candidates (point + index, 16 bytes each, consecutive in the cell lists) with ONE coalesced
+        // load, requested one step ahead of its use
         auto cand = [&](int base) -> float4 {              // lane's candidate of the step at `base` (clamped past T)
             const int j = base + lane;
             const int jj = j < T ? j : 0;
@@ -228,30 +268,26 @@ __global__ __launch_bounds__(kQWaves * 64) void bq_grid_query_kernel(int n, int 
             const float4 cur = nxt;
             if (base + 64 < T) nxt = cand(base + 64);       // (wave-uniform: a one-step query requests nothing ahead)
             const int k = __float_as_int(cur.w);
-            const float cxp = cur.x, cyp = cur.y, czp = cur.z;
-            const float dx = x2 - cxp, dy = y2 - cyp, dz = z2 - czp;
+            const float dx = x2 - cur.x, dy = y2 - cur.y, dz = z2 - cur.z;
             const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));   // as ballquery.hip
-            if (__ballot(valid && d2 < B.thi_max) == 0ull) continue;
+            // band membership of this lane's candidate as a bit mask: the same comparisons as ballquery.hip, as 0 / 1 integers
+            unsigned mask = 0u;
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                const bool hit = valid && (DIL ? (d2 == 0.0f || (d2 >= B.tlo[i] && d2 < B.thi[i])) : (d2 < B.thi[i]));
-                const unsigned long long hall = __ballot(hit);
-                if (hall != 0ull) {
-                    tot[i] += (int)__popcll(hall);
-                    const bool take = hit && k <= tau[i];                  // beyond the bound: cannot be among the nsample smallest
-                    const unsigned long long hm = __ballot(take);
-                    // lanes below me that take: v_mbcnt (two VALU instructions; the shift-and-popcount form was 64-bit arithmetic)
-                    const int at = cnts[i] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u));
-                    if (take) hits[i][at] = k;                             // at < kCap: the list had >= 64 free entries
-                    cnts[i] += (int)__popcll(hm);
-                    if (cnts[i] > kCap - 64) {                             // no room for another step: keep the nsample smallest
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        tau[i] = keep_smallest(hits[i], cnts[i], B.ns[i], lane);
-                        cnts[i] = B.ns[i];
-                    }
-                }
+                unsigned bit;
+                if (DIL) bit = ((d2 >= B.tlo[i] ? 1u : 0u) & (d2 < B.thi[i] ? 1u : 0u)) | (d2 == 0.0f ? 1u : 0u);
+                else bit = d2 < B.thi[i] ? 1u : 0u;
+                mask |= bit << i;
             }
+            mask = valid ? mask : 0u;
+            const unsigned long long hm = __ballot(mask != 0u);
+            if (hm == 0ull) continue;
+            const int at = nlist + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u));
+            if (mask != 0u) list[at] = k | (int)(mask << kMaskShift);           // at < kListCap: the list had >= 64 free entries
+            nlist += (int)__popcll(hm);
+            if (nlist > kListCap - 64) flush();
         }
+        flush();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -269,9 +305,7 @@ __global__ __launch_bounds__(kQWaves * 64) void bq_grid_query_kernel(int n, int 
                 // rank of every hit among the hits of this band; the nsample smallest indices fill slots 0..c-1
                 int kmin = 0x7FFFFFFF;
                 if (H <= 64) {
-                    // the usual case: one hit per lane, the others' values broadcast through v_readlane (an SGPR) instead of
-                    // an LDS round trip per comparison -- the rank loop was a chain of H dependent LDS reads (~100 cycles
-                    // each: 54 per query on ring-structured frames, 128 on dense ones; round 5)
+                    // the usual case: one hit per lane, the others' values broadcast through v_readlane (an SGPR)
                     const int k = lane < H ? hits[i][lane] : 0x7FFFFFFF;
                     int rank = 0;
                     for (int j = 0; j < H; ++j) rank += __builtin_amdgcn_readlane(k, j) < k ? 1 : 0;
@@ -327,7 +361,7 @@ extern "C" int sa_query_ball_point_grid(int b, int n, int m, int nbands, const f
     // the per-query hit lists (LDS) hold kCap entries per band and must keep nsample of them plus one step of 64:
     // larger nsample goes to the plain scan kernels (found by tests/fuzz_ops.py: nsample = 300 rows were cut at 256)
     for (int i = 0; i < nbands; ++i)
-        if (ns[i] > kCap - 64) return sa_query_ball_point_multi(b, n, m, nbands, rmin, rmax, ns, dilated, xyz1, xyz2, idx, cnt, stream);
+        if (ns[i] > kCap - 64 || n > (1 << kMaskShift)) return sa_query_ball_point_multi(b, n, m, nbands, rmin, rmax, ns, dilated, xyz1, xyz2, idx, cnt, stream);
     GBands B;
     B.nbands = nbands;
     B.dilated = dilated ? 1 : 0;
