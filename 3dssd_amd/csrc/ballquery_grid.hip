@@ -382,8 +382,15 @@ extern "C" int sa_query_ball_point_grid(int b, int n, int m, int nbands, const f
     const float cell_min = rmax_all * 1.0001f + 1e-6f;
     hipLaunchKernelGGL(bq_grid_build_kernel, dim3(b), dim3(1024), 0, stream, n, cell_min, xyz1, (int *)workspace);
     SA_CHECK_LAUNCH();
-    int gx = (m + kQWaves - 1) / kQWaves;
+    // queries per wave: a wave's set-up (block -> frame mapping, the frame's grid parameters: a dependent scalar load) is
+    // paid once per wave; with enough work to fill the chip several times over, a wave takes kQPW queries
+    static const int qpw = SA_KNOB("SA_BQ_QPW", 8);
+    const long waves_total = (long)b * ((m + kQWaves - 1) / kQWaves) * kQWaves;
+    int per_wave = qpw;                                                   // ... while >= 4 rounds of the chip's 8192 wave slots remain
+    while (per_wave > 1 && waves_total / per_wave < 4l * 8192) per_wave >>= 1;
+    int gx = (m + kQWaves * per_wave - 1) / (kQWaves * per_wave);
     if (gx > 4096) gx = 4096;
+    if (gx > 8) gx = (gx + 7) & ~7;                                       // multiples of 8: the XCD-aware frame mapping
 #define SA_BQ_LAUNCH(NB_, DIL_)                                                                                         \
     hipLaunchKernelGGL((bq_grid_query_kernel<NB_, DIL_>), dim3(gx, b), dim3(kQWaves * 64), 0, stream, n, m, xyz1, xyz2, \
                        (const int *)workspace, B)
