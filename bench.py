@@ -13,11 +13,16 @@ package's own (3dssd_amd/pipeline.py, SAPipeline): a step = one block copy of th
 16 consecutive batches form a package that runs as two captured hipGraphs on three HIP streams (layer-1 sampling stage
 on a sampler stream, the rest on one of two main streams) -- all inside the timed region.  (The layer-1 D-FPS is a
 serial chain that keeps one CU per frame busy: throughput comes from the sampling stage of one package running beside
-the chip-filling kernels of others.)  Before the warm-up steps the executor is primed (every slot replayed twice,
->= 150 ms of work), independent of --warmup.  The timed region is bracketed by barrier + synchronize on both sides and
-all K steps complete inside it.  After it, --verify batches go through the same pipeline again and every output is
+the chip-filling kernels of others.)  Order of a run: priming (every slot replayed twice, >= 150 ms of work, independent
+of --warmup) -> W warm-up steps -> dress rehearsals (the timed sequence itself, untimed, >= 3 times and on until the last
+three agree within 6 %: first-use costs and a host / device disturbance land there, not in the measurement) -> barrier +
+synchronize -> EXACTLY K steps -> synchronize + barrier; all K steps complete inside the bracket.  The host sleeps through
+most of a window (blocking HIP events in front of the contract's torch.cuda.synchronize()) and the cyclic GC is frozen: a
+process under a CPU quota that spins is frozen by the kernel scheduler for the rest of a 100 ms period (measured,
+DESIGN.md section 5).  After the bracket, --verify batches go through the same pipeline again and every output is
 compared bit for bit with the eager single-stream result of the same batch.  Rank 0 prints ONE JSON line: `config`
-carries the executor and what decides a short run (queues, priming, the device-side timeline of the timed packages),
+starts with flat scalars that say what decided a short run (timed / probe / rehearsal windows, per-call host stamps,
+page faults, context switches, cgroup quota and throttle counts, package timeline),
 `roofline` describes the kernel with the largest share of GPU time, `stages` every C-ABI call, `cpu_baseline` the CPU
 oracle timed on this host on a bounded sample of the same workload.
 """
