@@ -366,7 +366,19 @@ int sa_wide128_try(int b, int n, int m, int ns, int c, const float *xyz, const f
     (void)hipFuncSetAttribute((const void *)group_mlp_wide128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipGetLastError();
     const long nitems = (max_tiles + kRT - 1) / kRT;
-    const int grid = (int)(nitems < 16384 ? (nitems > 0 ? nitems : 1) : 16384);
+    // a PERSISTENT grid, one workgroup per CU (150 KB of LDS: no second one fits): until round 5 the grid was one
+    // workgroup per item of the densest plan (16 384 at 128 frames for 6 100 real items), so every item started cold --
+    // its row references (two dependent global round trips) and biases with nothing to overlap them -- and the
+    // "resolved one item ahead" prefetch in the kernel never had a next item.  SA_W96_GRID (tuning build) = workgroups.
+    static const int grid_knob = SA_KNOB("SA_W96_GRID", 0);
+    int cus = 256;
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        (void)hipGetLastError();
+    }
+    const long cap = grid_knob > 0 ? grid_knob : cus;
+    const int grid = (int)(nitems < cap ? (nitems > 0 ? nitems : 1) : cap);
     hipLaunchKernelGGL(group_mlp_wide128_kernel, dim3(grid), dim3(kThreads), lds, stream, P);
     *st = hipGetLastError() == hipSuccess ? SA_OK : SA_ERR_LAUNCH;
     return 1;
