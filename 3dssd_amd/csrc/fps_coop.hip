@@ -55,6 +55,7 @@ __global__ __launch_bounds__(kBlock) void fps_coop_kernel(int n, int m, int gshi
                                                           int out_stride, int idx_off, int *err_word, unsigned max_spin) {
     __shared__ float s_val[2][kWaves];
     __shared__ unsigned s_key[2][kWaves];
+    __shared__ int s_old[2];
     const int G = 1 << gshift;
     const int f = blockIdx.x >> gshift, g = blockIdx.x & (G - 1);
     const float *p = inp + (size_t)f * n * C;
@@ -120,25 +121,35 @@ __global__ __launch_bounds__(kBlock) void fps_coop_kernel(int n, int m, int gshi
                 ((unsigned long long)__float_as_uint(M) << 32) | ((unsigned long long)(unsigned)it << 16) | wkey;
             __hip_atomic_store(sl + par * G + g, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        // every wave polls the G slots of this pick itself (no second barrier)
-        const unsigned long long *sp = sl + par * G + (lane & (G - 1));
-        unsigned long long wv;
-        unsigned spins = 0;
-        for (;;) {
-            wv = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const bool ok = (((unsigned)wv >> 16) & 0xFFFFu) == (unsigned)it;
-            if (__ballot(ok) == ~0ull) break;
-            if (++spins > max_spin) {                  // partners lost: sticky error + leave (every wave of the frame's
-                sa::coop_raise(err_word, sa::kCoopErrFps);   // workgroups runs into the same bound; a finished wave
-                return;                                //  no longer counts at the workgroup barrier)
+        // ONE wave polls the G slots of this pick and hands the winner to the others through LDS + a second barrier
+        // (round 5; until then every wave polled: 16 x G loads per poll round on the same lines of the coherence point).
+        if (w == 0) {
+            const unsigned long long *sp = sl + par * G + (lane & (G - 1));
+            unsigned long long wv;
+            unsigned spins = 0;
+            int winner = -1;                           // -1: partners lost
+            for (;;) {
+                wv = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool ok = (((unsigned)wv >> 16) & 0xFFFFu) == (unsigned)it;
+                if (__ballot(ok) == ~0ull) {
+                    const float gv = __uint_as_float((unsigned)(wv >> 32));
+                    const float GM = sa::row16_allmax(gv);
+                    const unsigned gk = (gv == GM) ? ((unsigned)wv & 0xFFFFu) : 0xFFFFFFFFu;
+                    const unsigned kmin = sa::row16_allmin_u32(gk);
+                    winner = __builtin_amdgcn_readfirstlane((int)(((kmin & 63u) << 10) | (kmin >> 6)));
+                    break;
+                }
+                if (++spins > max_spin) {              // partners lost: sticky error word, and every wave of the workgroup leaves
+                    sa::coop_raise(err_word, sa::kCoopErrFps);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
             }
-            __builtin_amdgcn_s_sleep(1);
+            if (lane == 0) s_old[par] = winner;
         }
-        const float gv = __uint_as_float((unsigned)(wv >> 32));
-        const float GM = sa::row16_allmax(gv);
-        const unsigned gk = (gv == GM) ? ((unsigned)wv & 0xFFFFu) : 0xFFFFFFFFu;
-        const unsigned kmin = sa::row16_allmin_u32(gk);
-        old = __builtin_amdgcn_readfirstlane((int)(((kmin & 63u) << 10) | (kmin >> 6)));
+        __syncthreads();
+        old = s_old[par];
+        if (old < 0) return;
         if (g == 0 && t == 0) o[it] = old + idx_off;
     }
 }
