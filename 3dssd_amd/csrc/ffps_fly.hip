@@ -55,6 +55,8 @@ __global__ __launch_bounds__(kT) void ffps_fly_kernel(FlyArgs A) {
     __shared__ float s_val[2][kW];
     __shared__ unsigned s_key[2][kW];
     __shared__ float s_sq[2][kW];
+    __shared__ int s_old[2];
+    __shared__ float s_oldsq[2];
     const int G = 1 << A.gshift;
     const int f = blockIdx.x >> A.gshift, g = blockIdx.x & (G - 1);
     const float *px = A.xyz + (size_t)f * A.xyz_bs, *pf = A.feat + (size_t)f * A.feat_bs;
@@ -146,29 +148,41 @@ __global__ __launch_bounds__(kT) void ffps_fly_kernel(FlyArgs A) {
             const unsigned lo = ((unsigned)it << 16) | (t == 0 ? kw_u : 0u);
             __hip_atomic_store(mine + t, ((unsigned long long)hi << 32) | lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        // ---- frame: every wave polls the 2 G words of this pick itself (no second barrier)
-        const int nw = 2 * G;
-        const unsigned long long *sp = sl + (size_t)par * G * 2 + (lane < nw ? lane : 0);
-        unsigned long long wv;
-        unsigned spins = 0;
-        for (;;) {
-            wv = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const bool okw = ((((unsigned)wv) >> 16) & 0xFFFFu) == (unsigned)it;
-            if (__ballot(okw || lane >= nw) == ~0ull) break;
-            if (++spins > kMaxSpin) {                      // partners lost: sticky error word + leave (sa_common.h)
-                sa::coop_raise(A.err_word, sa::kCoopErrFfps);
-                return;
+        // ---- frame: ONE wave polls the 2 G words of this pick and hands (winner, |winner|^2) to the others through LDS + a
+        //      second barrier (round 5, as in fps_coop.hip: eight polling waves per workgroup fought over the same lines)
+        if (w == 0) {
+            const int nw = 2 * G;
+            const unsigned long long *sp = sl + (size_t)par * G * 2 + (lane < nw ? lane : 0);
+            unsigned long long wv;
+            unsigned spins = 0;
+            int winner = -1;                               // -1: partners lost
+            float wsq = 0.0f;
+            for (;;) {
+                wv = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool okw = ((((unsigned)wv) >> 16) & 0xFFFFu) == (unsigned)it;
+                if (__ballot(okw || lane >= nw) == ~0ull) {
+                    const bool isval = lane < nw && (lane & 1) == 0;   // even lanes: {max | pick | key}, odd: {|candidate|^2 | pick}
+                    const float gv = isval ? __uint_as_float((unsigned)(wv >> 32)) : -3.4e38f;
+                    const float GM = sa::row16_allmax(gv);
+                    const unsigned gk = sa::row16_allmin_u32((isval && gv == GM) ? ((unsigned)wv & 0xFFFFu) : 0xFFFFFFFFu);
+                    const unsigned gk_u = (unsigned)__builtin_amdgcn_readfirstlane((int)gk);
+                    const int gwin = (int)(gk_u & 63u);
+                    wsq = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)(unsigned)(wv >> 32), 2 * gwin + 1));
+                    winner = (int)(gk_u >> 6) + kPW * gwin;
+                    break;
+                }
+                if (++spins > kMaxSpin) {                  // partners lost: sticky error word (sa_common.h); every wave leaves below
+                    sa::coop_raise(A.err_word, sa::kCoopErrFfps);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
             }
-            __builtin_amdgcn_s_sleep(1);
+            if (lane == 0) { s_old[par] = winner; s_oldsq[par] = wsq; }
         }
-        const bool isval = lane < nw && (lane & 1) == 0;   // even lanes: {max | pick | key}, odd: {|candidate|^2 | pick}
-        const float gv = isval ? __uint_as_float((unsigned)(wv >> 32)) : -3.4e38f;
-        const float GM = sa::row16_allmax(gv);
-        const unsigned gk = sa::row16_allmin_u32((isval && gv == GM) ? ((unsigned)wv & 0xFFFFu) : 0xFFFFFFFFu);
-        const unsigned gk_u = (unsigned)__builtin_amdgcn_readfirstlane((int)gk);
-        const int gwin = (int)(gk_u & 63u);
-        sq_old = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)(unsigned)(wv >> 32), 2 * gwin + 1));
-        old = (int)(gk_u >> 6) + kPW * gwin;
+        __syncthreads();
+        old = s_old[par];
+        sq_old = s_oldsq[par];
+        if (old < 0) return;
         if (g == 0 && t == 0) o[it] = old + A.idx_off;
     }
     if (A.ctr && g == 0) {                                 // the picked points themselves (layers_util.py:116-119)
