@@ -255,7 +255,7 @@ def _fps_kernel_names(stage):
 
 def _pmc_traffic(stage):
     """HBM bytes per launch of the stage's kernel from the COMMITTED rocprofv3 PMC pass (profiles/, made by
-    tools/gpu_prof.sh + tools/summarize_prof.py: FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md +
+    tools/gpu_prof128.sh + tools/summarize_128f.py: FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md +
     WRITE_SIZE).  A snapshot keyed by kernel name, NOT collected in this run; (None, None) when absent."""
     d, rel = _profile_json()
     if d is None or not stage["kernel"].startswith("sa_f"):
