@@ -759,6 +759,15 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
     cfgs, syn = pkg("configs"), pkg("synthetic")
     arch = cfgs.KITTI_3DSSD_ARCH
     params = syn.random_backbone_params(arch)
+    quota = cgroup_cpu_quota()
+    graphs_note = None
+    if args.graphs is None:
+        # hipGraphs unless this process has less than two cores' worth of CPU quota: ROCm's graph runtime keeps a thread
+        # spinning (0.8 cores) for as long as graph work is pending, which a tight CFS quota turns into 50-90 ms freezes of the
+        # whole process (profiles/r05_stall_quota_final.txt); eager launches run at the same rate with 0.3 cores
+        args.graphs = 0 if (quota is not None and quota < 2.0) else 1
+        if not args.graphs:
+            graphs_note = "eager launches chosen: cgroup CPU quota %.2f cores < 2 (hipGraph replays keep a runtime thread spinning)" % quota
     use_graphs = bool(args.graphs) and graphs_ok
     P = pkg("pipeline")
     capture_error = None
@@ -972,7 +981,7 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
              ("frames_per_step_per_gpu", args.batch), ("data", args.data), ("pool_frames_per_gpu", nb * args.batch),
              ("inputs", "pinned host memory, copied per step (PCIe-inclusive)" if args.host_input else "resident in HBM"),
              ("slots", pipe.nslots), ("streams_used", pipe.streams_used()), ("hw_queues", P.hw_queues()),
-             ("graph_capture_error", capture_error), ("batches_per_replay", C), ("linear_graphs", pipe.linear_graphs),
+             ("graph_capture_error", capture_error), ("graphs_note", graphs_note), ("batches_per_replay", C), ("linear_graphs", pipe.linear_graphs),
              ("gc", "frozen across the timed bracket"), ("load_avg_1min", round(os.getloadavg()[0], 2)), ("host_cores", os.cpu_count()),
              ("sharding", "frame f -> rank f mod N, no data-path collective"),
              ("executor_note", EXECUTOR_NOTES[args.executor] % {"C": C, "B": args.batch, "n": pipe.nslots}),
@@ -1232,7 +1241,8 @@ def main():
     ap.add_argument("--hw-queues", type=int, default=None, help="GPU_MAX_HW_QUEUES for this run (default: unset for staged, = --streams for slots)")
     ap.add_argument("--verify", type=int, default=None, help="batches re-run through the pipeline and compared with eager (0: skip)")
     ap.add_argument("--profile-iters", type=int, default=3)
-    ap.add_argument("--graphs", type=int, default=1, help="1 (default): one captured hipGraph per slot; 0: eager launches")
+    ap.add_argument("--graphs", type=int, default=None, help="1: captured hipGraphs (the default); 0: eager launches on the same streams (same throughput; "
+                         "the default under a CPU quota below 2 cores: a process replaying hipGraphs burns 0.8 cores in a runtime thread while graph work is pending)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-executor", action="store_true", help="skip the secondary measurement with the other executor")
     ap.add_argument("--allow-knobs", action="store_true", help="run although SA_* / SA3D_* environment variables are set (recorded in the line)")
