@@ -213,6 +213,16 @@ __global__ __launch_bounds__(256) void copy_blocks_kernel(CopyJobs J) {
         job.dst[f * job.dst_fs + r * job.dst_rs + c] = job.src[f * job.src_fs + r * job.src_rs + c];
     }
 }
+// ---- the executor's package fill: up to 32 dense batches (equal size, 16-byte multiples) into consecutive parts of one
+//      buffer in ONE launch (3dssd_amd/pipeline.py: a submit only notes the source; the copies of a package used to be 16
+//      launches in front of its sampling stage)
+constexpr int kMaxBatches = 32;
+struct BatchSrcs { const float4 *src[kMaxBatches]; };
+__global__ __launch_bounds__(256) void copy_batches_kernel(BatchSrcs S, float4 *__restrict__ dst, long vec_per_batch) {
+    const float4 *__restrict__ s = S.src[blockIdx.y];
+    float4 *__restrict__ d = dst + (size_t)blockIdx.y * vec_per_batch;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < vec_per_batch; i += (long)gridDim.x * blockDim.x) d[i] = s[i];
+}
 }  // namespace
 
 // jobs: host array of njobs (<= 4) records of 9 longs {src, dst, frames, rows, cols, src_frame_stride,
@@ -238,6 +248,24 @@ extern "C" int sa_copy_blocks(int njobs, const long *jobs, hipStream_t stream) {
 }
 
 // lib/utils/tf_ops/sampling/tf_sampling.cpp:235  gatherpointLauncher(b,n,m,c,inp,idx,out)
+// n dense batches of `bytes_per_batch` bytes each (a multiple of 16; srcs[i] and dst 16-byte aligned) -> dst, back to back.
+extern "C" int sa_copy_batches(int n, const void *const *srcs, void *dst, long bytes_per_batch, hipStream_t stream) {
+    if (n < 1 || n > kMaxBatches || !srcs || !dst || bytes_per_batch <= 0 || (bytes_per_batch & 15) || ((uintptr_t)dst & 15))
+        return SA_ERR_INVALID;
+    BatchSrcs S{};
+    for (int i = 0; i < n; ++i) {
+        if (!srcs[i] || ((uintptr_t)srcs[i] & 15)) return SA_ERR_INVALID;
+        S.src[i] = (const float4 *)srcs[i];
+    }
+    const long vec = bytes_per_batch / 16;
+    long blocks = (vec + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(copy_batches_kernel, dim3((unsigned)blocks, n), dim3(256), 0, stream, S, (float4 *)dst, vec);
+    SA_CHECK_LAUNCH();
+    return SA_OK;
+}
+
 extern "C" int sa_gather_point(int b, int n, int m, int c, const float *inp, const int *idx, float *out,
                                hipStream_t stream) {
     if (b <= 0 || n <= 0 || m <= 0 || c <= 0 || !inp || !idx || !out) return SA_ERR_INVALID;

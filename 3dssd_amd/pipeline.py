@@ -35,6 +35,7 @@ round of a slot has its own flag word, zeroed on the slot's stream before the ro
 after it -- a ticket raises for ITS package only.  Nothing here is a collective: on a multi-GPU node every rank owns
 one pipeline and its share of the frames (sharding.py).
 """
+import ctypes
 import os
 import time
 import warnings
@@ -75,10 +76,11 @@ def hw_queues():
 
 class _Round:
     """One use of a slot: the package of up to `coalesce` batches that is launched together."""
-    __slots__ = ("slot", "fill", "size", "launched", "event", "flag", "outs")
+    __slots__ = ("slot", "fill", "size", "launched", "event", "flag", "outs", "srcs")
 
     def __init__(self, slot, flag):
         self.slot, self.fill, self.size, self.launched, self.event, self.flag, self.outs = slot, 0, 0, False, None, flag, []
+        self.srcs = []            # (part, tensor) of the batches whose copy into the slot's buffer waits for the launch
 
 
 class Ticket:
@@ -151,7 +153,7 @@ class Ticket:
 class _Slot:
     # graphs: {package size (batches): (stage-A graph or None, stage-B / whole graph)}; lists: {size: forward()'s lists}
     __slots__ = ("pipe", "index", "stream_a", "stream_b", "inp", "overflow", "graphs", "lists", "round", "last_event",
-                 "copier", "inp_ptr")
+                 "copy_batches", "src_ptrs", "inp_ptr")
 
 
 class SAPipeline:
@@ -245,8 +247,8 @@ class SAPipeline:
                 s.stream_a = s.stream_b = torch.cuda.Stream(device=dev)
             s.inp = torch.zeros(shape, dtype=torch.float32, device=dev)
             s.inp_ptr = s.inp.data_ptr()
-            s.copier = N.BlockCopy(self.batch, self.points, self.channels, (self.points * self.channels, self.channels),
-                                   (self.points * self.channels, self.channels), s.stream_a.cuda_stream)
+            s.copy_batches = N.lib().sa_copy_batches
+            s.src_ptrs = (ctypes.c_void_p * max(self.coalesce, 1))()
             s.overflow = torch.zeros(1, dtype=torch.int32, device=dev)
             s.round, s.last_event = None, None
             self.slots.append(s)
@@ -337,7 +339,9 @@ class SAPipeline:
     def submit(self, batch, out=None, sync_source=True):
         """Enqueue one batch [B, points, channels] fp32 (device tensor; a pinned host tensor is copied
         asynchronously).  Returns immediately.  sync_source=False skips the event that orders the copy behind the
-        stream that produced `batch` (for inputs known to be complete, e.g. a resident pool).
+        stream that produced `batch` (for inputs known to be complete, e.g. a resident pool); such a batch is copied when
+        its PACKAGE is launched (one launch for the whole package), so it must stay unchanged until then -- the executor
+        keeps the tensor alive, the caller may drop its reference at once.
         out = (xyz [B,m,3], feat [B,m,C]): the results are additionally copied there on the slot's stream.
         With coalesce > 1 the package is launched by the submit that fills it (or by flush / drain / result)."""
         T.require(isinstance(batch, torch.Tensor) and tuple(batch.shape) == (self.batch, self.points, self.channels),
@@ -351,13 +355,14 @@ class SAPipeline:
             self._flag_next = (self._flag_next + 1) % _FLAG_RING
         part = r.fill
         st = s.stream_a
-        fast = batch.is_cuda and batch.is_contiguous() and not sync_source
+        fast = (batch.is_cuda and batch.is_contiguous() and not sync_source and (batch.data_ptr() & 15) == 0 and
+                (self._part_bytes & 15) == 0)
         if fast:
-            # resident, dense, already complete: one C call on the slot's stream, descriptor and pointers prepared at
-            # set-up (no stream context, no event: 8 us of host time per batch instead of 25)
+            # resident, dense, already complete: the submit only NOTES the source (the round keeps the tensor alive); the
+            # package is filled by ONE sa_copy_batches launch in front of its sampling stage (_launch) -- 16 copy launches
+            # and 25 us of host time each sat there before round 5
             T.require(batch.device == self.device, "batch lives on %s, the pipeline on %s" % (batch.device, self.device))
-            batch.record_stream(st)           # the caller may drop `batch` now: its block is not reused before the copy ran
-            s.copier.copy(batch.data_ptr(), s.inp_ptr + part * self._part_bytes)
+            r.srcs.append((part, batch))
         else:
             dst = s.inp[part * self.batch:(part + 1) * self.batch]
             with torch.cuda.device(self.device):
@@ -401,6 +406,22 @@ class SAPipeline:
         with torch.cuda.device(self.device):
             a, b = s.stream_a, s.stream_b
             marks = []
+            if r.srcs:                            # the deferred input copies of this package: one launch for a run of parts
+                srcs, r.srcs = r.srcs, []
+                i = 0
+                while i < len(srcs):
+                    j = i
+                    while j + 1 < len(srcs) and srcs[j + 1][0] == srcs[j][0] + 1 and j + 1 - i < 32:     # sa_copy_batches: <= 32 per launch
+                        j += 1
+                    n = j - i + 1
+                    for q in range(n):
+                        s.src_ptrs[q] = srcs[i + q][1].data_ptr()
+                    N.check(s.copy_batches(n, s.src_ptrs, s.inp_ptr + srcs[i][0] * self._part_bytes, self._part_bytes, a.cuda_stream),
+                            "copy_batches")
+                    i = j + 1
+                for _part, t in srcs:
+                    t.record_stream(a)            # the caller's tensor may be freed now: its block is not reused before the copy ran
+                stamp("launch:copy_batches")
             with torch.cuda.stream(a):
                 if tl:
                     marks.append(self._mark(a))

@@ -24,6 +24,7 @@ SIGNATURES = {
     "sa_fps_ex": [_c_int] * 4 + [_vp, _vp, _vp, _c_int, _c_int, _vp],
     "sa_fps_with_distance_ex": [_c_int] * 3 + [_vp, _vp, _vp, _c_int, _c_int, _vp],
     "sa_copy_blocks": [_c_int, _vp, _vp],
+    "sa_copy_batches": [_c_int, _vp, _vp, _c_long, _vp],
     "sa_fps_dual_ex": [_c_int] * 3 + [_vp, _vp, _c_int, _c_int, _vp, _c_long, _vp, _c_long, _c_int, _c_int, _vp, _c_long, _vp,
                        _c_int, _c_int, _vp, _c_long, _vp],
     "sa_group_mlp_max_layer": [_c_int] * 4 + [_vp, _c_int, _vp, _vp, _vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _vp,
@@ -165,25 +166,6 @@ def copy_blocks(jobs, stream=None):
         flat += [src.data_ptr(), dst.data_ptr(), frames, rows, cols, src.stride(0), src.stride(1), dst.stride(0), dst.stride(1)]
     arr = (ctypes.c_long * len(flat))(*flat)
     check(lib().sa_copy_blocks(len(jobs), arr, current_stream() if stream is None else stream), "copy_blocks")
-
-
-class BlockCopy:
-    """A one-job sa_copy_blocks call whose descriptor is built once and re-used (the executor's per-batch input copy: the
-    Python side of a submit was 25 us, most of it descriptor building and a stream context): copy(src_ptr, dst_ptr)."""
-    __slots__ = ("arr", "fn", "stream")
-
-    def __init__(self, frames, rows, cols, src_strides, dst_strides, stream):
-        self.arr = (ctypes.c_long * 9)(0, 0, frames, rows, cols, src_strides[0], src_strides[1], dst_strides[0], dst_strides[1])
-        self.fn = lib().sa_copy_blocks
-        self.stream = stream
-
-    def copy(self, src_ptr, dst_ptr):
-        a = self.arr
-        a[0] = src_ptr
-        a[1] = dst_ptr
-        st = self.fn(1, a, self.stream)
-        if st != 0:
-            check(st, "copy_blocks")
 
 
 def mlp_plan_ws(b, m, ns, device, c=None, dims=None):

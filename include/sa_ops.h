@@ -130,6 +130,9 @@ int sa_ffps_fly_ex(int b, int n, int c1, int m, const float *xyz, long xyz_bstri
  * src_frame_stride, src_row_stride, dst_frame_stride, dst_row_stride}, pointers as integers, strides in floats;
  * dst[f, r, 0:cols] = src[f, r, 0:cols]. */
 int sa_copy_blocks(int njobs, const long *jobs, sa_stream_t stream);
+/* Up to 32 dense batches of bytes_per_batch bytes each (a multiple of 16; pointers 16-byte aligned) copied back to back
+ * into dst in one launch: the executor's package fill (3dssd_amd/pipeline.py). */
+int sa_copy_batches(int n, const void *const *srcs, void *dst, long bytes_per_batch, sa_stream_t stream);
 /* Forces the global-scratch kernels (mode 0: points [b,n,c], mode 1: matrix [b,n,n]); test hook. */
 int sa_fps_generic(int b, int n, int c, int m, const float *inp, float *temp, int *out, int mode,
                    sa_stream_t stream);
