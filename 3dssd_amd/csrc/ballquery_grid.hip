@@ -42,12 +42,15 @@ struct GBands {
 __device__ __forceinline__ float wave_allmin_f(float x) { return -sa::wave_allmax(-x); }
 
 // workspace per frame (in ints): cell_start[kNC + 1] (+3 padding) | sorted[n] float4 = (x, y, z, index bits) in cell
-// order | params[4] floats (minx, minz, inv, 0).  Round 5: the cell lists hold the POINTS, not their indices -- a query's
+// order | params[4] floats (minx, minz, inv, cell size).  Round 5: the cell lists hold the POINTS, not their indices -- a query's
 // chain was bounds -> sorted index -> point (a scattered 12-byte gather); it is now bounds -> one coalesced 16-byte read.
 constexpr int kCellInts = kNC + 4;
 __host__ __device__ __forceinline__ size_t ws_stride(int n) { return (size_t)kCellInts + 4 * (size_t)n + 4; }
 
-__global__ __launch_bounds__(1024) void bq_grid_build_kernel(int n, float cell_min, const float *__restrict__ xyz1,
+// reuse != 0: the workspace is stated to hold the grid of these very points from an earlier call; it is kept if its cells
+// are at least cell_min wide (params[3] = the cell size it was built with), rebuilt otherwise -- decided here, on the
+// device, because the cell size depends on the frame's extent.
+__global__ __launch_bounds__(1024) void bq_grid_build_kernel(int n, float cell_min, int reuse, const float *__restrict__ xyz1,
                                                              int *__restrict__ ws) {
     __shared__ int s_cnt[kNC];
     __shared__ float s_red[4][16];
@@ -57,6 +60,7 @@ __global__ __launch_bounds__(1024) void bq_grid_build_kernel(int n, float cell_m
     int *cell_start = ws + (size_t)b * ws_stride(n);
     float4 *sorted = (float4 *)(cell_start + kCellInts);
     float *params = (float *)(sorted + n);
+    if (reuse && params[3] >= cell_min) return;          // (the same word for every thread of the workgroup)
 
     float mnx = 3e38f, mxx = -3e38f, mnz = 3e38f, mxz = -3e38f;
     for (int k = tid; k < n; k += 1024) {
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(1024) void bq_grid_build_kernel(int n, float cell_m
     float cs = sa::fmax_nn(cell_min, sa::fmax_nn(mxx - mnx, mxz - mnz) / (float)(kNX - 2));
     cs = sa::fmax_nn(cs, 1e-20f);
     const float inv = 1.0f / cs;
-    if (tid == 0) { params[0] = mnx; params[1] = mnz; params[2] = inv; params[3] = 0.0f; }
+    if (tid == 0) { params[0] = mnx; params[1] = mnz; params[2] = inv; params[3] = cs; }
 
     for (int k = tid; k < n; k += 1024) {
         const int cx = min(kNX - 1, max(0, (int)((p[k * 3 + 0] - mnx) * inv)));
@@ -353,9 +357,12 @@ extern "C" int sa_query_ball_point_multi(int b, int n, int m, int nbands, const 
 
 // Same contract as sa_query_ball_point_multi (all bands of one SA layer), through the grid.  `workspace` is
 // caller-owned device memory of sa_query_ball_point_grid_ws_bytes(b, n, m) bytes.  nbands <= 4.
-extern "C" int sa_query_ball_point_grid(int b, int n, int m, int nbands, const float *rmin, const float *rmax,
-                                        const int *ns, int dilated, const float *xyz1, const float *xyz2,
-                                        int *const *idx, int *const *cnt, void *workspace, hipStream_t stream) {
+// flags bit 0: `workspace` still holds the grid an earlier call of this function built over the SAME xyz1 contents (same b, n)
+// and that call is ordered before this one: the build is skipped when that grid's cells are wide enough for these radii
+// (checked on the device), e.g. the per-band calls of the reference's stand-alone ops over one point set.
+extern "C" int sa_query_ball_point_grid_ex(int b, int n, int m, int nbands, const float *rmin, const float *rmax,
+                                           const int *ns, int dilated, const float *xyz1, const float *xyz2,
+                                           int *const *idx, int *const *cnt, void *workspace, int flags, hipStream_t stream) {
     if (b <= 0 || n <= 0 || m <= 0 || nbands <= 0 || nbands > kMaxBands || !xyz1 || !xyz2 || !idx || !cnt || !workspace)
         return SA_ERR_INVALID;
     // the per-query hit lists (LDS) hold kCap entries per band and must keep nsample of them plus one step of 64:
@@ -380,7 +387,7 @@ extern "C" int sa_query_ball_point_grid(int b, int n, int m, int nbands, const f
         if (on && rmax[i] > rmax_all) rmax_all = rmax[i];
     }
     const float cell_min = rmax_all * 1.0001f + 1e-6f;
-    hipLaunchKernelGGL(bq_grid_build_kernel, dim3(b), dim3(1024), 0, stream, n, cell_min, xyz1, (int *)workspace);
+    hipLaunchKernelGGL(bq_grid_build_kernel, dim3(b), dim3(1024), 0, stream, n, cell_min, flags & 1, xyz1, (int *)workspace);
     SA_CHECK_LAUNCH();
     // queries per wave: a wave's set-up (block -> frame mapping, the frame's grid parameters: a dependent scalar load) is
     // paid once per wave; with enough work to fill the chip several times over, a wave takes kQPW queries
@@ -407,4 +414,10 @@ extern "C" int sa_query_ball_point_grid(int b, int n, int m, int nbands, const f
 #undef SA_BQ_LAUNCH
     SA_CHECK_LAUNCH();
     return SA_OK;
+}
+
+extern "C" int sa_query_ball_point_grid(int b, int n, int m, int nbands, const float *rmin, const float *rmax,
+                                        const int *ns, int dilated, const float *xyz1, const float *xyz2,
+                                        int *const *idx, int *const *cnt, void *workspace, hipStream_t stream) {
+    return sa_query_ball_point_grid_ex(b, n, m, nbands, rmin, rmax, ns, dilated, xyz1, xyz2, idx, cnt, workspace, 0, stream);
 }

@@ -44,6 +44,7 @@ SIGNATURES = {
     "sa_calc_square_dist_split_ws": [_c_int] * 5 + [_vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sa_query_ball_point_multi": [_c_int] * 4 + [_vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _vp],
     "sa_query_ball_point_grid": [_c_int] * 4 + [_vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sa_query_ball_point_grid_ex": [_c_int] * 4 + [_vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _vp, _c_int, _vp],
     "sa_group_mlp_max": [_c_int] * 5 + [_vp] * 5 + [_c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp,
                          ctypes.c_size_t, _c_int, _vp, _vp],
     "sa_group_mlp_plan": [_c_int] * 3 + [_vp, _vp, _vp, _vp, _c_int, _vp, _vp, _c_int, _vp],

@@ -8,6 +8,7 @@ messages (lib/utils/tf_ops/grouping/tf_grouping.cpp:275-288,368-384,453-459).
 Rows of empty balls are zero-filled (the reference leaves them unwritten).
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -26,6 +27,30 @@ def _check_xyz(op, xyz1, xyz2):
 GRID_BALL_QUERY_MIN_N = 512
 
 
+# The reference calls the ball query once per radius over the same point set (layers_util.py:134-147): the grid of the
+# LAST point set queried is kept, so that the second and third band skip the build (a quarter of a call at 16384 points).
+# A hit needs the same tensor OBJECT (weak reference: a new tensor in a recycled allocation is a different object), the
+# same torch version counter (every in-place torch op bumps it), pointer, shape and stream, and no capture in progress
+# (a replay would skip the build over new contents).  Writes through a raw pointer by code outside torch are not seen:
+# SHARE_GRID = False switches the sharing off.
+SHARE_GRID = True
+_grid_of_last_call = None          # (weakref to xyz1, (version, data_ptr, shape, stream handle), workspace)
+
+
+def _grid_workspace(lib, xyz1, b, n, m, stream):
+    """-> (workspace tensor, flags of sa_query_ball_point_grid_ex)."""
+    global _grid_of_last_call
+    if not SHARE_GRID or torch.cuda.is_current_stream_capturing():
+        return torch.empty((lib.sa_query_ball_point_grid_ws_bytes(b, n, m) + 3) // 4, dtype=torch.int32, device=xyz1.device), 0
+    g = _grid_of_last_call
+    key = (xyz1._version, xyz1.data_ptr(), tuple(xyz1.shape), stream)
+    if g is not None and g[0]() is xyz1 and g[1] == key:
+        return g[2], 1
+    ws = torch.empty((lib.sa_query_ball_point_grid_ws_bytes(b, n, m) + 3) // 4, dtype=torch.int32, device=xyz1.device)
+    _grid_of_last_call = (weakref.ref(xyz1), key, ws)
+    return ws, 0
+
+
 def _ball_query_one_band(op, min_radius, max_radius, nsample, dilated, xyz1, xyz2):
     b, n, _ = xyz1.shape
     m = xyz2.shape[1]
@@ -33,12 +58,13 @@ def _ball_query_one_band(op, min_radius, max_radius, nsample, dilated, xyz1, xyz
     cnt = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
     lib = N.lib()
     if n >= GRID_BALL_QUERY_MIN_N:
-        ws = torch.empty((lib.sa_query_ball_point_grid_ws_bytes(b, n, m) + 3) // 4, dtype=torch.int32, device=xyz1.device)
-        st = lib.sa_query_ball_point_grid(b, n, m, 1, (ctypes.c_float * 1)(float(min_radius)),
-                                          (ctypes.c_float * 1)(float(max_radius)), (ctypes.c_int * 1)(int(nsample)),
-                                          1 if dilated else 0, xyz1.data_ptr(), xyz2.data_ptr(),
-                                          (ctypes.c_void_p * 1)(idx.data_ptr()), (ctypes.c_void_p * 1)(cnt.data_ptr()),
-                                          ws.data_ptr(), N.current_stream())
+        stream = N.current_stream()
+        ws, flags = _grid_workspace(lib, xyz1, b, n, m, stream)
+        st = lib.sa_query_ball_point_grid_ex(b, n, m, 1, (ctypes.c_float * 1)(float(min_radius)),
+                                             (ctypes.c_float * 1)(float(max_radius)), (ctypes.c_int * 1)(int(nsample)),
+                                             1 if dilated else 0, xyz1.data_ptr(), xyz2.data_ptr(),
+                                             (ctypes.c_void_p * 1)(idx.data_ptr()), (ctypes.c_void_p * 1)(cnt.data_ptr()),
+                                             ws.data_ptr(), flags, stream)
     elif dilated:
         st = lib.sa_query_ball_point_dilated(b, n, m, float(min_radius), float(max_radius), int(nsample),
                                              xyz1.data_ptr(), xyz2.data_ptr(), idx.data_ptr(), cnt.data_ptr(),

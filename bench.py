@@ -114,10 +114,10 @@ def _algorithmic(name, a):
     if name in ("sa_calc_square_dist_split", "sa_calc_square_dist_split_ws"):
         b, n, m, c0, c1 = a[0:5]
         return 2 * b * n * m * (c0 + c1), b * (n * m * 4 + (n + m) * (c0 + c1) * 4), "calc_square_dist n=%d c=%d" % (n, c0 + c1)
-    if name in ("sa_query_ball_point_multi", "sa_query_ball_point_grid"):
+    if name in ("sa_query_ball_point_multi", "sa_query_ball_point_grid", "sa_query_ball_point_grid_ex"):
         b, n, m, nb = a[0:4]
         ns = [a[6][i] for i in range(nb)]
-        return 8 * b * n * m, b * (n * 12 + m * 12 + sum(m * s * 4 + m * 4 for s in ns)), "ball_query%s n=%d m=%d bands=%d" % ("_grid" if name.endswith("grid") else "", n, m, nb)
+        return 8 * b * n * m, b * (n * 12 + m * 12 + sum(m * s * 4 + m * 4 for s in ns)), "ball_query%s n=%d m=%d bands=%d" % ("_grid" if "grid" in name else "", n, m, nb)
     if name == "sa_group_mlp_max":
         b, n, m, ns, c = a[0:5]
         nl = a[10]
@@ -1020,7 +1020,7 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
         plan_ms = sum(s["avg_ms"] * s["calls_per_step"] for s in stages if s["kernel"] == "sa_group_mlp_plan")
         mlp_ms = mlp_only_ms + plan_ms
         mlp_fl = sum(s["gflop"] * s["calls_per_step"] for s in mlp)
-        bq = [s for s in stages if s["kernel"] in ("sa_query_ball_point_multi", "sa_query_ball_point_grid")]
+        bq = [s for s in stages if s["kernel"] in ("sa_query_ball_point_multi", "sa_query_ball_point_grid", "sa_query_ball_point_grid_ex")]
         bq_ms = sum(s["avg_ms"] * s["calls_per_step"] for s in bq)
         bq_mb = sum(s["mbytes"] * s["calls_per_step"] for s in bq)
         gflop_step = sum(s["gflop"] * s["calls_per_step"] for s in stages if s["kernel"] in MFMA_CALLS)

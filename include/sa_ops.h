@@ -166,6 +166,12 @@ unsigned long sa_query_ball_point_grid_ws_bytes(int b, int n, int m);
 int sa_query_ball_point_grid(int b, int n, int m, int nbands, const float *rmin, const float *rmax, const int *ns,
                              int dilated, const float *xyz1, const float *xyz2, int *const *idx, int *const *cnt,
                              void *workspace, sa_stream_t stream);
+/* flags bit 0: `workspace` still holds the grid an earlier, stream-ordered call built over the SAME xyz1 contents (same
+ * b, n): kept if its cells are wide enough for these radii (decided on the device), rebuilt otherwise.  The per-band
+ * calls of the reference's stand-alone ops over one point set (tf_grouping.py:53-83) share one grid this way. */
+int sa_query_ball_point_grid_ex(int b, int n, int m, int nbands, const float *rmin, const float *rmax, const int *ns,
+                                int dilated, const float *xyz1, const float *xyz2, int *const *idx, int *const *cnt,
+                                void *workspace, int flags, sa_stream_t stream);
 
 /* One scale of pointnet_sa_module_msg fused: mask, group, concat [features, rel-xyz], nl x
  * (conv1x1 + folded BN + ReLU), max over nsample, empty-ball mask (layers_util.py:157-181).

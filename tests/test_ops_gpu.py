@@ -1238,3 +1238,48 @@ def test_multi_workgroup_sampler_under_capture_is_opt_in(gpu, oracle):
         torch.cuda.synchronize()
         outs[flags] = out.cpu().numpy()
     assert np.array_equal(outs[0], ref) and np.array_equal(outs[1], ref)
+
+
+@pytest.mark.gpu
+def test_stand_alone_band_calls_over_one_point_set_share_the_grid(gpu, oracle):
+    """tf_grouping.query_ball_point keeps the grid of the last point set: the per-band calls of the reference's
+    layers_util.py:134-147 build it once.  Results must not depend on it: ascending radii (a finer grid cannot serve a
+    wider band: rebuilt on the device), descending radii (a coarser grid serves a narrower band), contents changed in place
+    (torch's version counter), and a new tensor -- all equal to the oracle."""
+    G = pkg("utils.tf_ops.grouping.tf_grouping")
+    rng = np.random.default_rng(2025)
+    b, n, m = 3, 4096, 512
+    xyz1 = _cloud(rng, b, n, scale=4.0, dup=100)               # extent 8 m over 126 cells: cell size = the radius above 0.07
+    xyz2 = np.concatenate([xyz1[:, :400], _cloud(rng, b, m - 400, scale=5.0)], 1)
+    t1, t2 = _t(xyz1, gpu), _t(xyz2, gpu)
+    assert G.SHARE_GRID
+    for radii in ((0.2, 0.4, 0.8, 1.7), (1.7, 0.8, 0.4, 0.2), (0.4, 0.4, 3.0, 0.1)):
+        for r in radii:
+            idx, cnt = G.query_ball_point(r, 32, t1, t2)
+            ridx, rcnt = oracle.query_ball_point(r, 32, xyz1, xyz2)
+            _check_ball(idx.cpu().numpy(), cnt.cpu().numpy(), ridx, rcnt)
+        g = G._grid_of_last_call
+        assert g is not None and g[0]() is t1
+    idx, cnt = G.query_ball_point_dilated(0.4, 0.8, 16, t1, t2)            # the dilated form through the same grid
+    ridx, rcnt = oracle.query_ball_point_dilated(0.4, 0.8, 16, xyz1, xyz2)
+    _check_ball(idx.cpu().numpy(), cnt.cpu().numpy(), ridx, rcnt)
+    # contents replaced in place: same object, same pointer, new version
+    xyz1b = _cloud(rng, b, n, scale=4.0, dup=50)
+    t1.copy_(_t(xyz1b, gpu))
+    idx, cnt = G.query_ball_point(0.4, 32, t1, t2)
+    ridx, rcnt = oracle.query_ball_point(0.4, 32, xyz1b, xyz2)
+    _check_ball(idx.cpu().numpy(), cnt.cpu().numpy(), ridx, rcnt)
+    # a new tensor (possibly in the allocation the old one left)
+    del t1
+    xyz1c = _cloud(rng, b, n, scale=4.0, dup=10)
+    t1 = _t(xyz1c, gpu)
+    idx, cnt = G.query_ball_point(0.4, 32, t1, t2)
+    ridx, rcnt = oracle.query_ball_point(0.4, 32, xyz1c, xyz2)
+    _check_ball(idx.cpu().numpy(), cnt.cpu().numpy(), ridx, rcnt)
+    # and with the sharing switched off
+    G.SHARE_GRID = False
+    try:
+        idx2, cnt2 = G.query_ball_point(0.4, 32, t1, t2)
+    finally:
+        G.SHARE_GRID = True
+    assert torch.equal(idx, idx2) and torch.equal(cnt, cnt2)
