@@ -223,11 +223,11 @@ __global__ __launch_bounds__(256) void sqdist_mfma_kernel(int n, int m, RowSrc A
 //     the 16 row norms of a lane fetched with 4 ds_read_b128 per row tile.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 #ifdef SA_SQ_TIMING
-// debug build only (tools/sqdist_ab.py): phase clocks of wave 0 of every workgroup, summed
-__device__ unsigned long long g_sq_prof[8];
+// debug build only (tools/sqdist_prof.py): phase clocks of wave 0 of every workgroup, summed
+__device__ unsigned long long g_sq_prof[256][8];      // 256 slots (same-address atomics serialise: 67 000 workgroups x 7 words)
 #define SQ_T0() unsigned long long t__ = __builtin_readcyclecounter(), acc__[6] = {0, 0, 0, 0, 0, 0}
 #define SQ_TICK(i) { const unsigned long long n__ = __builtin_readcyclecounter(); acc__[i] += n__ - t__; t__ = n__; }
-#define SQ_FLUSH() if (tid == 0) { for (int i__ = 0; i__ < 6; ++i__) atomicAdd(&g_sq_prof[i__], acc__[i__]); atomicAdd(&g_sq_prof[7], 1ull); }
+#define SQ_FLUSH() if (tid == 0) { unsigned long long *g__ = g_sq_prof[(blockIdx.x + 31u * blockIdx.y + 97u * blockIdx.z) & 255u]; for (int i__ = 0; i__ < 6; ++i__) atomicAdd(&g__[i__], acc__[i__]); atomicAdd(&g__[7], 1ull); }
 #else
 #define SQ_T0()
 #define SQ_TICK(i)
@@ -652,6 +652,10 @@ __global__ __launch_bounds__(256, 4) void sqdist_mfma3_kernel(int n, int m, int 
     const int half = lane >> 5, col = lane & 31;
     const int S = (c + kKS2 - 1) / kKS2, Ta = npa / kMT, Tb = npb / kMT;
 
+    SQ_T0();
+#ifdef SA_SQ_TIMING
+    const unsigned long long wall0__ = wall_clock64();         // 100 MHz: the workgroup's lifetime in real time
+#endif
     f32x16 acc[2][2];
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
@@ -678,6 +682,7 @@ __global__ __launch_bounds__(256, 4) void sqdist_mfma3_kernel(int n, int m, int 
 #pragma unroll
         for (int i = 0; i < kCp; ++i) { dA[i * 256] = ra[i]; dB[i * 256] = rb[i]; }
         __syncthreads();
+        SQ_TICK(0)
         if (st + 1 < S) {                                  // next stage's images: in flight during the matrix work
             const f32x4v *nA = srcA + (size_t)(st + 1) * Ta * (kPackTile / 4), *nB = srcB + (size_t)(st + 1) * Tb * (kPackTile / 4);
 #pragma unroll
@@ -701,20 +706,33 @@ __global__ __launch_bounds__(256, 4) void sqdist_mfma3_kernel(int n, int m, int 
                 }
             }
         }
+        SQ_TICK(1)
     }
     __syncthreads();                               // operand planes dead -> norms and transpose patches
     if (tid < kMT) sA[tid] = nrm; else sB[tid - kMT] = nrm;
     __syncthreads();
     // full tiles (wave-uniform): both images in 256-byte row pieces; edge tiles: the scalar path of sq_store_tile
+    SQ_TICK(2)
     const bool full = i0 + kMT <= n && j0 + kMT <= m && (m & 3) == 0 && (!SYM || (n & 3) == 0);
     if (full) sq_store_full<SYM, NT>(&s_pl[0][0][0][0], sA, sB, acc, b, n, m, i0, j0, SYM && bi != bj, w, lane, out);
     else sq_store_tile<SYM, NT>(&s_pl[0][0][0][0], sA, sB, acc, b, n, m, i0, j0, SYM && bi != bj, w, lane, out);
+#ifdef SA_SQ_TIMING
+    SQ_TICK(3)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the stores' drain, which the wave's end waits for anyway
+    SQ_TICK(4)
+    acc__[5] = wall_clock64() - wall0__;
+    SQ_FLUSH()
+#endif
 }
 
 #ifdef SA_SQ_TIMING
 }  // namespace
 extern "C" int sa_debug_sq_prof(unsigned long long *host8, int reset) {
-    if (host8 && hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_sq_prof), sizeof(g_sq_prof)) != hipSuccess) return SA_ERR_LAUNCH;
+    if (host8) {
+        static unsigned long long all[256][8];
+        if (hipMemcpyFromSymbol(all, HIP_SYMBOL(g_sq_prof), sizeof(g_sq_prof)) != hipSuccess) return SA_ERR_LAUNCH;
+        for (int i = 0; i < 8; ++i) { host8[i] = 0; for (int sl = 0; sl < 256; ++sl) host8[i] += all[sl][i]; }
+    }
     if (reset) {
         void *d = nullptr;
         if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_sq_prof)) != hipSuccess) return SA_ERR_LAUNCH;
