@@ -215,6 +215,42 @@ def test_inputs_may_be_dropped_right_after_submit(gpu, pipe6):
         assert torch.equal(tk.result()[1], eager[i]), i
 
 
+@pytest.mark.parametrize("mode", ["staged", "slots"])
+def test_resident_inputs_are_copied_at_package_launch_by_one_launch(gpu, mode):
+    # round 5: submit(sync_source=False) only notes a resident, dense, 16-byte aligned batch; sa_copy_batches fills the
+    # package in front of its first stage.  Dropped inputs, a package mixing both kinds of submit (runs of parts broken by
+    # a copy made at submit), a misaligned view (copied at submit), and a partly filled package must all equal eager.
+    cfgs, syn = pkg("configs"), pkg("synthetic")
+    arch = cfgs.KITTI_3DSSD_ARCH
+    pipe = pkg("pipeline").SAPipeline(arch, syn.random_backbone_params(arch), gpu, batch=2, points=16384, streams=3,
+                                      coalesce=4, max_translate_range=cfgs.KITTI_MAX_TRANSLATE_RANGE, mode=mode)
+    host = _batches("default", 14, 2, first=1500)
+    eager = [pipe.forward_eager(torch.from_numpy(h).to(gpu))[1][-1].clone() for h in host]
+    torch.cuda.synchronize()
+    odd = torch.empty((2 * 16384 * 4 + 1,), dtype=torch.float32, device=gpu)       # a view 4 bytes off a 16-byte boundary
+    outs = [(torch.empty((2, 256, 3), device=gpu), torch.empty((2, 256, 512), device=gpu)) for _ in host]
+    tickets = []
+    for i, h in enumerate(host):
+        t = torch.from_numpy(h).to(gpu)
+        torch.cuda.synchronize()                       # "known to be complete": what sync_source=False promises
+        if i % 5 == 2:
+            tickets.append(pipe.submit(t, out=outs[i]))             # ordered behind the producing stream, copied at submit
+        elif i % 5 == 4:
+            v = odd[1:].view(2, 16384, 4)
+            v.copy_(t)
+            torch.cuda.synchronize()
+            assert v.data_ptr() % 16 == 4
+            tickets.append(pipe.submit(v, out=outs[i], sync_source=False))
+            torch.cuda.synchronize()                   # `odd` is reused by a later batch: its copy (at submit) has run
+        else:
+            tickets.append(pipe.submit(t, out=outs[i], sync_source=False))
+        del t                                          # the round keeps the tensor until the package's copy ran
+    assert not tickets[-1].done()                      # batches 12, 13: a package of four that holds two
+    for i, tk in enumerate(tickets):
+        assert torch.equal(tk.result()[1], eager[i]), i
+    pipe.drain()
+
+
 def test_pipeline_refuses_a_network_whose_sampler_must_stay_on_one_stream(gpu):
     # the on-the-fly F-FPS (csrc/ffps_fly.hip) spins on partner workgroups and needs all its launches
     # on one stream; the executor alternates that layer between its main streams, so it refuses such a network instead of
