@@ -41,6 +41,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 # (--executor slots asks for one hardware queue per slot -- pipeline.request_hw_queues, before the first CUDA call in
 # main(); the default staged executor runs on ROCm's default of 4 queues and sets nothing)
+# the host driver of these boxes supports dmabuf IPC only: without this RCCL's peer set-up (N > 1) fails with
+# "hipIpcGetMemHandle: invalid argument".  Already exported on the boxes; kept for a shell that lost it.  Not a kernel knob.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
 import torch
