@@ -46,6 +46,28 @@ __device__ __forceinline__ float4 cross_wave_pick(const float (*s_val)[kWaves],
     return r;
 }
 
+// The same for the distance-matrix sampler, which also wants the RUNNER-UP of the arg-max (the row to request early; it
+// never enters the result).  Every wave publishes its maximum AND its second maximum (over its other lanes; a lane's own
+// second-best point is not looked at): the runner-up is the largest of the other waves' maxima and the winner wave's second.
+// It must be exact across lanes: on FPS-ordered input (layer 2 samples the layer-1 picks) the next pick is nearly always
+// an index neighbour of the current one, i.e. in the SAME wave -- the best of the other waves predicts 5 % of the picks,
+// the true runner-up 90-96 % (tools/ffps_spec_hitrate.py).
+__device__ __forceinline__ int cross_wave_pick2(const float (*s_val)[kWaves], const float4 (*s_pt)[kWaves], int par, int lane,
+                                                int &c1) {
+    const int slot = lane & (kWaves - 1);
+    const float v = s_val[par][slot];
+    const float4 q = s_pt[par][slot];               // .x: the wave's second maximum, .y: its index, .w: index of the maximum
+    const int idx = __float_as_int(q.w), idx2 = __float_as_int(q.y);
+    const float M = sa::row16_allmax(v);
+    const int ws = __builtin_ctzll(__ballot(v == M)) & (kWaves - 1);       // lowest wave holding the maximum
+    const float r = slot == ws ? q.x : v;
+    const float R = sa::row16_allmax(r);
+    const int ws2 = __builtin_ctzll(__ballot(r == R)) & (kWaves - 1);
+    const int a = __builtin_amdgcn_readlane(idx, ws2), b2 = __builtin_amdgcn_readlane(idx2, ws);
+    c1 = ws2 == ws ? b2 : a;
+    return __builtin_amdgcn_readlane(idx, ws);
+}
+
 // Optional inputs/outputs of the *_ex2 entry points: a frame stride for `inp` (so that a range slice xyz[:, s:e] of a
 // larger tensor is sampled in place, no copy launch) and the picked points themselves (the gather_point that
 // layers_util.py:116-119 runs right after the sampler, fused into the sampler's epilogue: one launch less per layer).
@@ -182,13 +204,126 @@ __device__ __forceinline__ void fpsdist_reg_body(int n, int m, const float *__re
     }
     if (S.xyz) write_centres(S, S.xyz + (size_t)b * S.xyz_bstride, o, m, idx_off, b, t, kBlock);
 }
+#ifdef SA_FFPS_SPEC_STATS
+__device__ unsigned long long g_ffps_spec[4];   // debug build: [0] picks, [1] picks whose row was not the held one, [2] loop clocks, [3] workgroups
+#endif
+// ---- the same with the next pick's row requested AHEAD (matrices read from HBM, rows of <= 16 KB) ----
+// A pick waits one memory round trip for the row of the point just picked (0.8 of its 1.2 us at the layer-2 shape: the
+// 64 MB matrix of a frame lives in HBM).  Round 5: the NEXT pick is nearly always known one pick in advance -- it is the
+// runner-up of the current arg-max in 90-96 % of the picks (tools/ffps_spec_hitrate.py on backbone features of three data
+// variants; two picks ahead the prediction is worthless: 2-20 %).  So whenever a pick is made, the row of its runner-up
+// candidate is requested into a second set of registers; a pick whose row is held there has had one pick's time of its
+// latency hidden.  The VALUES are the matrix rows either way: results are bit-identical, only the waiting changes.
+// Extra HBM reads: one row per pick.
+// Used where it pays (host rule below): a matrix that fits the on-chip caches (layer 3: 1 MB per frame, rows answer in
+// 0.3 us) gains nothing and pays for the runner-up's second reduction (+6 %); rows of 32-64 KB (n > 4096) are bound by
+// the CU's load rate, not by latency (configs[2]: no change).
 template <int PPT>
+__device__ __forceinline__ void fpsdist_ahead_body(int n, int m, const float *__restrict__ dist, int *__restrict__ out,
+                                                 int out_stride, int idx_off, const FpsSide &S) {
+    __shared__ float s_val[2][kWaves];
+    __shared__ float4 s_pt[2][kWaves];
+    // the picks are collected in LDS and written out once: a store per pick from thread 0 sits, in order, between the row
+    // requests of its wave, and the wait for a held row then also waits for that store's acknowledgement
+    __shared__ int s_picks[kBlock * PPT];
+    const int b = blockIdx.x;
+    const float *D = dist + (size_t)b * n * n;
+    int *o = out + (size_t)b * out_stride;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+
+    float td[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) td[j] = (t + kBlock * j) < n ? kInit : kAbsent;
+    int old = 0;
+    if (t == 0) s_picks[0] = 0;
+    // Two register sets used in turn: pick `it` reads set (it & 1), whose row was requested at the START of the previous pick,
+    // and first of all requests the row of its own runner-up candidate into the other set -- so a held row has had a whole
+    // pick (its wait included) to arrive, and per pick the chain is (latency + arg-max) / 2 instead of their sum.  Order of
+    // the requests inside a pick: the row of this pick if it is not the held one (its set is idle: the request it replaces
+    // is waited for), THEN the candidate's row; the update then waits for all but the newest PPT loads -- on either path.
+    int heldA = -1, heldB = -1, c1 = 0;             // rows held in the two sets | runner-up of the arg-max that produced `old`
+    float svA[PPT], svB[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) { svA[j] = 0.0f; svB[j] = 0.0f; }
+    auto fetch = [&](float (&dst)[PPT], int r) {
+        const float *row = D + (size_t)r * n;       // tf_sampling_g.cu:202
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int k = t + kBlock * j;
+            dst[j] = row[k < n ? k : 0];            // (a thread without point k reads element 0: its slot stays kAbsent under
+                                                    //  the min below whatever it reads -- no branch around the load, and no select
+                                                    //  behind it, which would make the request wait for its own data)
+        }
+    };
+#ifdef SA_FFPS_SPEC_STATS
+    unsigned long long misses__ = 0, clk0__ = __builtin_readcyclecounter();
+#endif
+    auto pick = [&](float (&cur)[PPT], int &held_cur, float (&nxt)[PPT], int &held_nxt, int it) {
+#ifdef SA_FFPS_SPEC_STATS
+        misses__ += old != held_cur;
+#endif
+        if (old != held_cur) fetch(cur, old);
+        held_nxt = c1;
+        fetch(nxt, c1);
+        float best = -1.0f;
+        int bk = 0;                                 // besti starts at 0, :190-191
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            float t2 = sa::fmin_nn(cur[j], td[j]);
+            td[j] = t2;
+            bool g = t2 > best;
+            best = g ? t2 : best;
+            bk = g ? (t + kBlock * j) : bk;
+        }
+        const float wmax = sa::wave_allmax(best);
+        const unsigned long long cand = __ballot(best == wmax);
+        const int first = __builtin_ctzll(cand);
+        const int par = it & 1;
+        // the wave's second maximum: over the lanes other than the winning one
+        const float best2 = lane == first ? -__builtin_inff() : best;
+        const float w2max = sa::wave_allmax(best2);
+        const int sec = __builtin_ctzll(__ballot(best2 == w2max));
+        const int bk2 = __builtin_amdgcn_readlane(bk, sec);
+        if (lane == first) {
+            s_val[par][w] = wmax;
+            s_pt[par][w] = make_float4(w2max, __int_as_float(bk2), 0.f, __int_as_float(bk));
+        }
+        __syncthreads();
+        old = cross_wave_pick2(s_val, s_pt, par, lane, c1);
+        if (t == 0) s_picks[it] = old;
+    };
+    for (int it = 1; it < m; it += 2) {
+        pick(svB, heldB, svA, heldA, it);
+        if (it + 1 < m) pick(svA, heldA, svB, heldB, it + 1);
+    }
+#ifdef SA_FFPS_SPEC_STATS
+    if (t == 0) {
+        atomicAdd(&g_ffps_spec[0], (unsigned long long)(m - 1)); atomicAdd(&g_ffps_spec[1], misses__);
+        atomicAdd(&g_ffps_spec[2], __builtin_readcyclecounter() - clk0__); atomicAdd(&g_ffps_spec[3], 1ull);
+    }
+#endif
+    __syncthreads();
+    for (int i = t; i < m; i += kBlock) o[i] = s_picks[i] + idx_off;
+    if (S.ctr && S.xyz) {                           // the picked points themselves (write_centres, from the LDS copy)
+        const float *src = S.xyz + (size_t)b * S.xyz_bstride;
+        float *c = S.ctr + (size_t)b * S.ctr_bstride;
+        for (int i = t; i < m; i += kBlock) {
+            const int k = s_picks[i];
+            c[i * 3 + 0] = src[k * 3 + 0]; c[i * 3 + 1] = src[k * 3 + 1]; c[i * 3 + 2] = src[k * 3 + 2];
+        }
+    }
+}
+template <int PPT, bool AHEAD>
 __global__ __launch_bounds__(kBlock) void fpsdist_reg_kernel(int n, int m,
                                                              const float *__restrict__ dist,
                                                              int *__restrict__ out, int out_stride,
                                                              int idx_off, FpsSide S) {
-    fpsdist_reg_body<PPT>(n, m, dist, out, out_stride, idx_off, S);
+    if (AHEAD) fpsdist_ahead_body<PPT>(n, m, dist, out, out_stride, idx_off, S);
+    else fpsdist_reg_body<PPT>(n, m, dist, out, out_stride, idx_off, S);
 }
+// rows are requested ahead when the call's matrices exceed what the on-chip caches hold (the rule sqdist.hip uses for its
+// non-temporal stores: such a matrix is read from HBM) and a row is at most 16 KB
+static inline bool ffps_rows_ahead(int b, int n) { return n <= 4 * kBlock && (size_t)b * n * n * sizeof(float) > ((size_t)192 << 20); }
 
 // The two samplers of an 'FS' layer (layers_util.py:93-98) -- or of a layer whose two ranges use F-FPS and D-FPS
 // (:101-106) -- in ONE launch: blockIdx.y == 0 runs the matrix sampler, blockIdx.y == 1 the coordinate sampler.  They are
@@ -200,9 +335,12 @@ struct FpsDualArgs {
     int *out;
     FpsSide S;
 };
-template <int PPTF, int PPTD>
+template <int PPTF, int PPTD, bool AHEAD>
 __global__ __launch_bounds__(kBlock) void fps_dual_kernel(FpsDualArgs F, FpsDualArgs D) {
-    if (blockIdx.y == 0) fpsdist_reg_body<PPTF>(F.n, F.m, F.src, F.out, F.out_stride, F.idx_off, F.S);
+    if (blockIdx.y == 0) {
+        if (AHEAD) fpsdist_ahead_body<PPTF>(F.n, F.m, F.src, F.out, F.out_stride, F.idx_off, F.S);
+        else fpsdist_reg_body<PPTF>(F.n, F.m, F.src, F.out, F.out_stride, F.idx_off, F.S);
+    }
     else fps3_reg_body<PPTD>(D.n, D.m, D.src, D.out, D.out_stride, D.idx_off, D.S);
 }
 
@@ -509,8 +647,10 @@ extern "C" int sa_fps_with_distance_ex2(int b, int n, int m, const float *dist, 
     if (ppt <= 16) {
         FpsSide S{};
         S.ctr = ctr; S.ctr_bstride = ctr_bstride; S.xyz = ctr ? xyz : nullptr; S.xyz_bstride = xyz_bstride;
+        const bool ahead = ffps_rows_ahead(b, n);
         switch (ppt) {
-#define SA_FPSD(P) case P: hipLaunchKernelGGL(fpsdist_reg_kernel<P>, dim3(b), dim3(kBlock), 0, stream, n, m, dist, out, out_stride, idx_off, S); break;
+#define SA_FPSD(P) case P: if (ahead && P <= 4) hipLaunchKernelGGL((fpsdist_reg_kernel<P, P <= 4>), dim3(b), dim3(kBlock), 0, stream, n, m, dist, out, out_stride, idx_off, S); \
+                           else hipLaunchKernelGGL((fpsdist_reg_kernel<P, false>), dim3(b), dim3(kBlock), 0, stream, n, m, dist, out, out_stride, idx_off, S); break;
             SA_FPSD(1) SA_FPSD(2) SA_FPSD(4) SA_FPSD(8) SA_FPSD(16)
 #undef SA_FPSD
         }
@@ -546,11 +686,15 @@ extern "C" int sa_fps_dual_ex(int b, int nf, int mf, const float *dist, int *out
     F.S.ctr = ctr_f; F.S.ctr_bstride = ctr_bstride_f; F.S.xyz = ctr_f ? xyz_f : nullptr; F.S.xyz_bstride = xyz_bstride_f;
     D.n = nd; D.m = md; D.out_stride = out_stride_d; D.idx_off = idx_off_d; D.src = inp; D.out = out_d;
     D.S.in_bstride = in_bstride; D.S.ctr = ctr_d; D.S.ctr_bstride = ctr_bstride_d;
+    const bool ahead = ffps_rows_ahead(b, nf);
+#define SA_FPSDUAL(P) if (ahead) hipLaunchKernelGGL((fps_dual_kernel<P, P, true>), dim3(b, 2), dim3(kBlock), 0, stream, F, D); \
+                      else hipLaunchKernelGGL((fps_dual_kernel<P, P, false>), dim3(b, 2), dim3(kBlock), 0, stream, F, D)
     switch (pf) {
-        case 1: hipLaunchKernelGGL((fps_dual_kernel<1, 1>), dim3(b, 2), dim3(kBlock), 0, stream, F, D); break;
-        case 2: hipLaunchKernelGGL((fps_dual_kernel<2, 2>), dim3(b, 2), dim3(kBlock), 0, stream, F, D); break;
-        default: hipLaunchKernelGGL((fps_dual_kernel<4, 4>), dim3(b, 2), dim3(kBlock), 0, stream, F, D); break;
+        case 1: SA_FPSDUAL(1); break;
+        case 2: SA_FPSDUAL(2); break;
+        default: SA_FPSDUAL(4); break;
     }
+#undef SA_FPSDUAL
     SA_CHECK_LAUNCH();
     return SA_OK;
 }
@@ -586,3 +730,14 @@ extern "C" int sa_farthest_point_sample_with_preidx(int b, int n, int c, int m, 
     SA_CHECK_LAUNCH();
     return SA_OK;
 }
+
+#ifdef SA_FFPS_SPEC_STATS
+extern "C" int sa_debug_ffps_spec(unsigned long long *host4, int reset) {
+    if (host4 && hipMemcpyFromSymbol(host4, HIP_SYMBOL(g_ffps_spec), sizeof(g_ffps_spec)) != hipSuccess) return SA_ERR_LAUNCH;
+    if (reset) {
+        void *d = nullptr;
+        if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_ffps_spec)) != hipSuccess || hipMemset(d, 0, sizeof(g_ffps_spec)) != hipSuccess) return SA_ERR_LAUNCH;
+    }
+    return SA_OK;
+}
+#endif

@@ -258,6 +258,34 @@ def test_fps_with_distance(gpu, oracle, b, n, m):
     assert np.array_equal(got, oracle.farthest_point_sample_with_distance(m, d))
 
 
+@pytest.mark.parametrize("kind,b,n,m", [("fps_ordered", 4, 4096, 512), ("random", 4, 4096, 301), ("random", 7, 2900, 2), ("ties", 13, 2048, 64),
+                                        ("fps_ordered", 6, 3000, 1), ("nonmetric", 14, 2000, 257), ("fps_ordered", 2, 8192, 130)])
+def test_fps_with_distance_rows_requested_ahead(gpu, oracle, kind, b, n, m):
+    """Matrices beyond 192 MB per call are sampled with the runner-up's row requested a pick ahead (csrc/fps.hip, round 5).
+    The picks must not depend on it: points in FPS order (the layer-2 case: nearly every prediction right), random features
+    (nearly every prediction wrong: the direct path behind a stale request), constant rows (every arg-max a tie), arbitrary
+    non-symmetric rows with negative entries, frame sizes that are no multiple of the workgroup, m = 1 / 2 / odd."""
+    S = pkg("utils.tf_ops.sampling.tf_sampling")
+    assert b * n * n * 4 > 192 << 20
+    rng = np.random.default_rng(n + m + b)
+    if kind == "fps_ordered":
+        p = _cloud(rng, 1, n, scale=30.0)
+        order = oracle.farthest_point_sample(n, p)[0]
+        base = p[:, order]                                              # every prefix is the FPS sample of the cloud
+        f = np.concatenate([base + rng.normal(0, 1e-3, (b, n, 3)).astype(np.float32), rng.normal(0, 0.05, (b, n, 5)).astype(np.float32)], -1)
+        d = oracle.calc_square_dist(f.astype(np.float32), f.astype(np.float32))
+    elif kind == "random":
+        f = rng.normal(0, 1, (b, n, 9)).astype(np.float32)
+        d = oracle.calc_square_dist(f, f)
+    elif kind == "ties":
+        d = np.full((b, n, n), 2.5, np.float32)
+        d[:, np.arange(n), np.arange(n)] = 0.0
+    else:
+        d = rng.normal(-0.5, 1.0, (b, n, n)).astype(np.float32)
+    got = S.farthest_point_sample_with_distance(m, _t(d, gpu)).cpu().numpy()
+    assert np.array_equal(got, oracle.farthest_point_sample_with_distance(m, d))
+
+
 def test_fps_with_distance_negative_rows(gpu, oracle):
     S = pkg("utils.tf_ops.sampling.tf_sampling")
     d = np.full((1, 3, 3), -2.0, np.float32)
