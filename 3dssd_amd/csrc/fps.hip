@@ -322,8 +322,9 @@ __global__ __launch_bounds__(kBlock) void fpsdist_reg_kernel(int n, int m,
     else fpsdist_reg_body<PPT>(n, m, dist, out, out_stride, idx_off, S);
 }
 // rows are requested ahead when the call's matrices exceed what the on-chip caches hold (the rule sqdist.hip uses for its
-// non-temporal stores: such a matrix is read from HBM) and a row is at most 16 KB
-static inline bool ffps_rows_ahead(int b, int n) { return n <= 4 * kBlock && (size_t)b * n * n * sizeof(float) > ((size_t)192 << 20); }
+// non-temporal stores: such a matrix is read from HBM), a row is at most 16 KB, and the picks fit the kernel's LDS list
+// (m > n is legal -- the surplus picks repeat -- and stays on the old loop)
+static inline bool ffps_rows_ahead(int b, int n, int m) { return n <= 4 * kBlock && m <= n && (size_t)b * n * n * sizeof(float) > ((size_t)192 << 20); }
 
 // The two samplers of an 'FS' layer (layers_util.py:93-98) -- or of a layer whose two ranges use F-FPS and D-FPS
 // (:101-106) -- in ONE launch: blockIdx.y == 0 runs the matrix sampler, blockIdx.y == 1 the coordinate sampler.  They are
@@ -647,7 +648,7 @@ extern "C" int sa_fps_with_distance_ex2(int b, int n, int m, const float *dist, 
     if (ppt <= 16) {
         FpsSide S{};
         S.ctr = ctr; S.ctr_bstride = ctr_bstride; S.xyz = ctr ? xyz : nullptr; S.xyz_bstride = xyz_bstride;
-        const bool ahead = ffps_rows_ahead(b, n);
+        const bool ahead = ffps_rows_ahead(b, n, m);
         switch (ppt) {
 #define SA_FPSD(P) case P: if (ahead && P <= 4) hipLaunchKernelGGL((fpsdist_reg_kernel<P, P <= 4>), dim3(b), dim3(kBlock), 0, stream, n, m, dist, out, out_stride, idx_off, S); \
                            else hipLaunchKernelGGL((fpsdist_reg_kernel<P, false>), dim3(b), dim3(kBlock), 0, stream, n, m, dist, out, out_stride, idx_off, S); break;
@@ -686,7 +687,7 @@ extern "C" int sa_fps_dual_ex(int b, int nf, int mf, const float *dist, int *out
     F.S.ctr = ctr_f; F.S.ctr_bstride = ctr_bstride_f; F.S.xyz = ctr_f ? xyz_f : nullptr; F.S.xyz_bstride = xyz_bstride_f;
     D.n = nd; D.m = md; D.out_stride = out_stride_d; D.idx_off = idx_off_d; D.src = inp; D.out = out_d;
     D.S.in_bstride = in_bstride; D.S.ctr = ctr_d; D.S.ctr_bstride = ctr_bstride_d;
-    const bool ahead = ffps_rows_ahead(b, nf);
+    const bool ahead = ffps_rows_ahead(b, nf, mf);
 #define SA_FPSDUAL(P) if (ahead) hipLaunchKernelGGL((fps_dual_kernel<P, P, true>), dim3(b, 2), dim3(kBlock), 0, stream, F, D); \
                       else hipLaunchKernelGGL((fps_dual_kernel<P, P, false>), dim3(b, 2), dim3(kBlock), 0, stream, F, D)
     switch (pf) {

@@ -259,12 +259,14 @@ def test_fps_with_distance(gpu, oracle, b, n, m):
 
 
 @pytest.mark.parametrize("kind,b,n,m", [("fps_ordered", 4, 4096, 512), ("random", 4, 4096, 301), ("random", 7, 2900, 2), ("ties", 13, 2048, 64),
-                                        ("fps_ordered", 6, 3000, 1), ("nonmetric", 14, 2000, 257), ("fps_ordered", 2, 8192, 130)])
+                                        ("fps_ordered", 6, 3000, 1), ("nonmetric", 14, 2000, 257), ("fps_ordered", 2, 8192, 130),
+                                        ("random", 13, 2048, 2100)])
 def test_fps_with_distance_rows_requested_ahead(gpu, oracle, kind, b, n, m):
     """Matrices beyond 192 MB per call are sampled with the runner-up's row requested a pick ahead (csrc/fps.hip, round 5).
     The picks must not depend on it: points in FPS order (the layer-2 case: nearly every prediction right), random features
     (nearly every prediction wrong: the direct path behind a stale request), constant rows (every arg-max a tie), arbitrary
-    non-symmetric rows with negative entries, frame sizes that are no multiple of the workgroup, m = 1 / 2 / odd."""
+    non-symmetric rows with negative entries, frame sizes that are no multiple of the workgroup, m = 1 / 2 / odd, and more
+    picks than points (the surplus repeats; that shape keeps the loop without the LDS pick list)."""
     S = pkg("utils.tf_ops.sampling.tf_sampling")
     assert b * n * n * 4 > 192 << 20
     rng = np.random.default_rng(n + m + b)
