@@ -247,7 +247,6 @@ extern "C" int sa_copy_blocks(int njobs, const long *jobs, hipStream_t stream) {
     return SA_OK;
 }
 
-// lib/utils/tf_ops/sampling/tf_sampling.cpp:235  gatherpointLauncher(b,n,m,c,inp,idx,out)
 // n dense batches of `bytes_per_batch` bytes each (a multiple of 16; srcs[i] and dst 16-byte aligned) -> dst, back to back.
 extern "C" int sa_copy_batches(int n, const void *const *srcs, void *dst, long bytes_per_batch, hipStream_t stream) {
     if (n < 1 || n > kMaxBatches || !srcs || !dst || bytes_per_batch <= 0 || (bytes_per_batch & 15) || ((uintptr_t)dst & 15))
@@ -266,6 +265,7 @@ extern "C" int sa_copy_batches(int n, const void *const *srcs, void *dst, long b
     return SA_OK;
 }
 
+// lib/utils/tf_ops/sampling/tf_sampling.cpp:235  gatherpointLauncher(b,n,m,c,inp,idx,out)
 extern "C" int sa_gather_point(int b, int n, int m, int c, const float *inp, const int *idx, float *out,
                                hipStream_t stream) {
     if (b <= 0 || n <= 0 || m <= 0 || c <= 0 || !inp || !idx || !out) return SA_ERR_INVALID;
