@@ -8,6 +8,7 @@ messages (lib/utils/tf_ops/grouping/tf_grouping.cpp:275-288,368-384,453-459).
 Rows of empty balls are zero-filled (the reference leaves them unwritten).
 """
 import ctypes
+import threading
 import weakref
 
 import torch
@@ -34,6 +35,7 @@ GRID_BALL_QUERY_MIN_N = 512
 # (a replay would skip the build over new contents).  Writes through a raw pointer by code outside torch are not seen:
 # SHARE_GRID = False switches the sharing off.
 SHARE_GRID = True
+_grid_lock = threading.Lock()      # look-up and launch are one step: a second thread must not see the entry before the build is enqueued
 _grid_of_last_call = None          # (weakref to xyz1, (version, data_ptr, shape, stream handle), workspace)
 
 
@@ -59,12 +61,13 @@ def _ball_query_one_band(op, min_radius, max_radius, nsample, dilated, xyz1, xyz
     lib = N.lib()
     if n >= GRID_BALL_QUERY_MIN_N:
         stream = N.current_stream()
-        ws, flags = _grid_workspace(lib, xyz1, b, n, m, stream)
-        st = lib.sa_query_ball_point_grid_ex(b, n, m, 1, (ctypes.c_float * 1)(float(min_radius)),
-                                             (ctypes.c_float * 1)(float(max_radius)), (ctypes.c_int * 1)(int(nsample)),
-                                             1 if dilated else 0, xyz1.data_ptr(), xyz2.data_ptr(),
-                                             (ctypes.c_void_p * 1)(idx.data_ptr()), (ctypes.c_void_p * 1)(cnt.data_ptr()),
-                                             ws.data_ptr(), flags, stream)
+        with _grid_lock:
+            ws, flags = _grid_workspace(lib, xyz1, b, n, m, stream)
+            st = lib.sa_query_ball_point_grid_ex(b, n, m, 1, (ctypes.c_float * 1)(float(min_radius)),
+                                                 (ctypes.c_float * 1)(float(max_radius)), (ctypes.c_int * 1)(int(nsample)),
+                                                 1 if dilated else 0, xyz1.data_ptr(), xyz2.data_ptr(),
+                                                 (ctypes.c_void_p * 1)(idx.data_ptr()), (ctypes.c_void_p * 1)(cnt.data_ptr()),
+                                                 ws.data_ptr(), flags, stream)
     elif dilated:
         st = lib.sa_query_ball_point_dilated(b, n, m, float(min_radius), float(max_radius), int(nsample),
                                              xyz1.data_ptr(), xyz2.data_ptr(), idx.data_ptr(), cnt.data_ptr(),
