@@ -51,7 +51,9 @@ MLP_PLAN_FLAGS = 0  # sa_group_mlp_max flag bit 0 (all nsample rows instead of t
 # bit-identical, MEASURED and left off (profiles/r05_granule4_ab.txt, 128 frames per launch): on the sparse default frames
 # layer 1 / layer 2 run 18 % / 23 % faster (half the padding rows), layer 3 / 4 do not move (eight pooled entries per tile
 # cost what the saved tiles gave), the plan kernels cost 65 % more (an 8-phase next-fit scan, twice the entries) -- net
-# -65 us of 6.8 ms; on ring-structured frames (8-33 rows per ball) every layer is 1-8 % SLOWER.  Opt-in for sparse data.
+# -65 us of 6.8 ms; on ring-structured frames (8-33 rows per ball) every layer is 1-8 % SLOWER.  Opt-in for sparse data:
+# True, or a set of npoint values = the layers to apply it to ({1024} = layer 2 alone, in the executor: default frames 0 to
+# +2 %, rings64 -1.3 %, dense +0.6 % -- no rule that is right for both kinds of frame).
 MLP_GRANULE4 = False
 GRID_BALL_QUERY_MIN_N = 1024   # round 5: the 1024-point frames of layer 3 through the grid too (120 -> 77 us per 128 frames; 512-point frames are faster brute force: 28 vs 42 us)
 MLP_GEMM_CHAIN = False  # True: eligible fp16 scales (layer4) run as three large-tile GEMM launches (flags bit 4); measured slower
@@ -470,7 +472,7 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
             acc += ls[-1].N
         have_plans = nscale <= 4
         base_flags = [MLP_PLAN_FLAGS | (16 if MLP_GEMM_CHAIN else 0) | (2 if have_plans else 0) | W.scale_flags(ls) for ls in layers]
-        if have_plans and MLP_GRANULE4:
+        if have_plans and (MLP_GRANULE4 is True or (MLP_GRANULE4 and m in MLP_GRANULE4)):      # True, or the set of npoint values (layers) to apply it to
             # granule size per scale: 4 rows where a row-wave kernel will take the scale (the library says which), else 8
             for i, ls in enumerate(layers):
                 d_ = (ctypes.c_int * (len(ls) + 1))(*([c_feat + 3] + [l.N for l in ls]))
