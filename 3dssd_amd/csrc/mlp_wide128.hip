@@ -15,6 +15,19 @@
 // pass per k-step, fp32 accumulate, k ascending, bias in the accumulator of the hidden layers (D^T form) and added at
 // the pooled write of the last (D form) -- bit-identical to group_mlp_wide_kernel / mlp_rs_kernel, and range-guarded
 // (mlp_act.h).
+//
+// Round 6 -- the item's phases overlap through LDS.  Until round 5 the gather of an item (12 100 of its 64 800 cycles:
+// 96 rows x 1 KiB of features, load latency + conversion) ran with the matrix pipe idle, and hiding it through
+// registers (54 per lane) made hipcc spill.  LDS is now THREE regions of 96 rows x 272 fp16 channels (157.5 KiB); each
+// holds the gathered input, the first hidden layer, or one 256-column half of the second:
+//     item q   input in I, hidden 1 -> H, hidden 2 -> (R2 | I), last layer reads (R2 | I) WHILE item q+1 is gathered
+//              into H (free since hidden 2 finished): one 16-byte group per thread and block of k-steps, requested at
+//              the top of a block and converted + stored at the top of the next (8 registers in flight, not 54);
+//     item q+1 input in H: the roles of I and H swap, R2 never moves.
+// The xyz tail of the next input (192 groups) is requested in front of hidden 2 and stored behind it.  The second
+// hidden layer takes its two column tiles per wave TOGETHER (2 x 3 accumulator tiles like the last layer), so an
+// activation fragment read from LDS feeds two MFMAs instead of one -- the hidden layers sat on LDS operand reads
+// (128 bytes per clock and CU = one 1 KiB fragment per MFMA issue slot of the CU).
 #include "sa_common.h"
 #include "mlp_plan.h"
 #include "mlp_act.h"
@@ -28,18 +41,25 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector f
 constexpr int kNW = 8, kThreads = kNW * 64;
 constexpr int kRows = 96, kRT = kRows / 32;         // row tiles of an item
 constexpr int kGB = 16;                              // LDS bytes of an 8-channel group (one fp16 plane)
-// weight fragments (k-steps) in flight per wave.  The L2s answer after ~1.7 us under this load whatever is asked, so a
-// wave's weight rate is (fragments in flight) x 1 KiB / 1.7 us: depth is what the spare registers are spent on.
-#ifndef SA_W96_DH
-#define SA_W96_DH 8
+// weight fragments (k-steps) in flight per wave and column tile.  (A ring kept ALIVE across the phases of an item -- the
+// last block of a phase fetching the first fragments of the next -- was built in round 6: with 64 more registers live
+// through the epilogues and the pooling hipcc spilled 92 of them and the item took 98 000 cycles instead of 67 000.)
+#ifndef SA_W96_DEPTH
+#define SA_W96_DEPTH 8
 #endif
-#ifndef SA_W96_D1
-#define SA_W96_D1 6      // first layer: 17 k-steps (259 + padding) = 3 blocks of 6, one step idle
+#ifndef SA_W96_H2PAIR
+#define SA_W96_H2PAIR 1  // hidden 2: the two column tiles of a wave together (an LDS activation fragment feeds two MFMAs)
 #endif
-#ifndef SA_W96_DL
-#define SA_W96_DL 8
+#ifndef SA_W96_SBMASK
+#define SA_W96_SBMASK 0x78F  // sched_barrier: everything but memory reads / writes (VMEM) may cross
 #endif
-constexpr int kDepthFirst = SA_W96_D1, kDepthHidden = SA_W96_DH, kDepthLast = SA_W96_DL;
+#ifndef SA_W96_SBMASK_DS
+#define SA_W96_SBMASK_DS 0      // sched_barrier between a fragment's MFMAs and its re-read: nothing crosses (0x47F = all but LDS: hipcc bunches the reads again)
+#endif
+#ifndef SA_W96_GDEPTH
+#define SA_W96_GDEPTH 1  // gather steps in flight under the last layer (8 registers each)
+#endif
+constexpr int kD = SA_W96_DEPTH;
 
 struct W128Layer {
     const uint4 *w;      // packed fp16 fragments [NT][KS][64]
@@ -54,29 +74,39 @@ struct W128Params {
     int out_stride, out_off;
     const int *gran, *hdr;
     W128Layer L[3];
-    int strideA, strideB;   // LDS row strides in bytes: buffer A (gathered input, then hidden 2), buffer B (hidden 1)
+    int rstride;            // LDS row stride in bytes of a region (96 rows x max(padded input, 256) fp16 channels + 16)
+    int ksplit;             // k-steps of hidden 2 held by region 2 (a run-time value: as a constant hipcc peels the blocks
+                            // of the last layer in front of it and loses the weight pipeline across the peeled copies)
+    float inv_gf;           // 1 / (C / 8): feature groups per row
     int *ovf;
 };
 
 #ifdef SA_W96_PROF
-// debug build only (tools/w96_prof.py): cycles of wave 0 per item: [0] gather + plan entries, [1] hidden 1, [2] hidden 2,
-// [3] last layer MFMA loops, [4] pooling / write-out, [5] items
-__device__ unsigned long long g_w96_prof[8];
+// debug build only (tools/w96_prof.py): cycles of wave 0 per item: [0] plan entries (+ the first item's gather),
+// [1] hidden 1, [2] hidden 2, [3] last layer MFMA loops (the next item's gather rides in them), [4] pooling / write-out,
+// [5] items
+__device__ unsigned long long g_w96_prof[16];   // [8 + w]: cycles wave w spent in phase 0 (the wait at the top-of-item barrier)
 #define WP_T0() unsigned long long wp_t = __builtin_readcyclecounter(), wp_acc[6] = {0, 0, 0, 0, 0, 0}
 #define WP_TICK(i) { const unsigned long long n__ = __builtin_readcyclecounter(); wp_acc[i] += n__ - wp_t; wp_t = n__; }
-#define WP_FLUSH() if (tid == 0) { for (int i__ = 0; i__ < 6; ++i__) atomicAdd(&g_w96_prof[i__], wp_acc[i__]); }
+#define WP_FLUSH() { if (tid == 0) { for (int i__ = 0; i__ < 6; ++i__) atomicAdd(&g_w96_prof[i__], wp_acc[i__]); } if (lane == 0) atomicAdd(&g_w96_prof[8 + w], wp_acc[0]); }
 #else
 #define WP_T0()
 #define WP_TICK(i)
 #define WP_FLUSH()
 #endif
 
+// Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() is fence + s_barrier, and on gfx9 (one vmcnt for loads
+// and stores) the fence is `s_waitcnt vmcnt(0)`: it drains every global load in flight -- here the weight ring's
+// fragments for the next phase, the next item's row references and gather -- a full L2 round trip at each of the three
+// barriers of an item.  The phases only exchange data through LDS; the pooled global stores need no ordering.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ f32x16 mfma_f16(uint4 a, uint4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
 // (ball, flat source point) of the rows lane and lane + 64 of an item: plan entry -> index / count -> point, two
-// dependent global round trips.  Resolved one item AHEAD (during the previous item's matrix work).
+// dependent global round trips.  Resolved one item AHEAD (during the previous item's hidden layers).
 struct RowRefs { int pt[2], ball[2]; };
 __device__ __forceinline__ RowRefs resolve_rows(const W128Params &P, int item, int ngran, int lane) {
     RowRefs R;
@@ -94,174 +124,269 @@ __device__ __forceinline__ RowRefs resolve_rows(const W128Params &P, int item, i
     return R;
 }
 
-// gather the item's 96 rows x [features, xyz - centre, 0 padding] into `buf` as fp16 (row-major, 16 bytes per
-// 8-channel group) from the rows resolved by resolve_rows (every wave holds all of them: lane -> rows lane, lane + 64).
-__device__ __forceinline__ void gather128(const W128Params &P, unsigned char *buf, const RowRefs &R, int tid,
-                                          sa::f16_guard_t &det) {
-    const int r_pt[2] = {R.pt[0], R.pt[1]}, r_ball[2] = {R.ball[0], R.ball[1]};
-    const int GF = P.C >> 3;                                // full feature groups per row (C % 8 == 0)
-    const int G0 = P.L[0].KS * 2;                           // groups of the padded input row
-    const int totF = kRows * GF;
-#pragma unroll 8
-    for (int it0 = 0; it0 < totF; it0 += kThreads) {
-        const bool live = it0 + tid < totF;
-        const int it = live ? it0 + tid : totF - 1;
-        const int row = it / GF, g = it - row * GF;
-        const int p0 = __shfl(r_pt[0], row & 63), p1 = __shfl(r_pt[1], row & 63);
-        const long pt = row < 64 ? p0 : p1;
-        const float4 f0 = *(const float4 *)(P.feat + pt * P.C + g * 8);
-        const float4 f1 = *(const float4 *)(P.feat + pt * P.C + g * 8 + 4);
-        const uint4 r = make_uint4(sa::cvt2_f16(f0.x, f0.y), sa::cvt2_f16(f0.z, f0.w), sa::cvt2_f16(f1.x, f1.y), sa::cvt2_f16(f1.z, f1.w));
+// ---- gather of an item's 96 rows x [features, xyz - centre, 0 padding] into a region as fp16 (row-major, 16 bytes per
+// 8-channel group), from the rows resolved by resolve_rows (every wave holds all of them: lane -> rows lane, lane + 64).
+// The feature part runs as a PIPE of steps: step j covers groups j * 512 + tid of the item (row-major); gp_tick() stores
+// the step requested by the previous tick and requests the next one -- no branch, steps past the end re-read the last
+// group and store nothing -- so the last layer's blocks of k-steps carry one tick each.
+constexpr int kGD = SA_W96_GDEPTH;
+struct GatherPipe {
+    float4 f0[kGD], f1[kGD];   // the groups in flight, oldest first
+    int off[kGD];              // their LDS byte offsets from the region's base (an idle step: the dummy slot)
+    int j;                     // next step to request
+};
+__device__ __forceinline__ void gp_reset(GatherPipe &G, int dummy_off) {
+#pragma unroll
+    for (int d = 0; d < kGD; ++d) { G.f0[d] = make_float4(0.f, 0.f, 0.f, 0.f); G.f1[d] = G.f0[d]; G.off[d] = dummy_off; }
+    G.j = 0;
+}
+__device__ __forceinline__ void gp_tick(const W128Params &P, unsigned char *buf, int dummy_off, const RowRefs &R, int tid,
+                                        GatherPipe &G, sa::f16_guard_t &det) {
+    {   // store the oldest group in flight (requested kGD ticks ago)
+        const float4 a = G.f0[0], b = G.f1[0];
+        const uint4 r = make_uint4(sa::cvt2_f16(a.x, a.y), sa::cvt2_f16(a.z, a.w), sa::cvt2_f16(b.x, b.y), sa::cvt2_f16(b.z, b.w));
         sa::f16_guard_signed(r, det);
-        if (live) *(uint4 *)(buf + row * P.strideA + g * kGB) = r;
+        *(uint4 *)(buf + G.off[0]) = r;                     // an idle step stores into the dummy slot: no branch in the block
+#pragma unroll
+        for (int d = 0; d + 1 < kGD; ++d) { G.f0[d] = G.f0[d + 1]; G.f1[d] = G.f1[d + 1]; G.off[d] = G.off[d + 1]; }
     }
-    const int GT = G0 - GF;                                 // tail groups: [dx, dy, dz, 0 ...], then zero groups
-    const int totT = kRows * GT;
-    for (int it0 = 0; it0 < totT; it0 += kThreads) {
-        const bool live = it0 + tid < totT;
-        const int it = live ? it0 + tid : totT - 1;
-        const int row = it / GT, g = GF + (it - row * GT);
-        const int p0 = __shfl(r_pt[0], row & 63), p1 = __shfl(r_pt[1], row & 63);
-        const int b0 = __shfl(r_ball[0], row & 63), b1 = __shfl(r_ball[1], row & 63);
-        const long pt = row < 64 ? p0 : p1, ball = row < 64 ? b0 : b1;
-        const float px = P.xyz[pt * 3 + 0] - P.new_xyz[ball * 3 + 0];
-        const float py = P.xyz[pt * 3 + 1] - P.new_xyz[ball * 3 + 1];
-        const float pz = P.xyz[pt * 3 + 2] - P.new_xyz[ball * 3 + 2];
-        const bool first = g == GF;
-        const uint4 r = make_uint4(sa::cvt2_f16(first ? px : 0.0f, first ? py : 0.0f), sa::cvt2_f16(first ? pz : 0.0f, 0.0f), 0u, 0u);
-        sa::f16_guard_signed(r, det);
-        if (live) *(uint4 *)(buf + row * P.strideA + g * kGB) = r;
-    }
+    const int GF = P.C >> 3, totF = kRows * GF;
+    const int it_raw = G.j * kThreads + tid;
+    const bool live = it_raw < totF;
+    const int it = live ? it_raw : totF - 1;
+    int row = (int)((float)it * P.inv_gf);                   // it < 2^16: one float estimate, exact after +-1
+    int g = it - row * GF;
+    { const bool hi = g >= GF, lo = g < 0; row += hi ? 1 : (lo ? -1 : 0); g += hi ? -GF : (lo ? GF : 0); }
+    const int p0 = __shfl(R.pt[0], row & 63), p1 = __shfl(R.pt[1], row & 63);
+    const long pt = row < 64 ? p0 : p1;
+    G.f0[kGD - 1] = *(const float4 *)(P.feat + pt * P.C + g * 8);
+    G.f1[kGD - 1] = *(const float4 *)(P.feat + pt * P.C + g * 8 + 4);
+    G.off[kGD - 1] = live ? row * P.rstride + g * kGB : dummy_off;
+    G.j += 1;
+}
+__device__ __forceinline__ int gp_steps(const W128Params &P) { return (kRows * (P.C >> 3) + kThreads - 1) / kThreads + kGD; }   // + the last stores
+
+// The tail groups of a row: [dx, dy, dz, 0 ...], then zero groups up to the padded width; at most 2 per row (c % 8 == 0),
+// i.e. one step of the 512 threads.  Requested (gt_issue) well before they are stored (gt_store).
+struct GatherTail { float p[3], c[3]; };
+__device__ __forceinline__ GatherTail gt_issue(const W128Params &P, const RowRefs &R, int tid) {
+    const int GF = P.C >> 3, GT = P.L[0].KS * 2 - GF, totT = kRows * GT;
+    const int it = tid < totT ? tid : totT - 1;
+    const int row = GT == 2 ? it >> 1 : it;
+    const int p0 = __shfl(R.pt[0], row & 63), p1 = __shfl(R.pt[1], row & 63);
+    const int b0 = __shfl(R.ball[0], row & 63), b1 = __shfl(R.ball[1], row & 63);
+    const long pt = row < 64 ? p0 : p1, ball = row < 64 ? b0 : b1;
+    GatherTail T;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) { T.p[e] = P.xyz[pt * 3 + e]; T.c[e] = P.new_xyz[ball * 3 + e]; }
+    return T;
+}
+__device__ __forceinline__ void gt_store(const W128Params &P, unsigned char *buf, const GatherTail &T, int tid, sa::f16_guard_t &det) {
+    const int GF = P.C >> 3, GT = P.L[0].KS * 2 - GF, totT = kRows * GT;
+    const int it = tid < totT ? tid : totT - 1;
+    const int row = GT == 2 ? it >> 1 : it, g = GF + (GT == 2 ? it & 1 : 0);
+    const bool first = g == GF;
+    const float px = T.p[0] - T.c[0], py = T.p[1] - T.c[1], pz = T.p[2] - T.c[2];
+    const uint4 r = make_uint4(sa::cvt2_f16(first ? px : 0.0f, first ? py : 0.0f), sa::cvt2_f16(first ? pz : 0.0f, 0.0f), 0u, 0u);
+    sa::f16_guard_signed(r, det);
+    if (tid < totT) *(uint4 *)(buf + row * P.rstride + g * kGB) = r;
 }
 
-// One 32-column tile `ct` of a hidden layer for the item's four row tiles (D^T form: weights are the MFMA A operand):
-// out[row][ocol0*32 .. +32) = relu(bias + in[row][:] W[:, ct]).  The weight fragments of DEPTH k-steps are in flight.
-template <int DEPTH>
-__device__ __forceinline__ void hidden_tile(const unsigned char *in, int strideIn, unsigned char *outb, int strideOut,
-                                            const W128Layer &L, int ct, int ocol0, int lane, sa::f16_guard_t &det) {
+// NCT 32-column tiles of a hidden layer for the item's three row tiles (D^T form: weights are the MFMA A operand):
+// out[t][row][ocol[t]*32 .. +32) = relu(bias + in[row][:] W[:, ct[t]]).  The weight fragments of DEPTH k-steps are in
+// flight per column tile; an activation fragment read from LDS feeds NCT MFMAs.  TAIL: the layer's k-steps need not be
+// a multiple of DEPTH (the first layer: 17 = 2 x 8 + 1) -- the remainder runs behind the ring, its first fragment
+// requested in front of it.
+template <int NCT, bool TAIL>
+__device__ __forceinline__ void hidden_tiles(const unsigned char *in, int strideIn, unsigned char *const (&outb)[NCT], int strideOut,
+                                             const W128Layer &L, const int (&ct)[NCT], const int (&ocol)[NCT], int lane,
+                                             sa::f16_guard_t &det) {
+    constexpr int DEPTH = kD;
     const int half = lane >> 5, col = lane & 31;
     const unsigned char *arow = in + col * strideIn + half * kGB;
-    f32x16 acc[kRT];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float4 bv = *(const float4 *)(L.bias + ct * 32 + 8 * q + 4 * half);
-#pragma unroll
-        for (int r = 0; r < kRT; ++r) {
-            acc[r][4 * q + 0] = bv.x; acc[r][4 * q + 1] = bv.y; acc[r][4 * q + 2] = bv.z; acc[r][4 * q + 3] = bv.w;
-        }
-    }
     // The k loop runs in straight-line blocks of DEPTH k-steps with NO branch inside: every step consumes ring slot d and
-    // refills it with the fragment DEPTH steps ahead, so DEPTH loads stay in flight across the whole loop.  (With an
-    // `if (ks < KS)` around each step the blocks end after every step and hipcc waits for the refill -- `s_waitcnt
-    // vmcnt(0)` -- before leaving the block: one L2 round trip per k-step.)  Steps past the end use a zero fragment.
-    const u32x4 *wb = (const u32x4 *)L.w + (size_t)ct * L.KS * 64 + lane;
-    const int KS = L.KS;
-    u32x4 wq[DEPTH];
+    // refills it with the fragment DEPTH steps ahead, so DEPTH loads stay in flight across the whole loop.  The refill of
+    // slot d goes BEHIND the MFMAs that read it, and no memory read may rise above them (sched_barrier): the new fragment
+    // then lands in the registers the old one just left.  Until round 5 it was requested in front of them: it needed
+    // registers of its own, the ring rotated through register copies at the end of the block, and the copy of the
+    // youngest load was waited for there -- `s_waitcnt vmcnt(1)`, the whole pipeline drained once per block (seen in
+    // the ISA); a zero fragment selected for steps past the end (v_cndmask on every loaded register) had the same effect.
+    const int KS = L.KS, KSm = TAIL ? KS / DEPTH * DEPTH : KS;   // !TAIL: KS % DEPTH == 0 (host check)
+    const u32x4 *wb[NCT];
+    u32x4 wq[DEPTH][NCT], wt[NCT];
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) wq[d] = wb[(d < KS ? d : KS - 1) * 64];
+    for (int t = 0; t < NCT; ++t) {
+        wb[t] = (const u32x4 *)L.w + (size_t)ct[t] * KS * 64 + lane;
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) wq[d][t] = wb[t][d * 64];   // KS >= DEPTH (host check)
+        if (TAIL) wt[t] = wb[t][(KSm < KS ? KSm : KS - 1) * 64];
+    }
     // The ring is loop-carried: slot d enters the loop from the prologue load above and from the refill below.  InstCombine
     // folds such a PHI of two loads into ONE load of a PHI of the addresses, placed at the top of the iteration that uses
     // it -- the software pipeline silently becomes "load, wait, use" (seen in the ISA).  Passing the prologue values
     // through an empty asm makes the PHI's inputs differ in kind and keeps the refills where they are written.
-#ifndef SA_W96_NOLAUNDER
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) asm volatile("" : "+v"(wq[d]));
-#endif
-    for (int ks0 = 0; ks0 < KS; ks0 += DEPTH) {
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+        for (int t = 0; t < NCT; ++t) asm volatile("" : "+v"(wq[d][t]));
+    f32x16 acc[NCT][kRT];
+#pragma unroll
+    for (int t = 0; t < NCT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 bv = *(const float4 *)(L.bias + ct[t] * 32 + 8 * q + 4 * half);
+#pragma unroll
+            for (int r = 0; r < kRT; ++r) {
+                acc[t][r][4 * q + 0] = bv.x; acc[t][r][4 * q + 1] = bv.y; acc[t][r][4 * q + 2] = bv.z; acc[t][r][4 * q + 3] = bv.w;
+            }
+        }
+    // The activation fragments rotate IN PLACE as well: fragment r of the next k-step is requested right behind the MFMAs
+    // that read fragment r of this one (no LDS read may rise above them), so it has the other fragments' MFMAs to arrive.
+    // Left to itself under this register pressure hipcc read one fragment, waited for it (`lgkmcnt(0)`), issued its
+    // MFMAs, read the next into the same registers, waited ...: the LDS latency sat in front of every pair of MFMAs
+    // (ISA of rounds 3-5; the matrix pipe of a wave was busy a third of the time).
+    uint4 af[kRT];
+#pragma unroll
+    for (int r = 0; r < kRT; ++r) af[r] = *(const uint4 *)(arow + r * 32 * strideIn);
+    for (int ks0 = 0; ks0 < KSm; ks0 += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             const int ks = ks0 + d;
-            const bool live = ks < KS;
-            const int ksc = live ? ks : KS - 1;
-            u32x4 wv = wq[d];
-            if (!live) wv = u32x4{0u, 0u, 0u, 0u};
-            const uint4 wf = __builtin_bit_cast(uint4, wv);
-            const int kw = ks + DEPTH < KS ? ks + DEPTH : KS - 1;
-            wq[d] = wb[kw * 64];
-            uint4 af[kRT];
+            const int kn = ks + 1 < KS ? ks + 1 : KS - 1;
+            uint4 wf[NCT];
 #pragma unroll
-            for (int r = 0; r < kRT; ++r) af[r] = *(const uint4 *)(arow + r * 32 * strideIn + ksc * 2 * kGB);
+            for (int t = 0; t < NCT; ++t) wf[t] = __builtin_bit_cast(uint4, wq[d][t]);
 #pragma unroll
-            for (int r = 0; r < kRT; ++r) acc[r] = mfma_f16(wf, af[r], acc[r]);
+            for (int r = 0; r < kRT; ++r) {
+#pragma unroll
+                for (int t = 0; t < NCT; ++t) acc[t][r] = mfma_f16(wf[t], af[r], acc[t][r]);
+                __builtin_amdgcn_sched_barrier(SA_W96_SBMASK_DS);
+                af[r] = *(const uint4 *)(arow + r * 32 * strideIn + kn * 2 * kGB);
+            }
+            __builtin_amdgcn_sched_barrier(SA_W96_SBMASK);
+            const int kw = ks + DEPTH < KSm ? ks + DEPTH : KSm - 1;
+#pragma unroll
+            for (int t = 0; t < NCT; ++t) wq[d][t] = wb[t][kw * 64];
+        }
+    }
+    if (TAIL) {
+        for (int ks = KSm; ks < KS; ++ks) {
+            const int kn = ks + 1 < KS ? ks + 1 : KS - 1;
+            uint4 wf[NCT];
+#pragma unroll
+            for (int t = 0; t < NCT; ++t) {
+                wf[t] = __builtin_bit_cast(uint4, wt[t]);
+                wt[t] = wb[t][kn * 64];
+            }
+#pragma unroll
+            for (int r = 0; r < kRT; ++r) {
+#pragma unroll
+                for (int t = 0; t < NCT; ++t) acc[t][r] = mfma_f16(wf[t], af[r], acc[t][r]);
+                __builtin_amdgcn_sched_barrier(SA_W96_SBMASK_DS);
+                af[r] = *(const uint4 *)(arow + r * 32 * strideIn + kn * 2 * kGB);
+            }
         }
     }
 #pragma unroll
-    for (int r = 0; r < kRT; ++r) {
-        unsigned char *orow = outb + (r * 32 + col) * strideOut + ocol0 * 4 * kGB + 8 * half;
+    for (int t = 0; t < NCT; ++t)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint2 pk = make_uint2(sa::cvt2_f16_relu(acc[r][4 * q], acc[r][4 * q + 1]), sa::cvt2_f16_relu(acc[r][4 * q + 2], acc[r][4 * q + 3]));
-            sa::f16_guard(pk, det);
-            *(uint2 *)(orow + q * kGB) = pk;
+        for (int r = 0; r < kRT; ++r) {
+            unsigned char *orow = outb[t] + (r * 32 + col) * strideOut + ocol[t] * 4 * kGB + 8 * half;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint2 pk = make_uint2(sa::cvt2_f16_relu(acc[t][r][4 * q], acc[t][r][4 * q + 1]), sa::cvt2_f16_relu(acc[t][r][4 * q + 2], acc[t][r][4 * q + 3]));
+                sa::f16_guard(pk, det);
+                *(uint2 *)(orow + q * kGB) = pk;
+            }
         }
-    }
 }
 
-// Last layer (D form), column tiles ct0, ct0 + 1 of this wave, k-steps [ks_lo, ks_hi) of the contraction whose operand
-// columns start at k-step ks_lo in `in`; accumulators persist across the calls of a pass.
-template <int DEPTH>
-__device__ __forceinline__ void last_partial(f32x16 (&acc)[2][kRT], const unsigned char *in, int strideIn,
-                                             const W128Layer &L, int ct0, int ks_lo, int ks_hi, int lane) {
+// Last layer (D form), column tiles ct0, ct0 + 1 of this wave over the whole contraction (KS a multiple of kD: host
+// check): k-steps below `ksplit` come from region `lo`, the others from region `hi` (the two 256-column halves of hidden
+// 2; ksplit is a multiple of DEPTH or >= KS).  Every block of DEPTH k-steps carries one tick of the next item's gather into `gbuf`.
+__device__ __forceinline__ void last_pass(f32x16 (&acc)[2][kRT], const unsigned char *lo, const unsigned char *hi, int ksplit,
+                                          int stride, const W128Layer &L, int ct0, int lane, const W128Params &P,
+                                          unsigned char *gbuf, int gdummy, const RowRefs &R, int tid, GatherPipe &G,
+                                          sa::f16_guard_t &det) {
+    constexpr int DEPTH = kD;
     const int half = lane >> 5, col = lane & 31;
-    const unsigned char *arow = in + col * strideIn + half * kGB;
-    const u32x4 *wb0 = (const u32x4 *)L.w + (size_t)(ct0 < L.NT ? ct0 : L.NT - 1) * L.KS * 64 + lane;
-    const u32x4 *wb1 = (const u32x4 *)L.w + (size_t)(ct0 + 1 < L.NT ? ct0 + 1 : L.NT - 1) * L.KS * 64 + lane;
+    const int lane_off = col * stride + half * kGB;
+    const int KS = L.KS;
+    const u32x4 *wb0 = (const u32x4 *)L.w + (size_t)(ct0 < L.NT ? ct0 : L.NT - 1) * KS * 64 + lane;
+    const u32x4 *wb1 = (const u32x4 *)L.w + (size_t)(ct0 + 1 < L.NT ? ct0 + 1 : L.NT - 1) * KS * 64 + lane;
     u32x4 wq[DEPTH][2];
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
-        const int kd = ks_lo + d < ks_hi ? ks_lo + d : ks_hi - 1;
-        wq[d][0] = wb0[kd * 64];
-        wq[d][1] = wb1[kd * 64];
+        wq[d][0] = wb0[d * 64];
+        wq[d][1] = wb1[d * 64];
     }
-#ifndef SA_W96_NOLAUNDER
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) asm volatile("" : "+v"(wq[d][0]), "+v"(wq[d][1]));   // see hidden_tile
-#endif
-    for (int ks0 = ks_lo; ks0 < ks_hi; ks0 += DEPTH) {       // branch-free blocks of DEPTH k-steps (see hidden_tile)
+    for (int d = 0; d < DEPTH; ++d) asm volatile("" : "+v"(wq[d][0]), "+v"(wq[d][1]));   // see hidden_tiles
+    // activation fragment r of k-step ks: region `lo` below ksplit, `hi` from there on (wave-uniform select)
+    auto aptr = [&](int ks, int r) -> const uint4 * {
+        const unsigned char *base = ks < ksplit ? lo + ks * 2 * kGB : hi + (ks - ksplit) * 2 * kGB;
+        return (const uint4 *)(base + lane_off + r * 32 * stride);
+    };
+    uint4 af[kRT];
+#pragma unroll
+    for (int r = 0; r < kRT; ++r) af[r] = *aptr(0, r);
+    for (int ks0 = 0; ks0 < KS; ks0 += DEPTH) {              // branch-free blocks of DEPTH k-steps (see hidden_tiles)
+        gp_tick(P, gbuf, gdummy, R, tid, G, det);
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             const int ks = ks0 + d;
-            const bool live = ks < ks_hi;
-            const int ksc = live ? ks : ks_hi - 1;
-            u32x4 v0 = wq[d][0], v1 = wq[d][1];
-            if (!live) { v0 = u32x4{0u, 0u, 0u, 0u}; v1 = v0; }
-            const uint4 w0 = __builtin_bit_cast(uint4, v0), w1 = __builtin_bit_cast(uint4, v1);
-            const int kw = ks + DEPTH < ks_hi ? ks + DEPTH : ks_hi - 1;
-            wq[d][0] = wb0[kw * 64];
-            wq[d][1] = wb1[kw * 64];
-            uint4 af[kRT];
-#pragma unroll
-            for (int r = 0; r < kRT; ++r) af[r] = *(const uint4 *)(arow + r * 32 * strideIn + (ksc - ks_lo) * 2 * kGB);
+            const int kn = ks + 1 < KS ? ks + 1 : KS - 1;
+            const uint4 w0 = __builtin_bit_cast(uint4, wq[d][0]), w1 = __builtin_bit_cast(uint4, wq[d][1]);   // KS % DEPTH == 0 (host check)
 #pragma unroll
             for (int r = 0; r < kRT; ++r) {
                 acc[0][r] = mfma_f16(af[r], w0, acc[0][r]);
                 acc[1][r] = mfma_f16(af[r], w1, acc[1][r]);
+                __builtin_amdgcn_sched_barrier(SA_W96_SBMASK_DS);     // in-place rotation of the activation fragments (see hidden_tiles)
+                af[r] = *aptr(kn, r);
             }
+            // in-place refill behind the MFMAs that read the slot (see hidden_tiles)
+            __builtin_amdgcn_sched_barrier(SA_W96_SBMASK);
+            const int kw = ks + DEPTH < KS ? ks + DEPTH : KS - 1;
+            wq[d][0] = wb0[kw * 64];
+            wq[d][1] = wb1[kw * 64];
         }
     }
 }
 
+constexpr int kHalfKS = 16;                                   // k-steps (256 columns) of hidden 2 that live in region 2
+static_assert(kHalfKS % kD == 0, "a block of k-steps of the last layer must not straddle the two halves of hidden 2");
+
 __global__ __launch_bounds__(kThreads, 2) void group_mlp_wide128_kernel(W128Params P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *bufA = smem;                               // gathered input, later the hidden-2 chunk
-    unsigned char *bufB = smem + kRows * P.strideA;           // hidden 1
+    const int rbytes = kRows * P.rstride;
+    unsigned char *regI = smem, *regH = smem + rbytes;        // input of this item / hidden 1 (and the next item's input)
+    unsigned char *const reg2 = smem + 2 * rbytes;            // columns 0 .. 255 of hidden 2
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6) & (kNW - 1);
     const int ngran = __builtin_amdgcn_readfirstlane(P.hdr[0]);
     const int nitems = (ngran + kRows / 8 - 1) / (kRows / 8);      // 96-row items = 12 granules of the plan
     const W128Layer &L1 = P.L[0], &L2 = P.L[1], &L3 = P.L[2];
     const int npass = (L3.NT + 2 * kNW - 1) / (2 * kNW);      // passes of 16 column tiles over the last layer
+    const int nsteps = gp_steps(P);
     sa::f16_guard_t det = 0;
 
     int istride;
     const int item0 = sa::xcd_block(blockIdx.x, gridDim.x, nitems, istride);
     if (item0 < 0) return;
     WP_T0();
+    GatherPipe gp;
+    // the dummy slot sits behind the three regions; as an offset from region I / region H
+    int dumI = 3 * rbytes, dumH = 2 * rbytes;
     RowRefs refs = resolve_rows(P, item0, ngran, lane);
     int gr_ent = sa::plan_entry(P.gran, ngran, item0 * (kRows / 8) + (lane < kRT * 4 ? lane : 0));
     int gr_cnt = gr_ent >= 0 ? P.cnt[sa::plan_ball(gr_ent)] : 0;
+    {   // the first item of this workgroup: gathered with nothing to hide behind
+        const GatherTail T = gt_issue(P, refs, tid);
+        gp_reset(gp, dumI);
+        for (int s = 0; s < nsteps; ++s) gp_tick(P, regI, dumI, refs, tid, gp, det);
+        gt_store(P, regI, T, tid, det);
+    }
     for (int item = item0; item < nitems; item += istride) {
-        gather128(P, bufA, refs, tid, det);
         // the plan entries and ball counts of the item's 12 granules (lane g holds granule g; resolved one item ahead)
         int ent[kRT][4], cn[kRT][4];
 #pragma unroll
@@ -269,24 +394,47 @@ __global__ __launch_bounds__(kThreads, 2) void group_mlp_wide128_kernel(W128Para
             ent[g >> 2][g & 3] = __builtin_amdgcn_readlane(gr_ent, g);
             cn[g >> 2][g & 3] = __builtin_amdgcn_readlane(gr_cnt, g);
         }
-        // the next item's rows and granules: requested now, needed at the top of the next iteration
+        // the next item's rows and granules: requested now, needed behind hidden 1 (the last item gathers itself again:
+        // no branch, region H is free either way)
         {
             const int nxt = item + istride < nitems ? item + istride : item;
             refs = resolve_rows(P, nxt, ngran, lane);
             gr_ent = sa::plan_entry(P.gran, ngran, nxt * (kRows / 8) + (lane < kRT * 4 ? lane : 0));
             gr_cnt = gr_ent >= 0 ? P.cnt[sa::plan_ball(gr_ent)] : 0;
         }
-        __syncthreads();
+        lds_barrier();                                        // this item's input is complete (gathered during the last item)
         WP_TICK(0)
-        // ---- hidden 1: 8 column tiles, one per wave: bufA -> bufB
-        hidden_tile<kDepthFirst>(bufA, P.strideA, bufB, P.strideB, L1, w, w, lane, det);
-        __syncthreads();
+        // ---- hidden 1: 8 column tiles, one per wave: I -> H
+        {
+            unsigned char *const ob[1] = {regH};
+            const int ct[1] = {w}, oc[1] = {w};
+            hidden_tiles<1, true>(regI, P.rstride, ob, P.rstride, L1, ct, oc, lane, det);
+        }
+        lds_barrier();
         WP_TICK(1)
-        // ---- hidden 2: column tiles w, w + 8, ...: bufB -> bufA (the gathered input is dead)
-        for (int ct = w; ct < L2.NT; ct += kNW) hidden_tile<kDepthHidden>(bufB, P.strideB, bufA, P.strideA, L2, ct, ct, lane, det);
-        __syncthreads();
+        // ---- hidden 2: column tiles w, w + 8 together: H -> (region 2 | I) (the gathered input is dead)
+        const GatherTail tail = gt_issue(P, refs, tid);       // the next item's xyz tail, stored behind hidden 2
+        for (int ct = w; ct < L2.NT; ct += (SA_W96_H2PAIR ? 2 : 1) * kNW) {
+            if (SA_W96_H2PAIR && ct + kNW < L2.NT) {
+                const int c2[2] = {ct, ct + kNW};
+                unsigned char *ob[2];
+                int oc[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) { ob[t] = c2[t] < kHalfKS / 2 ? reg2 : regI; oc[t] = c2[t] < kHalfKS / 2 ? c2[t] : c2[t] - kHalfKS / 2; }
+                unsigned char *const obc[2] = {ob[0], ob[1]};
+                hidden_tiles<2, false>(regH, P.rstride, obc, P.rstride, L2, c2, oc, lane, det);
+            } else {
+                unsigned char *const ob[1] = {ct < kHalfKS / 2 ? reg2 : regI};
+                const int c1[1] = {ct}, oc[1] = {ct < kHalfKS / 2 ? ct : ct - kHalfKS / 2};
+                hidden_tiles<1, false>(regH, P.rstride, ob, P.rstride, L2, c1, oc, lane, det);
+            }
+        }
+        lds_barrier();
         WP_TICK(2)
-        // ---- last layer in passes of 16 column tiles over the LDS-resident hidden 2; pooled write per pass
+        // ---- last layer in passes of 16 column tiles over the LDS-resident hidden 2; pooled write per pass.  Region H
+        //      is free: the next item's input goes there, one gather step per block of k-steps
+        gt_store(P, regH, tail, tid, det);
+        gp_reset(gp, dumH);
         for (int p = 0; p < npass; ++p) {
             const int ct0 = p * 2 * kNW + 2 * w;              // this wave's two column tiles of the pass
             // their bias: requested HERE, used after the matrix loop (a load in front of the pooled write was waited
@@ -301,7 +449,7 @@ __global__ __launch_bounds__(kThreads, 2) void group_mlp_wide128_kernel(W128Para
                 for (int r = 0; r < kRT; ++r)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[t2][r][e] = 0.0f;
-            last_partial<kDepthLast>(acc, bufA, P.strideA, L3, ct0, 0, L3.KS, lane);
+            last_pass(acc, reg2, regI, P.ksplit, P.rstride, L3, ct0, lane, P, regH, dumH, refs, tid, gp, det);
             WP_TICK(3)
             const int col = lane & 31;
 #pragma unroll
@@ -319,7 +467,9 @@ __global__ __launch_bounds__(kThreads, 2) void group_mlp_wide128_kernel(W128Para
                 }
             }
         }
-        __syncthreads();                                      // the next item's gather overwrites bufA
+        while (gp.j < nsteps) gp_tick(P, regH, dumH, refs, tid, gp, det);   // fewer blocks than gather steps (narrow last layers)
+        { unsigned char *t = regI; regI = regH; regH = t; }
+        { const int t = dumI; dumI = dumH; dumH = t; }
 #ifdef SA_W96_PROF
         WP_TICK(4)
         wp_acc[5] += 1;
@@ -346,6 +496,8 @@ int sa_wide128_try(int b, int n, int m, int ns, int c, const float *xyz, const f
     // 48 us against mlp_rs_kernel's 35 (LDS-streamed weights win while the whole scale's weights are small): the narrower
     // scale stays where it was unless the caller forces this kernel (flags bit 5, tests)
     if (!force && (long)dims[2] * dims[3] < 512l * 1024) return 0;
+    // the weight rings of hidden 2 and of the last layer refill in place, without a tail: whole blocks of k-steps only
+    if ((dims[1] / 16) % kD || (dims[2] / 16) % kD || r128_roundup(dims[0], 16) / 16 < kD) return 0;
     W128Params P{};
     P.xyz = xyz; P.feat = feat; P.new_xyz = new_xyz; P.idx = idx; P.cnt = cnt; P.out = out;
     P.n = n; P.m = m; P.ns = ns; P.C = c; P.out_stride = out_stride; P.out_off = out_off;
@@ -357,10 +509,12 @@ int sa_wide128_try(int b, int n, int m, int ns, int c, const float *xyz, const f
         P.L[l].NT = r128_roundup(dims[l + 1], 32) / 32;
         P.L[l].N = dims[l + 1];
     }
-    const int wA = P.L[0].KS * 16 > dims[2] ? P.L[0].KS * 16 : dims[2];                     // gathered input row / hidden 2
-    P.strideA = wA * 2 + 16;
-    P.strideB = dims[1] * 2 + 16;
-    const size_t lds = (size_t)kRows * (P.strideA + P.strideB);
+    // a region holds the padded input row, hidden 1 (256 columns) or one half of hidden 2 (<= 256 columns)
+    const int wR = P.L[0].KS * 16 > 256 ? P.L[0].KS * 16 : 256;
+    P.rstride = wR * 2 + 16;
+    P.inv_gf = 1.0f / (float)(c >> 3);
+    P.ksplit = kHalfKS;
+    const size_t lds = (size_t)3 * kRows * P.rstride + 16;
     if (lds > 160 * 1024) return 0;
     if (dry) { *st = SA_OK; return 1; }          // the shape would be taken (nothing launched)
     (void)hipFuncSetAttribute((const void *)group_mlp_wide128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -385,7 +539,7 @@ int sa_wide128_try(int b, int n, int m, int ns, int c, const float *xyz, const f
 }
 
 #ifdef SA_W96_PROF
-extern "C" int sa_debug_w96_prof(unsigned long long *host8, int reset) {
+extern "C" int sa_debug_w96_prof(unsigned long long *host8, int reset) {   // host8: 16 words
     if (host8 && hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_w96_prof), sizeof(g_w96_prof)) != hipSuccess) return SA_ERR_LAUNCH;
     if (reset) {
         void *d = nullptr;

@@ -112,3 +112,78 @@ def gather_check(xyz, feat):
     nbytes = sum(t.numel() * t.element_size() for t in xs + fs)
     return {"ranks_seen": int(ones.item()), "world": world, "backend": backend + (" (RCCL)" if on_gpu else ""),
             "rank_order_ok": bool(ok), "distinct_rank_digests": distinct, "bytes_gathered": int(nbytes), "ms": round(ms, 3)}
+
+
+# ---- RCCL smoke on ONE GPU -------------------------------------------------------------------------------
+# No lease of this build ever had more than one GPU, so backend "nccl" (= RCCL) had never initialised anywhere.  A
+# world-size-1 communicator proves the pieces an 8-GPU run depends on before such a node appears: librccl loads, its
+# kernels run on gfx950, the HSA_ENABLE_IPC_MODE_LEGACY setting bench.py exports is accepted, and reduce_timing /
+# gather_check (the only collectives of this path; lib/core/trainer.py:120-155 is the reference's analogue) work on
+# DEVICE tensors.  It is not a scaling point.
+def rccl_smoke(device_index=0):
+    """Run in a process of its own (it creates and destroys the default process group).  -> dict, "status": "ok" on success."""
+    import socket
+    assert torch.cuda.is_available(), "rccl_smoke needs a GPU"
+    assert not dist.is_initialized(), "rccl_smoke owns the default process group: call it in a fresh process"
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
+    t0 = time.perf_counter()
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    try:
+        barrier()
+        t_max, frames = reduce_timing(1.25, 160, device=dev)                     # all_reduce MAX + SUM on device scalars
+        g = torch.Generator(device="cpu").manual_seed(6)
+        xyz = torch.randn(8, 256, 3, generator=g).to(dev)
+        feat = torch.randn(8, 256, 512, generator=g).to(dev)
+        chk = gather_check(xyz, feat)                                             # all_gather x3 + all_reduce, digests compared
+        big = torch.ones(1 << 22, dtype=torch.float32, device=dev)               # a bandwidth-sized all_reduce (16 MiB)
+        dist.all_reduce(big)
+        torch.cuda.synchronize()
+        ok = (t_max == 1.25 and frames == 160 and chk["ranks_seen"] == 1 and chk["rank_order_ok"] and
+              chk["backend"].startswith("nccl") and float(big[0].item()) == 1.0)
+        ver = None
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001
+            pass
+        return {"status": "ok" if ok else "wrong result", "backend": dist.get_backend(), "world": 1, "rccl_version": ver,
+                "reduce_timing": [t_max, frames], "gather_check": chk, "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+                "seconds": round(time.perf_counter() - t0, 2)}
+    finally:
+        dist.destroy_process_group()
+
+
+def rccl_smoke_main():
+    import json
+    try:
+        out = rccl_smoke()
+    except Exception as e:  # noqa: BLE001 -- the caller reads the line, not the exit code
+        out = {"status": "failed: %r" % (e,)}
+    print("RCCL_SMOKE " + json.dumps(out), flush=True)
+
+
+def rccl_smoke_subprocess(timeout_s=120):
+    """rccl_smoke() in a child process (a hang or crash inside RCCL cannot take the caller down)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import importlib, sys; sys.path.insert(0, %r); importlib.import_module('3dssd_amd.sharding').rccl_smoke_main()" % root
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout_s, env=env)
+    except subprocess.TimeoutExpired:
+        return {"status": "timeout after %d s" % timeout_s}
+    for ln in reversed(p.stdout.splitlines()):
+        if ln.startswith("RCCL_SMOKE "):
+            return json.loads(ln[len("RCCL_SMOKE "):])
+    return {"status": "failed: no result line (rc %d): %s" % (p.returncode, (p.stderr or "")[-300:])}

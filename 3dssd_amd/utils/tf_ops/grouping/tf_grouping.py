@@ -7,6 +7,7 @@ function `group_point_grad(points, idx, grad_out)` -- no autograd registration. 
 messages (lib/utils/tf_ops/grouping/tf_grouping.cpp:275-288,368-384,453-459).
 Rows of empty balls are zero-filled (the reference leaves them unwritten).
 """
+import contextlib
 import ctypes
 import threading
 import weakref
@@ -28,21 +29,39 @@ def _check_xyz(op, xyz1, xyz2):
 GRID_BALL_QUERY_MIN_N = 512
 
 
-# The reference calls the ball query once per radius over the same point set (layers_util.py:134-147): the grid of the
-# LAST point set queried is kept, so that the second and third band skip the build (a quarter of a call at 16384 points).
-# A hit needs the same tensor OBJECT (weak reference: a new tensor in a recycled allocation is a different object), the
-# same torch version counter (every in-place torch op bumps it), pointer, shape and stream, and no capture in progress
-# (a replay would skip the build over new contents).  Writes through a raw pointer by code outside torch are not seen:
-# SHARE_GRID = False switches the sharing off.
-SHARE_GRID = True
+# The reference calls the ball query once per radius over the same point set (layers_util.py:134-147).  Inside a
+# `with shared_grid():` block the grid of the LAST point set queried is kept, so that the second and third band skip the
+# build (a quarter of a call at 16384 points).  OFF by default: a hit is decided from the tensor OBJECT (weak
+# reference), torch's version counter, pointer, shape and stream -- and the version counter does NOT see hipGraph
+# replays into static buffers, this library's own raw-pointer kernels (`out=` tensors, sa_copy_batches, any ctypes launch),
+# `.data` writes or custom ops.  The caller who opens the block states that xyz1 is not rewritten that way inside it.
+# Inference tensors (no version counter) and captures never share.
+SHARE_GRID = False
 _grid_lock = threading.Lock()      # look-up and launch are one step: a second thread must not see the entry before the build is enqueued
 _grid_of_last_call = None          # (weakref to xyz1, (version, data_ptr, shape, stream handle), workspace)
+
+
+@contextlib.contextmanager
+def shared_grid():
+    """Per-band calls over ONE point set inside the block build its grid once.  The caller guarantees that the point set
+    is only modified through torch in-place ops (which bump `_version`) while the block is open; graph replays and
+    raw-pointer writes into xyz1 are NOT detected.  The kept grid is dropped when the block closes."""
+    global SHARE_GRID, _grid_of_last_call
+    with _grid_lock:
+        before, SHARE_GRID = SHARE_GRID, True
+    try:
+        yield
+    finally:
+        with _grid_lock:
+            SHARE_GRID = before
+            if not before:
+                _grid_of_last_call = None
 
 
 def _grid_workspace(lib, xyz1, b, n, m, stream):
     """-> (workspace tensor, flags of sa_query_ball_point_grid_ex)."""
     global _grid_of_last_call
-    if not SHARE_GRID or torch.cuda.is_current_stream_capturing():
+    if not SHARE_GRID or xyz1.is_inference() or torch.cuda.is_current_stream_capturing():
         return torch.empty((lib.sa_query_ball_point_grid_ws_bytes(b, n, m) + 3) // 4, dtype=torch.int32, device=xyz1.device), 0
     g = _grid_of_last_call
     key = (xyz1._version, xyz1.data_ptr(), tuple(xyz1.shape), stream)
@@ -81,7 +100,8 @@ def _ball_query_one_band(op, min_radius, max_radius, nsample, dilated, xyz1, xyz
 
 def query_ball_point(radius, nsample, xyz1, xyz2):
     """xyz1: (batch, ndataset, 3), xyz2: (batch, npoint, 3) ->
-    idx (batch, npoint, nsample) int32, pts_cnt (batch, npoint) int32.   tf_grouping.py:53-66"""
+    idx (batch, npoint, nsample) int32, pts_cnt (batch, npoint) int32.   tf_grouping.py:53-66
+    Every call builds its own grid unless it runs inside `with shared_grid():` (see there for what that promises)."""
     T.require(float(radius) > 0, "QueryBallPoint expects positive radius")
     T.require(int(nsample) > 0, "QueryBallPoint expects positive nsample")
     xyz1 = T.f32_cuda(xyz1, "xyz1")
@@ -91,7 +111,8 @@ def query_ball_point(radius, nsample, xyz1, xyz2):
 
 
 def query_ball_point_dilated(min_radius, max_radius, nsample, xyz1, xyz2):
-    """Ball query on the band min_radius <= d < max_radius (plus d == 0).   tf_grouping.py:68-83"""
+    """Ball query on the band min_radius <= d < max_radius (plus d == 0).   tf_grouping.py:68-83
+    Every call builds its own grid unless it runs inside `with shared_grid():`."""
     T.require(float(min_radius) >= 0, "QueryBallPointDilated expects positive min_radius")
     T.require(float(max_radius) > 0, "QueryBallPointDilated expects positive max_radius")
     T.require(int(nsample) > 0, "QueryBallPointDilated expects positive nsample")

@@ -1282,34 +1282,40 @@ def test_stand_alone_band_calls_over_one_point_set_share_the_grid(gpu, oracle):
     xyz1 = _cloud(rng, b, n, scale=4.0, dup=100)               # extent 8 m over 126 cells: cell size = the radius above 0.07
     xyz2 = np.concatenate([xyz1[:, :400], _cloud(rng, b, m - 400, scale=5.0)], 1)
     t1, t2 = _t(xyz1, gpu), _t(xyz2, gpu)
-    assert G.SHARE_GRID
-    for radii in ((0.2, 0.4, 0.8, 1.7), (1.7, 0.8, 0.4, 0.2), (0.4, 0.4, 3.0, 0.1)):
-        for r in radii:
-            idx, cnt = G.query_ball_point(r, 32, t1, t2)
-            ridx, rcnt = oracle.query_ball_point(r, 32, xyz1, xyz2)
-            _check_ball(idx.cpu().numpy(), cnt.cpu().numpy(), ridx, rcnt)
-        g = G._grid_of_last_call
-        assert g is not None and g[0]() is t1
-    idx, cnt = G.query_ball_point_dilated(0.4, 0.8, 16, t1, t2)            # the dilated form through the same grid
-    ridx, rcnt = oracle.query_ball_point_dilated(0.4, 0.8, 16, xyz1, xyz2)
-    _check_ball(idx.cpu().numpy(), cnt.cpu().numpy(), ridx, rcnt)
-    # contents replaced in place: same object, same pointer, new version
-    xyz1b = _cloud(rng, b, n, scale=4.0, dup=50)
-    t1.copy_(_t(xyz1b, gpu))
-    idx, cnt = G.query_ball_point(0.4, 32, t1, t2)
-    ridx, rcnt = oracle.query_ball_point(0.4, 32, xyz1b, xyz2)
-    _check_ball(idx.cpu().numpy(), cnt.cpu().numpy(), ridx, rcnt)
-    # a new tensor (possibly in the allocation the old one left)
-    del t1
-    xyz1c = _cloud(rng, b, n, scale=4.0, dup=10)
-    t1 = _t(xyz1c, gpu)
-    idx, cnt = G.query_ball_point(0.4, 32, t1, t2)
-    ridx, rcnt = oracle.query_ball_point(0.4, 32, xyz1c, xyz2)
-    _check_ball(idx.cpu().numpy(), cnt.cpu().numpy(), ridx, rcnt)
-    # and with the sharing switched off
-    G.SHARE_GRID = False
-    try:
-        idx2, cnt2 = G.query_ball_point(0.4, 32, t1, t2)
-    finally:
-        G.SHARE_GRID = True
+    assert not G.SHARE_GRID                                     # off by default: sharing is the caller's statement
+    G.query_ball_point(0.4, 32, t1, t2)
+    assert G._grid_of_last_call is None
+    with G.shared_grid():
+        for radii in ((0.2, 0.4, 0.8, 1.7), (1.7, 0.8, 0.4, 0.2), (0.4, 0.4, 3.0, 0.1)):
+            for r in radii:
+                idx, cnt = G.query_ball_point(r, 32, t1, t2)
+                ridx, rcnt = oracle.query_ball_point(r, 32, xyz1, xyz2)
+                _check_ball(idx.cpu().numpy(), cnt.cpu().numpy(), ridx, rcnt)
+            g = G._grid_of_last_call
+            assert g is not None and g[0]() is t1
+        idx, cnt = G.query_ball_point_dilated(0.4, 0.8, 16, t1, t2)            # the dilated form through the same grid
+        ridx, rcnt = oracle.query_ball_point_dilated(0.4, 0.8, 16, xyz1, xyz2)
+        _check_ball(idx.cpu().numpy(), cnt.cpu().numpy(), ridx, rcnt)
+        # contents replaced in place: same object, same pointer, new version
+        xyz1b = _cloud(rng, b, n, scale=4.0, dup=50)
+        t1.copy_(_t(xyz1b, gpu))
+        idx, cnt = G.query_ball_point(0.4, 32, t1, t2)
+        ridx, rcnt = oracle.query_ball_point(0.4, 32, xyz1b, xyz2)
+        _check_ball(idx.cpu().numpy(), cnt.cpu().numpy(), ridx, rcnt)
+        # a new tensor (possibly in the allocation the old one left)
+        del t1
+        xyz1c = _cloud(rng, b, n, scale=4.0, dup=10)
+        t1 = _t(xyz1c, gpu)
+        idx, cnt = G.query_ball_point(0.4, 32, t1, t2)
+        ridx, rcnt = oracle.query_ball_point(0.4, 32, xyz1c, xyz2)
+        _check_ball(idx.cpu().numpy(), cnt.cpu().numpy(), ridx, rcnt)
+        # an inference tensor has no version counter: never shared, no exception
+        with torch.inference_mode():
+            ti = _t(xyz1c, gpu)
+            idx3, cnt3 = G.query_ball_point(0.4, 32, ti, t2)
+            idx3, cnt3 = G.query_ball_point(0.4, 32, ti, t2)
+        assert torch.equal(idx, idx3) and torch.equal(cnt, cnt3)
+    assert not G.SHARE_GRID and G._grid_of_last_call is None    # the block dropped its grid
+    # and outside the block
+    idx2, cnt2 = G.query_ball_point(0.4, 32, t1, t2)
     assert torch.equal(idx, idx2) and torch.equal(cnt, cnt2)

@@ -262,3 +262,16 @@ def test_pipeline_refuses_a_network_whose_sampler_must_stay_on_one_stream(gpu):
     for mode in ("staged", "slots"):
         with pytest.raises(ValueError, match="ffps_fly"):
             pkg("pipeline").SAPipeline(arch, params, gpu, batch=1, points=16384, streams=2, net=net, mode=mode, graphs=False)
+
+
+@pytest.mark.gpu
+def test_rccl_world_size_one_smoke():
+    """backend "nccl" (= RCCL) initialises on this box and sharding.reduce_timing / gather_check run
+    through it on device tensors (a process of its own: it owns the default process group).  Not a scaling point --
+    proof that librccl, the IPC setting and the collectives of this path work before an 8-GPU node appears."""
+    import importlib
+    sh = importlib.import_module("3dssd_amd.sharding")
+    out = sh.rccl_smoke_subprocess(timeout_s=240)
+    print("rccl smoke:", out)
+    assert out["status"] == "ok", out
+    assert out["gather_check"]["backend"] == "nccl (RCCL)" and out["gather_check"]["bytes_gathered"] > 0
