@@ -99,15 +99,16 @@ class PostProcessor:
             N.check(st, "boxes_to_bev")
         idx, cnt = self.nms(bev, pred_score)
         C, K = self.cls_num, self.max_output_size
-        valid = idx >= 0
-        safe = idx.clamp(min=0).long()
-        flat = safe.reshape(bs, C * K)
-        gb = torch.gather(boxes, 1, flat[..., None].expand(-1, -1, 7)) * valid.reshape(bs, C * K, 1)
-        sc = torch.gather(pred_score.transpose(1, 2).reshape(bs, C, n), 2, safe) * valid
-        cat = torch.arange(C, device=boxes.device, dtype=torch.int32)[None, :, None].expand(bs, C, K)
+        # the kept rows as fixed-size tensors: one launch (csrc/head.hip), no torch gather / where on the data path
+        gb = torch.empty((bs, C * K, 7), dtype=torch.float32, device=boxes.device)
+        sc = torch.empty((bs, C * K), dtype=torch.float32, device=boxes.device)
+        cat = torch.empty((bs, C * K), dtype=torch.int32, device=boxes.device)
+        st = N.lib().sa_nms_gather(bs, n, C, K, 1, boxes.data_ptr(), pred_score.data_ptr(), idx.data_ptr(), gb.data_ptr(),
+                                   sc.data_ptr(), cat.data_ptr(), N.current_stream())
+        N.check(st, "nms_gather")
         output_dict.setdefault("pred_3d_bbox", []).append(gb)
-        output_dict.setdefault("pred_3d_score", []).append(sc.reshape(bs, C * K))
-        output_dict.setdefault("pred_3d_cls_category", []).append(torch.where(valid, cat, torch.full_like(cat, -1)).reshape(bs, C * K))
+        output_dict.setdefault("pred_3d_score", []).append(sc)
+        output_dict.setdefault("pred_3d_cls_category", []).append(cat)
         output_dict.setdefault("nms_idx", []).append(idx)
         output_dict.setdefault("nms_cnt", []).append(cnt)
         return output_dict

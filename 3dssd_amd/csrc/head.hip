@@ -131,7 +131,41 @@ __global__ __launch_bounds__(64) void nms_bev_kernel(int n, int C, int max_out, 
     if (lane == 0) out_cnt[(size_t)b * C + c] = nsel;
 }
 
+// the kept candidates of every (frame, class) as fixed-size rows: box, score, class id (zeros / -1 behind the count)
+__global__ __launch_bounds__(256) void nms_gather_kernel(long total, int n, int C, int K, int kbox, const float *__restrict__ boxes,
+                                                         const float *__restrict__ scores, const int *__restrict__ idx,
+                                                         float *__restrict__ ob, float *__restrict__ os, int *__restrict__ oc) {
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(t % K);
+        const int c = (int)((t / K) % C);
+        const long b = t / ((long)K * C);
+        const int i = idx[t];
+        const bool ok = i >= 0;
+        const int r = c < kbox ? c : kbox - 1;                              // class-aware boxes: reg_i = min(i, k - 1), postprocessor.py:76-80
+        const float *bp = boxes + ((b * n + (ok ? i : 0)) * kbox + r) * 7;
+#pragma unroll
+        for (int e = 0; e < 7; ++e) ob[t * 7 + e] = ok ? bp[e] : 0.0f;
+        os[t] = ok ? scores[(b * n + i) * C + c] : 0.0f;
+        oc[t] = ok ? c : -1;
+    }
+}
+
 }  // namespace
+
+// The rows sa_nms_bev kept, as the reference's post-processor returns them (lib/builder/postprocessor.py:90-118: gather of
+// boxes / scores per class, class id), fixed-size: out_boxes [b,C*max_out,7], out_scores / out_cls [b,C*max_out]; rows
+// behind a class's count are zero with class -1.  boxes [b,n,kbox,7] (kbox = 1: class-agnostic), scores [b,n,C], idx [b,C,max_out].
+extern "C" int sa_nms_gather(int b, int n, int C, int max_out, int kbox, const float *boxes, const float *scores, const int *idx,
+                             float *out_boxes, float *out_scores, int *out_cls, hipStream_t stream) {
+    if (b <= 0 || n <= 0 || C <= 0 || max_out <= 0 || kbox <= 0 || !boxes || !scores || !idx || !out_boxes || !out_scores || !out_cls)
+        return SA_ERR_INVALID;
+    const long total = (long)b * C * max_out;
+    const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+    hipLaunchKernelGGL(nms_gather_kernel, dim3(grid), dim3(256), 0, stream, total, n, C, max_out, kbox, boxes, scores, idx, out_boxes,
+                       out_scores, out_cls);
+    SA_CHECK_LAUNCH();
+    return SA_OK;
+}
 
 // xyz [b,n,3], reg [b,n,6+2A] (offsets | angle cls | angle res), cls [b,n,C] -> boxes [b,n,7], scores [b,n,C],
 // bev [b,n,4].  Additional to the reference API (there it is TF graph code).

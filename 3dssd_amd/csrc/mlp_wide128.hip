@@ -38,7 +38,13 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector for the weight ring (plain loads / moves)
 
-constexpr int kNW = 8, kThreads = kNW * 64;
+#ifndef SA_W96_NW
+#define SA_W96_NW 8      // waves per workgroup: 8 (two per SIMD, two column tiles per wave and pass) or 16 (four per SIMD, one)
+#endif
+constexpr int kNW = SA_W96_NW, kThreads = kNW * 64;
+constexpr int kTPW = 16 / kNW;                       // column tiles of a wave in a pass of 16 over the last layer / in hidden 2
+constexpr int kH1W = 8;                              // column tiles of hidden 1 (width 256): the first 8 waves run it
+static_assert(kNW == 8 || kNW == 16, "8 or 16 waves");
 constexpr int kRows = 96, kRT = kRows / 32;         // row tiles of an item
 constexpr int kGB = 16;                              // LDS bytes of an 8-channel group (one fp16 plane)
 // weight fragments (k-steps) in flight per wave and column tile.  (A ring kept ALIVE across the phases of an item -- the
@@ -304,7 +310,7 @@ __device__ __forceinline__ void hidden_tiles(const unsigned char *in, int stride
 // Last layer (D form), column tiles ct0, ct0 + 1 of this wave over the whole contraction (KS a multiple of kD: host
 // check): k-steps below `ksplit` come from region `lo`, the others from region `hi` (the two 256-column halves of hidden
 // 2; ksplit is a multiple of DEPTH or >= KS).  Every block of DEPTH k-steps carries one tick of the next item's gather into `gbuf`.
-__device__ __forceinline__ void last_pass(f32x16 (&acc)[2][kRT], const unsigned char *lo, const unsigned char *hi, int ksplit,
+__device__ __forceinline__ void last_pass(f32x16 (&acc)[kTPW][kRT], const unsigned char *lo, const unsigned char *hi, int ksplit,
                                           int stride, const W128Layer &L, int ct0, int lane, const W128Params &P,
                                           unsigned char *gbuf, int gdummy, const RowRefs &R, int tid, GatherPipe &G,
                                           sa::f16_guard_t &det) {
@@ -312,16 +318,18 @@ __device__ __forceinline__ void last_pass(f32x16 (&acc)[2][kRT], const unsigned 
     const int half = lane >> 5, col = lane & 31;
     const int lane_off = col * stride + half * kGB;
     const int KS = L.KS;
-    const u32x4 *wb0 = (const u32x4 *)L.w + (size_t)(ct0 < L.NT ? ct0 : L.NT - 1) * KS * 64 + lane;
-    const u32x4 *wb1 = (const u32x4 *)L.w + (size_t)(ct0 + 1 < L.NT ? ct0 + 1 : L.NT - 1) * KS * 64 + lane;
-    u32x4 wq[DEPTH][2];
+    const u32x4 *wb[kTPW];
+    u32x4 wq[DEPTH][kTPW];
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {
-        wq[d][0] = wb0[d * 64];
-        wq[d][1] = wb1[d * 64];
+    for (int t = 0; t < kTPW; ++t) {
+        wb[t] = (const u32x4 *)L.w + (size_t)(ct0 + t < L.NT ? ct0 + t : L.NT - 1) * KS * 64 + lane;
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) wq[d][t] = wb[t][d * 64];
     }
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) asm volatile("" : "+v"(wq[d][0]), "+v"(wq[d][1]));   // see hidden_tiles
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+        for (int t = 0; t < kTPW; ++t) asm volatile("" : "+v"(wq[d][t]));   // see hidden_tiles
     // activation fragment r of k-step ks: region `lo` below ksplit, `hi` from there on (wave-uniform select)
     auto aptr = [&](int ks, int r) -> const uint4 * {
         const unsigned char *base = ks < ksplit ? lo + ks * 2 * kGB : hi + (ks - ksplit) * 2 * kGB;
@@ -336,19 +344,21 @@ __device__ __forceinline__ void last_pass(f32x16 (&acc)[2][kRT], const unsigned 
         for (int d = 0; d < DEPTH; ++d) {
             const int ks = ks0 + d;
             const int kn = ks + 1 < KS ? ks + 1 : KS - 1;
-            const uint4 w0 = __builtin_bit_cast(uint4, wq[d][0]), w1 = __builtin_bit_cast(uint4, wq[d][1]);   // KS % DEPTH == 0 (host check)
+            uint4 wf[kTPW];
+#pragma unroll
+            for (int t = 0; t < kTPW; ++t) wf[t] = __builtin_bit_cast(uint4, wq[d][t]);   // KS % DEPTH == 0 (host check)
 #pragma unroll
             for (int r = 0; r < kRT; ++r) {
-                acc[0][r] = mfma_f16(af[r], w0, acc[0][r]);
-                acc[1][r] = mfma_f16(af[r], w1, acc[1][r]);
+#pragma unroll
+                for (int t = 0; t < kTPW; ++t) acc[t][r] = mfma_f16(af[r], wf[t], acc[t][r]);
                 __builtin_amdgcn_sched_barrier(SA_W96_SBMASK_DS);     // in-place rotation of the activation fragments (see hidden_tiles)
                 af[r] = *aptr(kn, r);
             }
             // in-place refill behind the MFMAs that read the slot (see hidden_tiles)
             __builtin_amdgcn_sched_barrier(SA_W96_SBMASK);
             const int kw = ks + DEPTH < KS ? ks + DEPTH : KS - 1;
-            wq[d][0] = wb0[kw * 64];
-            wq[d][1] = wb1[kw * 64];
+#pragma unroll
+            for (int t = 0; t < kTPW; ++t) wq[d][t] = wb[t][kw * 64];
         }
     }
 }
@@ -356,7 +366,7 @@ __device__ __forceinline__ void last_pass(f32x16 (&acc)[2][kRT], const unsigned 
 constexpr int kHalfKS = 16;                                   // k-steps (256 columns) of hidden 2 that live in region 2
 static_assert(kHalfKS % kD == 0, "a block of k-steps of the last layer must not straddle the two halves of hidden 2");
 
-__global__ __launch_bounds__(kThreads, 2) void group_mlp_wide128_kernel(W128Params P) {
+__global__ __launch_bounds__(kThreads, kNW / 4) void group_mlp_wide128_kernel(W128Params P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int rbytes = kRows * P.rstride;
     unsigned char *regI = smem, *regH = smem + rbytes;        // input of this item / hidden 1 (and the next item's input)
@@ -366,7 +376,7 @@ __global__ __launch_bounds__(kThreads, 2) void group_mlp_wide128_kernel(W128Para
     const int ngran = __builtin_amdgcn_readfirstlane(P.hdr[0]);
     const int nitems = (ngran + kRows / 8 - 1) / (kRows / 8);      // 96-row items = 12 granules of the plan
     const W128Layer &L1 = P.L[0], &L2 = P.L[1], &L3 = P.L[2];
-    const int npass = (L3.NT + 2 * kNW - 1) / (2 * kNW);      // passes of 16 column tiles over the last layer
+    const int npass = (L3.NT + 15) / 16;                      // passes of 16 column tiles over the last layer
     const int nsteps = gp_steps(P);
     sa::f16_guard_t det = 0;
 
@@ -405,7 +415,7 @@ __global__ __launch_bounds__(kThreads, 2) void group_mlp_wide128_kernel(W128Para
         lds_barrier();                                        // this item's input is complete (gathered during the last item)
         WP_TICK(0)
         // ---- hidden 1: 8 column tiles, one per wave: I -> H
-        {
+        if (w < kH1W) {
             unsigned char *const ob[1] = {regH};
             const int ct[1] = {w}, oc[1] = {w};
             hidden_tiles<1, true>(regI, P.rstride, ob, P.rstride, L1, ct, oc, lane, det);
@@ -414,8 +424,8 @@ __global__ __launch_bounds__(kThreads, 2) void group_mlp_wide128_kernel(W128Para
         WP_TICK(1)
         // ---- hidden 2: column tiles w, w + 8 together: H -> (region 2 | I) (the gathered input is dead)
         const GatherTail tail = gt_issue(P, refs, tid);       // the next item's xyz tail, stored behind hidden 2
-        for (int ct = w; ct < L2.NT; ct += (SA_W96_H2PAIR ? 2 : 1) * kNW) {
-            if (SA_W96_H2PAIR && ct + kNW < L2.NT) {
+        for (int ct = w; ct < L2.NT; ct += (SA_W96_H2PAIR && kTPW == 2 ? 2 : 1) * kNW) {
+            if (SA_W96_H2PAIR && kTPW == 2 && ct + kNW < L2.NT) {
                 const int c2[2] = {ct, ct + kNW};
                 unsigned char *ob[2];
                 int oc[2];
@@ -436,15 +446,15 @@ __global__ __launch_bounds__(kThreads, 2) void group_mlp_wide128_kernel(W128Para
         gt_store(P, regH, tail, tid, det);
         gp_reset(gp, dumH);
         for (int p = 0; p < npass; ++p) {
-            const int ct0 = p * 2 * kNW + 2 * w;              // this wave's two column tiles of the pass
+            const int ct0 = p * 16 + kTPW * w;                // this wave's column tile(s) of the pass
             // their bias: requested HERE, used after the matrix loop (a load in front of the pooled write was waited
             // for -- a full memory round trip per tile)
-            float bias3[2];
+            float bias3[kTPW];
 #pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2) bias3[t2] = L3.bias[(ct0 + t2 < L3.NT ? ct0 + t2 : L3.NT - 1) * 32 + (lane & 31)];
-            f32x16 acc[2][kRT];
+            for (int t2 = 0; t2 < kTPW; ++t2) bias3[t2] = L3.bias[(ct0 + t2 < L3.NT ? ct0 + t2 : L3.NT - 1) * 32 + (lane & 31)];
+            f32x16 acc[kTPW][kRT];
 #pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2)
+            for (int t2 = 0; t2 < kTPW; ++t2)
 #pragma unroll
                 for (int r = 0; r < kRT; ++r)
 #pragma unroll
@@ -453,7 +463,7 @@ __global__ __launch_bounds__(kThreads, 2) void group_mlp_wide128_kernel(W128Para
             WP_TICK(3)
             const int col = lane & 31;
 #pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2) {
+            for (int t2 = 0; t2 < kTPW; ++t2) {
                 const int ct = ct0 + t2;
                 if (ct < L3.NT) {
                     const int ch = ct * 32 + col;
@@ -491,7 +501,7 @@ int sa_wide128_try(int b, int n, int m, int ns, int c, const float *xyz, const f
                    const float *const *bias, float *out, int out_stride, int out_off, const int *plan_hdr,
                    const int *plan_gran, long max_tiles, int fp16, int force, int dry, int *overflow, hipStream_t stream, int *st) {
     if (!fp16 || nl != 3 || c < 8 || (c & 7) || !feat) return 0;
-    if (dims[1] != 32 * kNW || (dims[2] & 31) || dims[2] > 512 || dims[2] < 128 || dims[3] < 32 * 2 * kNW || dims[3] > 2048) return 0;
+    if (dims[1] != 32 * kH1W || (dims[2] & 31) || dims[2] > 512 || dims[2] < 128 || dims[3] < 32 * 16 || dims[3] > 2048) return 0;
     // measured on layer4 of 3dssd.yaml: 259-256-512-1024 96 -> 88 us against group_mlp_wide_kernel's 105; 259-256-256-512
     // 48 us against mlp_rs_kernel's 35 (LDS-streamed weights win while the whole scale's weights are small): the narrower
     // scale stays where it was unless the caller forces this kernel (flags bit 5, tests)

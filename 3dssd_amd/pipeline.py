@@ -139,6 +139,24 @@ class Ticket:
             st.synchronize()
         return xyz, feat
 
+    def detections(self, copy=False):
+        """This batch's part of what the pipeline's `tail` produced behind the backbone (SAPipeline(tail=DetectionHead):
+        boxes, scores, classes, NMS indices / counts -- modeling.single_stage_detector.DETECTION_KEYS), as views of the
+        slot's static tensors (copy=True: clones).  Same validity rules as result()."""
+        self.result()                                         # waits, and raises what result() raises
+        r = self._round
+        T.require(r.slot.pipe.tail is not None, "this pipeline has no tail (SAPipeline(tail=...))")
+        if self._stale():
+            raise RuntimeError("this ticket's slot has been reused by a later submit")
+        B, p = r.slot.pipe.batch, self._part
+        out = {k: v[p * B:(p + 1) * B] for k, v in r.slot.extras[r.size].items()}
+        if copy:
+            st = r.slot.stream_b
+            with torch.cuda.stream(st):
+                out = {k: v.clone() for k, v in out.items()}
+            st.synchronize()
+        return out
+
     def all_outputs(self):
         """(xyz_list, feature_list, fps_idx_list) of this batch, as SABackbone.forward returns them (views of the slot's
         static buffers)."""
@@ -153,14 +171,14 @@ class Ticket:
 class _Slot:
     # graphs: {package size (batches): (stage-A graph or None, stage-B / whole graph)}; lists: {size: forward()'s lists}
     __slots__ = ("pipe", "index", "stream_a", "stream_b", "inp", "overflow", "graphs", "lists", "round", "last_event",
-                 "copy_batches", "src_ptrs", "inp_ptr")
+                 "copy_batches", "src_ptrs", "inp_ptr", "extras")
 
 
 class SAPipeline:
     def __init__(self, arch, params, device="cuda:0", batch=8, points=16384, channels=4, streams=None,
                  graphs=True, max_translate_range=(-3.0, -2.0, -3.0), aggregation_sa_feature=True, net=None,
                  precision=None, check_overflow=True, coalesce=1, mode="staged", timeline=False, linear_graphs=None,
-                 main_streams=MAIN_STREAMS, sampler_streams=1):
+                 main_streams=MAIN_STREAMS, sampler_streams=1, tail=None):
         """arch / params as for SABackbone.  mode / coalesce: module docstring.  `streams`: the number of slots --
         packages in the ring for mode="staged" (default 4), slots = HIP streams for mode="slots" (default 16).
         graphs=False launches eagerly on the same streams (same throughput with large packages, more host work).
@@ -170,7 +188,12 @@ class SAPipeline:
         mode="staged" (with branches the three streams + two branch streams share ROCm's default 4 hardware queues and
         block one another: 10.8 k instead of 16.2 k frames/s, profiles/r04_sweep_queues.txt); mode="slots" defaults to
         the branch form (15.7 k against 14.6 k on 16 queues).  main_streams / sampler_streams: streams the two stages
-        alternate between (2 / 1 by default: a second sampler stream was measured)."""
+        alternate between (2 / 1 by default: a second sampler stream was measured).
+        tail: a callable(lists) -> {name: tensor [batch x package, ...]} issued right behind the backbone on the same stream
+        (captured into the stage-B graph): what follows the backbone in the caller's network, e.g. the detection head +
+        decode + NMS (modeling.single_stage_detector.DetectionHead: `tail=lambda net: DetectionHead(net.variables, ...)`
+        is also accepted -- a factory called with the pipeline's network).  It must only launch on the current stream and
+        allocate shapes that depend on the package size alone; tickets return its outputs through detections()."""
         self.device = torch.device(device)
         T.require(self.device.type == "cuda", "SAPipeline needs a GPU: the HIP path has no CPU fallback")
         T.require(mode in ("staged", "slots"), "SAPipeline mode must be 'staged' or 'slots'")
@@ -197,6 +220,9 @@ class SAPipeline:
                                                            coop_capture=(mode == "staged" and bool(graphs) and int(points) > 16384))
         if net is not None:                           # what the caller's network really does, not what was asked for here
             self.linear_graphs = net.settings.get("dfps_side_stream") == 5
+        if tail is not None and getattr(tail, "_is_tail_factory", False):
+            tail = tail(self.net)
+        self.tail = tail
         self.check_overflow = bool(check_overflow)
         self.mode = mode
         self.batch, self.points, self.channels = int(batch), int(points), int(channels)
@@ -240,7 +266,7 @@ class SAPipeline:
         self.slots = []
         for i in range(self.nslots):
             s = _Slot()
-            s.pipe, s.index, s.graphs, s.lists = self, i, {}, {}
+            s.pipe, s.index, s.graphs, s.lists, s.extras = self, i, {}, {}, {}
             if self.mode == "staged":
                 s.stream_a, s.stream_b = self.sampler_streams[i % self.n_samp], self.main_streams[i % self.n_main]
             else:
@@ -260,7 +286,9 @@ class SAPipeline:
         warm[:, :, :3] = torch.rand((shape[0], self.points, 3), device=dev) * 20.0
         for size in self.sizes:
             for _ in range(2):
-                self.net(warm[:size * self.batch])
+                lists = self.net(warm[:size * self.batch])
+                if self.tail is not None:
+                    self.tail(lists)
         torch.cuda.synchronize(dev)
         for s in self.slots:
             s.inp.copy_(warm)
@@ -284,11 +312,15 @@ class SAPipeline:
                                 raise RuntimeError("forward_staged yielded twice")
                             except StopIteration as e:
                                 lists = e.value
+                            if self.tail is not None:
+                                s.extras[size] = self.tail(lists)
                         s.graphs[size] = (ga, gb)
                     else:
                         g = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(g, stream=s.stream_b, **kw):
                             lists = self.net(view)
+                            if self.tail is not None:
+                                s.extras[size] = self.tail(lists)
                         pool = pool or g.pool()
                         s.graphs[size] = (None, g)
                 s.lists[size] = lists
@@ -468,6 +500,8 @@ class SAPipeline:
                                 s.lists[size] = e.value
                         else:
                             s.lists[size] = self.net(view)
+                        if self.tail is not None:
+                            s.extras[size] = self.tail(s.lists[size])
                 xl, fl, _ = s.lists[size]
                 for part, (ox, of) in r.outs:
                     N.copy_blocks([(xl[-1][part * B:(part + 1) * B], ox, B, xl[-1].shape[1], 3),
@@ -546,3 +580,8 @@ class SAPipeline:
     def forward_eager(self, batch):
         """The same network, eager launches on the current stream (the reference result of the tests)."""
         return self.net(batch)
+
+    def tail_eager(self, batch):
+        """(lists, tail outputs) of one batch, eager launches on the current stream."""
+        lists = self.net(batch)
+        return lists, (self.tail(lists) if self.tail is not None else None)

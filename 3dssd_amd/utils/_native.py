@@ -53,6 +53,7 @@ SIGNATURES = {
     "sa_decode_anchor_free": [_c_int] * 4 + [_vp] * 7,
     "sa_boxes_to_bev": [_c_long, _vp, _vp, _vp],
     "sa_nms_bev": [_c_int] * 4 + [_c_float, _vp, _vp, _vp, _vp, _vp],
+    "sa_nms_gather": [_c_int] * 5 + [_vp] * 7,
     "sa_vote_translate": [_c_long, _vp, _vp, _c_float, _c_float, _c_float, _vp, _vp],
     "sa_vote_tail": [_c_long, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_float, _c_float, _c_float, _vp, _vp],
     "sa_three_nn": [_c_int] * 3 + [_vp, _vp, _vp, _vp, _vp],

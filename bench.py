@@ -4,7 +4,7 @@
     python bench.py --gpus N --steps K --warmup W            (N > 1 without torchrun: spawns the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
     python bench.py --data default|dup10|dense|rings64       (sensitivity of the data-dependent kernels)
-    python bench.py --workload configs2|configs4|group       (the other single-GPU configurations of BASELINE.json)
+    python bench.py --workload configs2|configs4|group|detector   (the other single-GPU configurations of BASELINE.json; points -> boxes)
     python bench.py --executor staged|slots                  (3dssd_amd/pipeline.py: default staged)
 
 A "step" is one batch of 8 DIFFERENT frames per GPU through the backbone, device-resident in and out: step i takes
@@ -172,6 +172,68 @@ EXECUTOR_NOTES = {
     "slots": "3dssd_amd.pipeline.SAPipeline(mode='slots'): %(n)d slots = %(n)d HIP streams, each with one captured hipGraph "
              "of the backbone over %(C)d batches x %(B)d frames; one block copy per step, one replay per %(C)d steps",
 }
+# ---- the secondary measurements the headline line carries as flat scalars --------------------------------
+# key -> (bench.py arguments of the sub-run, what to read from its line).  Each runs in a process of its own right after the
+# headline (the hardware-queue count and the executor's streams are per process), bounded by --extras-budget seconds in all.
+EXTRA_RUNS = [
+    ("steady512_frames_s", ["--steps", "512", "--warmup", "64"], "value"),
+    ("rings64_frames_s", ["--data", "rings64", "--steps", "512", "--warmup", "64"], "value"),
+    ("detector_frames_s", ["--workload", "detector", "--steps", "512", "--warmup", "64"], "value"),
+    ("configs4_frames_s", ["--workload", "configs4"], "value"),
+    ("configs2_frames_s", ["--workload", "configs2"], "value"),
+    ("group_b128_hbm_frac", ["--workload", "group", "--batch", "128", "--profile-iters", "1"], "roofline.frac"),
+    ("group_b32_hbm_frac", ["--workload", "group", "--batch", "32", "--profile-iters", "1"], "roofline.frac"),
+    ("group_b8_hbm_frac", ["--workload", "group", "--batch", "8", "--profile-iters", "1"], "roofline.frac"),
+    ("dense_frames_s", ["--data", "dense", "--steps", "256", "--warmup", "32"], "value"),
+]
+EXTRA_KEYS = [k for k, _a, _w in EXTRA_RUNS] + ["rccl_smoke"]
+
+
+def run_extras(args, line):
+    """Fill line["config"][EXTRA_KEYS] (already present, None) from sub-runs of this script; never raises."""
+    cfg = line["config"]
+    t_start = time.perf_counter()
+    budget = float(args.extras_budget)
+    detail, skipped = {}, []
+    base = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-other-executor", "--extras-budget", "0", "--verify", "0"]
+    if args.allow_knobs:
+        base.append("--allow-knobs")
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES" or args.hwq_from_env}
+    for key, extra, what in EXTRA_RUNS:
+        if key == "steady512_frames_s" and args.steps >= 512 and args.data == "default":
+            cfg[key] = line["value"]
+            continue
+        left = budget - (time.perf_counter() - t_start)
+        if left < 8.0:
+            skipped.append(key)
+            continue
+        cmd = base + (extra if "--profile-iters" in extra else extra + ["--profile-iters", "0"])
+        t0 = time.perf_counter()
+        try:
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=min(left, 90.0), env=env).stdout.strip().splitlines()
+            d = json.loads(out[-1])
+            v = d
+            for part in what.split("."):
+                v = v[part]
+            cfg[key] = v
+            detail[key] = {"seconds": round(time.perf_counter() - t0, 1), "steps": d.get("steps"), "ms_per_step": d.get("ms_per_step"),
+                           "verify": (d.get("verify") or {}).get("all_equal_eager")}
+        except Exception as e:  # noqa: BLE001 -- a secondary figure must not take the headline down
+            detail[key] = {"error": repr(e)[:200], "seconds": round(time.perf_counter() - t0, 1)}
+    left = budget - (time.perf_counter() - t_start)
+    if left >= 8.0:
+        r = pkg("sharding").rccl_smoke_subprocess(timeout_s=int(min(left, 120.0)))
+        cfg["rccl_smoke"] = r.get("status")
+        detail["rccl_smoke"] = r
+    else:
+        skipped.append("rccl_smoke")
+    line["extras"] = {"seconds": round(time.perf_counter() - t_start, 1), "budget_s": budget, "skipped": skipped, "runs": detail,
+                      "note": "sub-runs of this script in processes of their own right after the headline measurement (never inside "
+                              "its timed region): 512-step steady state, --data rings64 / dense, points -> boxes (--workload "
+                              "detector), configs[4] / configs[2], the unfused ball_query + group workload at 128 / 32 / 8 frames "
+                              "per call (roofline.frac = SURVEY 8d bytes / kernel time / 8 TB/s), and a world-size-1 RCCL smoke"}
+
+
 MLP_CALLS = ("sa_group_mlp_max", "sa_group_mlp_max_layer")
 MFMA_CALLS = MLP_CALLS + ("sa_dense", "sa_vote_tail")
 
@@ -734,10 +796,11 @@ def verify_pipeline(pipe, batches, nverify, submit_from=None):
     if nverify <= 0:
         return None
     submit_from = batches if submit_from is None else submit_from      # (the pinned host copies with --host-input)
-    eager = []
+    eager, eager_tail = [], []
     for i in range(nverify):
-        xl, fl, _ = pipe.forward_eager(batches[i])
-        eager.append((xl[-1].clone(), fl[-1].clone()))
+        lists, extra = pipe.tail_eager(batches[i])
+        eager.append((lists[0][-1].clone(), lists[1][-1].clone()))
+        eager_tail.append(None if extra is None else {k: v.clone() for k, v in extra.items()})
     torch.cuda.synchronize()
     equal, first = True, None
     per_round = pipe.nslots * pipe.coalesce                     # every slot full: that many batches in flight
@@ -747,21 +810,34 @@ def verify_pipeline(pipe, batches, nverify, submit_from=None):
         for i, t in tickets:
             x, f = t.result()
             ok = torch.equal(x, eager[i][0]) and torch.equal(f, eager[i][1])
+            if eager_tail[i] is not None:                        # --workload detector: boxes, scores, classes, NMS indices / counts
+                got = t.detections()
+                ok = ok and all(torch.equal(got[k], v) for k, v in eager_tail[i].items())
             equal = equal and ok
             if first is None:
                 first = (_sha1(f), _sha1(eager[i][1]))
     return {"batches": nverify, "slots_in_flight": min(pipe.nslots, -(-nverify // pipe.coalesce)),
             "batches_per_replay": pipe.coalesce, "all_equal_eager": bool(equal),
+            "tail_outputs_compared": sorted(eager_tail[0]) if eager_tail and eager_tail[0] is not None else None,
             "output_sha1_replay": first[0], "output_sha1_eager": first[1],
             "note": "every batch through the pipeline (graph replay over batches_per_replay batches at once, all slots "
                     "busy with other batches) against the eager result of THAT batch alone on one stream; sha1 of the "
                     "[B,256,512] feature output of pool batch 0 both ways"}
 
 
-def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
+def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag, detector=False):
     cfgs, syn = pkg("configs"), pkg("synthetic")
     arch = cfgs.KITTI_3DSSD_ARCH
     params = syn.random_backbone_params(arch)
+    tail = None
+    if detector:
+        # points -> boxes (README.md:10 of the reference quotes frames/s of the whole detector): the 'Det'
+        # head, anchor-free decode, BEV boxes, per-class NMS and the gather of the kept rows run as the executor's tail,
+        # captured behind stage B (3dssd_amd/modeling/single_stage_detector.py)
+        syn.random_head_params(512, 1, cfgs.KITTI_ANGLE_CLS_NUM, params=params)
+        tail = pkg("modeling.single_stage_detector").detection_tail(
+            cfgs.KITTI_3DSSD_HEAD, cls_num=1, angle_cls_num=cfgs.KITTI_ANGLE_CLS_NUM,
+            max_output_size=cfgs.KITTI_MAX_OUTPUT_NUM, nms_threshold=cfgs.KITTI_NMS_THRESH)
     quota = cgroup_cpu_quota()
     graphs_note = None
     if args.graphs is None:
@@ -779,7 +855,7 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
         return P.SAPipeline(arch, params, dev, batch=args.batch, points=points, channels=4, streams=max(1, args.streams),
                             graphs=graphs, max_translate_range=cfgs.KITTI_MAX_TRANSLATE_RANGE,
                             coalesce=max(1, args.coalesce), mode=args.executor, linear_graphs=args.linear_graphs,
-                            main_streams=args.main_streams, sampler_streams=args.sampler_streams)
+                            main_streams=args.main_streams, sampler_streams=args.sampler_streams, tail=tail)
     try:
         pipe = make(use_graphs)
     except Exception as e:  # noqa: BLE001
@@ -902,6 +978,14 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
     packages = pipe.timeline(base[0])
     x_last, f_last = tickets[-1].result()
     assert f_last.shape == (args.batch, 256, 512) and x_last.shape == (args.batch, 256, 3)
+    detections = None
+    if detector:
+        d_last = tickets[-1].detections()
+        assert d_last["pred_3d_bbox"].shape == (args.batch, cfgs.KITTI_MAX_OUTPUT_NUM, 7)
+        detections = {"boxes_kept_per_frame_last_batch": d_last["nms_cnt"].reshape(-1).cpu().tolist(),
+                      "max_output_num": cfgs.KITTI_MAX_OUTPUT_NUM, "nms_threshold": cfgs.KITTI_NMS_THRESH,
+                      "outputs": "pred_3d_bbox [B,%d,7], pred_3d_score, pred_3d_cls_category (lib/builder/postprocessor.py:90-118), "
+                                 "fixed size, zero rows behind the count" % cfgs.KITTI_MAX_OUTPUT_NUM}
     # configs[3] "RCCL result gather" (untimed): every rank's last batch of outputs all-gathered and checked by digest
     gathered = sh.gather_check(x_last, f_last) if args.gather else None
     overlap = overlap_probe(pipe, run, min(args.steps, 96)) if rank == 0 else None
@@ -944,14 +1028,15 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
     clock_mhz = MAX_CLOCK_MHZ
     # the calls as the pipeline issues them: one replay = `coalesce` batches in one pass
     launch = [torch.cat([batches[(i * C + j) % nb] for j in range(C)]) for i in range(min(max(nb // C, 1), 4))]
-    stages = profile_stages(lambda: net(launch[0]), args.profile_iters)
+    stages = profile_stages((lambda: pipe.tail(net(launch[0]))) if detector else (lambda: net(launch[0])), args.profile_iters)
     rows = mlp_row_stats(net, launch)
     fpl = args.batch * C                                        # frames per launch
     ms_step = t_max / args.steps * 1e3
     window_ms = t_max * 1e3
     line = {
-        "metric": "point-cloud frames/sec through full SA backbone, KITTI 16384-pt" if points == 16384 else
-                  "point-cloud frames/sec through full SA backbone, %d-pt frames" % points,
+        "metric": ("point-cloud frames/sec points -> boxes (SA backbone + Det head + decode + BEV NMS), KITTI 16384-pt" if detector else
+                   "point-cloud frames/sec through full SA backbone, KITTI 16384-pt" if points == 16384 else
+                   "point-cloud frames/sec through full SA backbone, %d-pt frames" % points),
         "value": round(frames_total / t_max, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
@@ -964,16 +1049,23 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
                                            if args.host_input else ""),
         "config": dict(
             # flat scalars FIRST (the driver record keeps those): what was run, and what decides a short window
-            [("workload", "%s: full 3DSSD SA backbone (3dssd.yaml rows 1-6), %d-pt frames, batch=%d per GPU" % (tag, points, args.batch)),
+            [("workload", ("%s: 3DSSD points -> boxes (3dssd.yaml rows 1-6 + HEAD row, decode, per-class BEV NMS), %d-pt frames, batch=%d per GPU"
+                           if detector else "%s: full 3DSSD SA backbone (3dssd.yaml rows 1-6), %d-pt frames, batch=%d per GPU")
+               % (tag, points, args.batch)),
              ("executor", args.executor), ("hip_graphs", use_graphs), ("frames_per_launch", fpl),
              ("timed_window_ms", round(window_ms, 3)),
              ("probe_window_ms", overlap["window_ms"] if overlap else None),
              ("timed_over_probe", round(window_ms / overlap["window_ms"], 3) if overlap and overlap["window_ms"] > 0 and
-              overlap["steps"] == args.steps else None),
+              overlap["steps"] == args.steps else None)] +
+            # the other claims of DESIGN.md, measured by THIS process right after the headline (run_extras),
+            # and the two cgroup scalars that say whether the host was throttled -- all inside the driver's first ~20 keys
+            [(k, None) for k in EXTRA_KEYS] +
+            [("cgroup_cpu_quota_cores", host.get("cgroup_cpu_quota_cores")), ("cgroup_nr_throttled", host.get("cgroup_nr_throttled")),
              ("rehearsals", len(rehearsal)), ("rehearsal_ms_first", rehearsal[0] if rehearsal else None),
              ("rehearsal_ms_min", min(rehearsal) if rehearsal else None), ("rehearsal_ms_max", max(rehearsal) if rehearsal else None),
              ("rehearsal_ms_last", rehearsal[-1] if rehearsal else None), ("blocking_wait", bool(args.blocking_wait)),
-             ("host_issue_ms_per_step", round(host_issue_ms, 4))] + list(host.items()) +
+             ("host_issue_ms_per_step", round(host_issue_ms, 4))] +
+            [(k, v) for k, v in host.items() if k not in ("cgroup_cpu_quota_cores", "cgroup_nr_throttled")] +
             [("pkg%d_%s_ms" % (i, nm), ms[j]) for i, (_sl, _f, ms) in enumerate(packages[:2])
              for j, nm in ((0, "reached"), (len(ms) - 1, "done"))] +
             [("sclk_before", clocks.get("before")), ("sclk_after", clocks.get("after")),
@@ -1013,6 +1105,8 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag):
         "mlp_rows_per_step": rows,
         "overlap": overlap,
     }
+    if detections is not None:
+        line["detections"] = detections
     if args.allow_shared_device and world > torch.cuda.device_count():
         line["shared_device"] = ("%d ranks on %d GPU(s): a functional check of the multi-rank path, NOT a scaling point"
                                  % (world, torch.cuda.device_count()))
@@ -1093,7 +1187,7 @@ def workload_ffps_isolated(args, sh, rank, world, dev):
             "warmup": args.warmup, "ms_per_step": round(t_max / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic KITTI-shape xyz + N(0,0.5) features (seeded)",
             "config": {"workload": "configs[2]: F-FPS isolated, [%d,%d,%d] -> %d per frame, batch=%d per GPU" % (batch, n, c, m, batch),
-                       "frames_per_step_per_gpu": len(frames), "data": args.data},
+                       "frames_per_step_per_gpu": len(frames), "data": args.data, "share_grid": bool(args.share_grid)},
             "timed_window_ms": round(t_max * 1e3, 3),
             "host_issue_ms_per_step": round(host_issue_ms, 3), "env_knobs": env_knobs()[0]}
     if stages:
@@ -1144,12 +1238,16 @@ def workload_group_materialised(args, sh, rank, world, dev):
         for _lo, _hi, ns in bands:
             by_alg += b * (m * ns * 4 + m * 4 + m * ns * (3 + c) * 4)
 
+    import contextlib
+
     def step():
         outs = []
-        for x_in, f_in, ctr, bands, dilated in jobs:
-            for lo, hi, ns in bands:
-                idx, cnt = (G.query_ball_point_dilated(lo, hi, ns, x_in, ctr) if dilated else G.query_ball_point(hi, ns, x_in, ctr))
-                outs.append((G.group_point(x_in, idx), G.group_point(f_in, idx)))
+        # --share-grid: the bands of a layer query ONE point set that nothing rewrites in between -- what shared_grid() is for
+        with (G.shared_grid() if args.share_grid else contextlib.nullcontext()):
+            for x_in, f_in, ctr, bands, dilated in jobs:
+                for lo, hi, ns in bands:
+                    idx, cnt = (G.query_ball_point_dilated(lo, hi, ns, x_in, ctr) if dilated else G.query_ball_point(hi, ns, x_in, ctr))
+                    outs.append((G.group_point(x_in, idx), G.group_point(f_in, idx)))
         return outs
 
     def run(k):
@@ -1199,7 +1297,7 @@ def workload_group_materialised(args, sh, rank, world, dev):
             "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 / int32 copies",
             "data": "synthetic KITTI-shape frames (seeded, --data %s); layer inputs taken from one backbone forward" % args.data,
             "config": {"workload": "ball_query + group_point materialised at the shapes of 3dssd.yaml rows 1-3, 6 (one band per call, like the reference), batch=%d per GPU" % args.batch,
-                       "frames_per_step_per_gpu": len(frames), "data": args.data},
+                       "frames_per_step_per_gpu": len(frames), "data": args.data, "share_grid": bool(args.share_grid)},
             "timed_window_ms": round(t_max * 1e3, 3), "host_issue_ms_per_step": round(host_issue_ms, 3), "env_knobs": env_knobs()[0],
             "roofline": {"kernel": "ball_query + group_point, all layers (one stream, HIP events per C-ABI call)", "bound": "hbm",
                          "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
@@ -1226,9 +1324,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="configs1", choices=["configs1", "configs2", "configs4", "group"],
+    ap.add_argument("--workload", default="configs1", choices=["configs1", "configs2", "configs4", "group", "detector"],
                     help="BASELINE.json configs[1] (default, the metric's configuration), configs[2], configs[4]; group: the "
-                         "reference's unfused ball_query + group_point sequence with materialised grouped tensors")
+                         "reference's unfused ball_query + group_point sequence with materialised grouped tensors; detector: "
+                         "configs[1] + Det head + decode + per-class BEV NMS (points -> boxes) through the same executor")
+    ap.add_argument("--extras-budget", type=float, default=75.0,
+                    help="seconds for the secondary measurements the configs[1] line carries as flat scalars (steady state, rings64, "
+                         "dense, detector, configs[2] / [4], group HBM fractions, RCCL smoke), each a sub-run of this script; 0: none")
+    ap.add_argument("--share-grid", action="store_true",
+                    help="--workload group: the per-band ball-query calls of a layer share one grid (tf_grouping.shared_grid(); off by default)")
     ap.add_argument("--data", default="default", choices=list(pkg("synthetic").DATA_VARIANTS),
                     help="default: SURVEY 8d generator; dup10: 10 %% duplicated rows (KITTI padding); dense: uniform box, every ball full")
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step")
@@ -1263,7 +1367,8 @@ def main():
     defaults = {"configs1": dict(steps=512, warmup=64, batch=8, points=16384, pool=256, verify=64, executor="staged"),
                 "configs2": dict(steps=4, warmup=1, batch=32, points=16384, streams=1, pool=32, verify=0, coalesce=1, executor="slots"),
                 "configs4": dict(steps=16, warmup=4, batch=16, points=65536, streams=4, pool=96, verify=8, coalesce=2, executor="staged"),
-                "group": dict(steps=20, warmup=5, batch=8, points=16384, streams=1, pool=8, verify=0, coalesce=1, executor="slots")}[args.workload]
+                "group": dict(steps=20, warmup=5, batch=8, points=16384, streams=1, pool=8, verify=0, coalesce=1, executor="slots"),
+                "detector": dict(steps=512, warmup=64, batch=8, points=16384, pool=256, verify=64, executor="staged")}[args.workload]
     for k, v in defaults.items():
         if getattr(args, k) is None:
             setattr(args, k, v)
@@ -1277,7 +1382,7 @@ def main():
     args.hwq_from_env = "GPU_MAX_HW_QUEUES" in os.environ
     if args.hw_queues is not None:
         os.environ["GPU_MAX_HW_QUEUES"] = str(args.hw_queues)
-    elif args.executor == "slots" and args.workload == "configs1" and not args.launch_check:
+    elif args.executor == "slots" and args.workload in ("configs1", "detector") and not args.launch_check:
         pkg("pipeline").request_hw_queues(args.streams)
 
     knobs, sa_keys = env_knobs()
@@ -1313,6 +1418,10 @@ def main():
 
     if args.workload == "configs1":
         line = workload_backbone(args, sh, rank, world, dev, args.points, True, "configs[1]")
+        if rank == 0 and world == 1 and args.extras_budget > 0 and not args.host_input:
+            run_extras(args, line)
+    elif args.workload == "detector":
+        line = workload_backbone(args, sh, rank, world, dev, args.points, True, "detector", detector=True)
     elif args.workload == "configs4":
         # 65536-pt frames: layer-1 FPS is the multi-workgroup kernel (fps_coop.hip); captured as a plain launch, every
         # such launch on the staged executor's one sampler stream (--executor slots falls back to eager launches)

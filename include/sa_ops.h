@@ -263,6 +263,11 @@ int sa_boxes_to_bev(long nboxes, const float *boxes, float *bev, sa_stream_t str
  * candidate indices in selection order padded with -1, cnt [b,C].  Equal scores: lower index first. */
 int sa_nms_bev(int b, int n, int C, int max_out, float iou_threshold, const float *bev, const float *scores,
                int *idx, int *cnt, sa_stream_t stream);
+/* the rows sa_nms_bev kept as fixed-size tensors (lib/builder/postprocessor.py:90-118): out_boxes [b,C*max_out,7],
+ * out_scores / out_cls [b,C*max_out], zero rows with class -1 behind a class's count.  boxes [b,n,kbox,7] (kbox = 1:
+ * class-agnostic; class i reads box set min(i, kbox-1), :76-80), scores [b,n,C], idx [b,C,max_out]. */
+int sa_nms_gather(int b, int n, int C, int max_out, int kbox, const float *boxes, const float *scores, const int *idx,
+                  float *out_boxes, float *out_scores, int *out_cls, sa_stream_t stream);
 
 /* ---- lib/utils/tf_ops/interpolation (used by the PointRCNN configurations) ------------ */
 

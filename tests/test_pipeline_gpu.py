@@ -275,3 +275,39 @@ def test_rccl_world_size_one_smoke():
     print("rccl smoke:", out)
     assert out["status"] == "ok", out
     assert out["gather_check"]["backend"] == "nccl (RCCL)" and out["gather_check"]["bytes_gathered"] > 0
+
+
+@pytest.mark.parametrize("mode,graphs", [("staged", True), ("slots", True), ("staged", False)])
+def test_detector_through_the_executor_equals_the_eager_detector(gpu, mode, graphs):
+    """head convolutions, anchor-free decode, BEV boxes, NMS and the gather of the kept rows run as the
+    executor's `tail`, captured behind stage B; a ticket's detections() are bit-equal to the eager SingleStageDetector on
+    the same batch (lib/modeling/single_stage_detector.py:115-125,195-228; lib/builder/postprocessor.py:49-123), on
+    DIFFERENT batches in flight, including a partly filled package."""
+    cfgs, syn = pkg("configs"), pkg("synthetic")
+    M = pkg("modeling.single_stage_detector")
+    arch = cfgs.KITTI_3DSSD_ARCH
+    params = syn.random_backbone_params(arch)
+    syn.random_head_params(512, 1, cfgs.KITTI_ANGLE_CLS_NUM, params=params)
+    kw = dict(cls_num=1, angle_cls_num=cfgs.KITTI_ANGLE_CLS_NUM, max_output_size=cfgs.KITTI_MAX_OUTPUT_NUM,
+              nms_threshold=cfgs.KITTI_NMS_THRESH)
+    pipe = pkg("pipeline").SAPipeline(arch, params, gpu, batch=2, points=16384, streams=3, coalesce=2, mode=mode, graphs=graphs,
+                                      max_translate_range=cfgs.KITTI_MAX_TRANSLATE_RANGE,
+                                      tail=M.detection_tail(cfgs.KITTI_3DSSD_HEAD, **kw))
+    det = M.SingleStageDetector(arch, cfgs.KITTI_3DSSD_HEAD, params, gpu, backbone=pipe.net, **kw)
+    dev = [torch.from_numpy(h).to(gpu) for h in _batches("default", 7, 2, first=700)]
+    eager = []
+    for t in dev:
+        out = det(t)
+        eager.append({k: out[k][0].clone() for k in M.DETECTION_KEYS})
+    torch.cuda.synchronize()
+    assert int(eager[0]["nms_cnt"].sum()) >= 2 and not torch.equal(eager[0]["pred_3d_bbox"], eager[1]["pred_3d_bbox"])
+    tickets = [pipe.submit(t) for t in dev[:6]]
+    got = [tk.detections(copy=True) for tk in tickets]
+    got.append(pipe.submit(dev[6]).detections())              # a package of one batch of two: launched by detections()
+    for i, g in enumerate(got):
+        for k in M.DETECTION_KEYS:
+            assert torch.equal(g[k], eager[i][k]), "batch %d, %s differs from the eager detector" % (i, k)
+    assert got[0]["pred_3d_bbox"].shape == (2, cfgs.KITTI_MAX_OUTPUT_NUM, 7) and got[0]["pred_3d_cls_category"].dtype == torch.int32
+    with pytest.raises(ValueError, match="no tail"):
+        pkg("pipeline").SAPipeline(arch, params, gpu, batch=2, points=16384, streams=1, graphs=False, net=pipe.net).submit(dev[0]).detections()
+    pipe.drain()
