@@ -76,11 +76,12 @@ def hw_queues():
 
 class _Round:
     """One use of a slot: the package of up to `coalesce` batches that is launched together."""
-    __slots__ = ("slot", "fill", "size", "launched", "event", "flag", "outs", "srcs")
+    __slots__ = ("slot", "fill", "size", "launched", "event", "flag", "outs", "srcs", "redo")
 
     def __init__(self, slot, flag):
         self.slot, self.fill, self.size, self.launched, self.event, self.flag, self.outs = slot, 0, 0, False, None, flag, []
         self.srcs = []            # (part, tensor) of the batches whose copy into the slot's buffer waits for the launch
+        self.redo = None          # (lists, tail outputs) of the package re-run in split bf16 after an fp16 range overflow
 
 
 class Ticket:
@@ -107,7 +108,7 @@ class Ticket:
 
     def _views(self):
         r, B = self._round, self._round.slot.pipe.batch
-        xl, fl, _ = r.slot.lists[r.size]
+        xl, fl, _ = r.redo[0] if r.redo is not None else r.slot.lists[r.size]
         return xl[-1][self._part * B:(self._part + 1) * B], fl[-1][self._part * B:(self._part + 1) * B]
 
     def result(self, copy=False):
@@ -120,13 +121,21 @@ class Ticket:
             raise RuntimeError("SA backbone: a multi-workgroup sampler launch gave up waiting for its partner workgroups "
                                "(csrc/fps_coop.hip / ffps_fly.hip: such launches must stay on one stream) -- the results of "
                                "the packages in flight are invalid; sa_coop_error_state(1) clears the sticky word")
-        if pipe.check_overflow and int(pipe._flags[r.flag]) != 0:
-            # fp16 scales guard their operand range (csrc/mlp_act.h): this round's own word, already on the host
-            raise FloatingPointError(
-                "SA backbone: an activation left the fp16 range (|x| > 65504, inf or NaN) in a scale evaluated in fp16 in "
-                "the package this batch ran in -- its results are invalid.  Use precision='bf16x3' for these weights.")
+        if pipe.check_overflow and int(pipe._flags[r.flag]) != 0 and r.redo is None:
+            # fp16 scales guard their operand range (csrc/mlp_act.h): this round's own word, already on the host.  The
+            # package is run again with every scale in split bf16 (no range limit, ~1e-5 of fp32) while its input is still
+            # in the slot -- a slower correct answer and a warning instead of an exception
+            if not pipe.rerun_overflow or self._stale():
+                raise FloatingPointError(
+                    "SA backbone: an activation left the fp16 range (|x| > 65504, inf or NaN) in a scale evaluated in fp16 in "
+                    "the package this batch ran in -- its results are invalid%s.  Use precision='bf16x3' for these weights."
+                    % (" and its slot has been reused, so it cannot be re-run" if pipe.rerun_overflow else ""))
+            pipe._rerun_bf16x3(r)
         if self._out is not None:
             return self._out
+        if r.redo is not None:                                # tensors of the re-run: owned by the round, never reused
+            xyz, feat = self._views()
+            return (xyz.clone(), feat.clone()) if copy else (xyz, feat)
         if self._stale():
             raise RuntimeError("this ticket's slot has been reused by a later submit (%d batches in flight at most): "
                                "call result() earlier, or submit(..., out=...) / result(copy=True)"
@@ -149,6 +158,8 @@ class Ticket:
         if self._stale():
             raise RuntimeError("this ticket's slot has been reused by a later submit")
         B, p = r.slot.pipe.batch, self._part
+        if r.redo is not None:
+            return {k: (v[p * B:(p + 1) * B].clone() if copy else v[p * B:(p + 1) * B]) for k, v in r.redo[1].items()}
         out = {k: v[p * B:(p + 1) * B] for k, v in r.slot.extras[r.size].items()}
         if copy:
             st = r.slot.stream_b
@@ -161,10 +172,12 @@ class Ticket:
         """(xyz_list, feature_list, fps_idx_list) of this batch, as SABackbone.forward returns them (views of the slot's
         static buffers)."""
         self.wait()
-        if self._stale():
-            raise RuntimeError("this ticket's slot has been reused by a later submit")
         B, p = self._round.slot.pipe.batch, self._part
         cut = lambda t: None if t is None else t[p * B:(p + 1) * B]
+        if self._round.redo is not None:
+            return tuple([cut(t) for t in lst] for lst in self._round.redo[0])
+        if self._stale():
+            raise RuntimeError("this ticket's slot has been reused by a later submit")
         return tuple([cut(t) for t in lst] for lst in self._round.slot.lists[self._round.size])
 
 
@@ -178,7 +191,7 @@ class SAPipeline:
     def __init__(self, arch, params, device="cuda:0", batch=8, points=16384, channels=4, streams=None,
                  graphs=True, max_translate_range=(-3.0, -2.0, -3.0), aggregation_sa_feature=True, net=None,
                  precision=None, check_overflow=True, coalesce=1, mode="staged", timeline=False, linear_graphs=None,
-                 main_streams=MAIN_STREAMS, sampler_streams=1, tail=None):
+                 main_streams=MAIN_STREAMS, sampler_streams=1, tail=None, rerun_overflow=True):
         """arch / params as for SABackbone.  mode / coalesce: module docstring.  `streams`: the number of slots --
         packages in the ring for mode="staged" (default 4), slots = HIP streams for mode="slots" (default 16).
         graphs=False launches eagerly on the same streams (same throughput with large packages, more host work).
@@ -193,7 +206,10 @@ class SAPipeline:
         (captured into the stage-B graph): what follows the backbone in the caller's network, e.g. the detection head +
         decode + NMS (modeling.single_stage_detector.DetectionHead: `tail=lambda net: DetectionHead(net.variables, ...)`
         is also accepted -- a factory called with the pipeline's network).  It must only launch on the current stream and
-        allocate shapes that depend on the package size alone; tickets return its outputs through detections()."""
+        allocate shapes that depend on the package size alone; tickets return its outputs through detections().
+        rerun_overflow: a package whose fp16 scales raised the range flag is run again, eagerly, with every scale in split
+        bf16 (a second packing of the same parameters, built on first use) and its tickets return THAT result with a
+        RuntimeWarning; False (or a slot already reused): FloatingPointError as before."""
         self.device = torch.device(device)
         T.require(self.device.type == "cuda", "SAPipeline needs a GPU: the HIP path has no CPU fallback")
         T.require(mode in ("staged", "slots"), "SAPipeline mode must be 'staged' or 'slots'")
@@ -224,6 +240,10 @@ class SAPipeline:
             tail = tail(self.net)
         self.tail = tail
         self.check_overflow = bool(check_overflow)
+        self.rerun_overflow = bool(rerun_overflow)
+        self._safe_net = None
+        self._net_args = (arch, max_translate_range, aggregation_sa_feature)
+        self.reruns = 0
         self.mode = mode
         self.batch, self.points, self.channels = int(batch), int(points), int(channels)
         if streams is None:
@@ -580,6 +600,32 @@ class SAPipeline:
     def forward_eager(self, batch):
         """The same network, eager launches on the current stream (the reference result of the tests)."""
         return self.net(batch)
+
+    def _rerun_bf16x3(self, r):
+        """The package of round `r` again, eager launches on its main stream, every grouped-MLP scale in split bf16: the
+        slot's input buffer still holds the package (the caller checked that the slot has not been reused)."""
+        s = r.slot
+        if self._safe_net is None:
+            arch, mtr, agg = self._net_args
+            T.require(arch is not None, "SAPipeline was built around a caller's network without `arch`: it cannot re-run an "
+                                        "overflowed package (pass rerun_overflow=False, or precision='bf16x3')")
+            self._safe_net = SABackbone(arch, self.net.variables.params, self.device, mtr, agg, precision="bf16x3",
+                                        dfps_side_stream=5)
+        warnings.warn("SAPipeline: an activation left the fp16 range in the package of %d batch(es) on slot %d; the package "
+                      "was run again in split bf16 (about three times the MLP time) -- consider precision='bf16x3' for these "
+                      "weights" % (r.fill, s.index), RuntimeWarning, stacklevel=3)
+        B = self.batch
+        with torch.cuda.device(self.device), torch.cuda.stream(s.stream_b):
+            view = s.inp[:r.size * B].clone()                 # the re-run must not race the slot's next round
+            lists = self._safe_net(view)
+            extras = self.tail(lists) if self.tail is not None else None
+            for part, (ox, of) in r.outs:                     # out= tensors of the submits: overwritten with the good result
+                N.copy_blocks([(lists[0][-1][part * B:(part + 1) * B], ox, B, lists[0][-1].shape[1], 3),
+                               (lists[1][-1][part * B:(part + 1) * B], of, B, lists[1][-1].shape[1], lists[1][-1].shape[2])])
+        s.stream_b.synchronize()
+        self._safe_net.raise_if_overflow()                    # split bf16 has no range guard to trip; a NaN input still raises
+        r.redo = (lists, extras)
+        self.reruns += 1
 
     def tail_eager(self, batch):
         """(lists, tail outputs) of one batch, eager launches on the current stream."""

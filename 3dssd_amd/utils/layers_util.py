@@ -46,6 +46,7 @@ AGGREGATION_SA_FEATURE = True
 # These are plain module attributes: nothing in the package reads the environment (experiments set them from tools/).
 DFPS_SIDE_STREAM = 6
 PLAN_LOG = None     # set to a list to collect (b, m, nsample, MACs per row, plan tensor) of every fused-MLP call
+CONCAT_LOG = None   # set to a list to collect (scope, pooled concat tensor [B,m,sum N], offsets, widths, precisions) per SA layer
 MLP_PLAN_FLAGS = 0  # sa_group_mlp_max flag bit 0 (all nsample rows instead of the distinct ones), A/B measurements
 # Row plans in granules of 4 rows for the scales the row-wave kernels take (csrc/mlp_plan.h; flag bit 6).  Built in round 5,
 # bit-identical, MEASURED and left off (profiles/r05_granule4_ab.txt, 128 frames per launch): on the sparse default frames
@@ -525,6 +526,8 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
                 nl = len(layers[i])
                 d_ = [c_feat + 3] + [l.N for l in layers[i]]
                 PLAN_LOG.append((bs, m, int(nsample_list[i]), sum(d_[j] * d_[j + 1] for j in range(nl)), plans[i][0]))
+        if CONCAT_LOG is not None:                                          # tests: the pooled outputs of the scales before the aggregation layer
+            CONCAT_LOG.append((scope, new_points_concat, list(offs), [ls[-1].N for ls in layers], [ls[0].precision for ls in layers]))
         if (AGGREGATION_SA_FEATURE if aggregation_sa_feature is None else aggregation_sa_feature):   # :184-185
             agg = vs.layer(scope + "/ensemble", bn)
             T.require(agg.N == aggregation_channel, "aggregation_channel does not match the ensemble weights")

@@ -178,12 +178,13 @@ def test_coalescing_slots_give_every_batch_its_own_eager_result(gpu, mode):
 def test_fp16_range_flag_is_raised_for_the_offending_package_only(gpu):
     # every round of a slot has its own flag word (one sticky word per VariableStore let ticket A raise for an
     # overflow of a concurrent batch C, and C then pass): a frame whose features are huge overflows the fp16 scales of
-    # layer 3 -- its ticket raises, the tickets of the batches around it do not, and the slot is clean afterwards
+    # layer 3 -- its ticket raises (rerun_overflow=False), the tickets of the batches around it do not, and the slot is
+    # clean afterwards
     cfgs, syn = pkg("configs"), pkg("synthetic")
     arch = cfgs.KITTI_3DSSD_ARCH
     for mode in ("staged", "slots"):
         pipe = pkg("pipeline").SAPipeline(arch, syn.random_backbone_params(arch), gpu, batch=1, points=16384, streams=3,
-                                          max_translate_range=cfgs.KITTI_MAX_TRANSLATE_RANGE, mode=mode)
+                                          max_translate_range=cfgs.KITTI_MAX_TRANSLATE_RANGE, mode=mode, rerun_overflow=False)
         dev = [torch.from_numpy(h).to(gpu) for h in _batches("default", 3, 1, first=40)]
         hot = dev[1].clone()
         hot[:, :, 3] = 3.0e7
@@ -196,6 +197,53 @@ def test_fp16_range_flag_is_raised_for_the_offending_package_only(gpu):
         clean = [pipe.submit(t) for t in dev]          # the same three slots again, without the hot frame
         for t in clean:
             assert torch.isfinite(t.result()[1]).all()
+
+
+def test_overflowed_package_is_rerun_in_split_bf16(gpu):
+    """an activation that leaves the fp16 range (one hot input channel: what a real checkpoint can do)
+    no longer turns into an exception.  The executor runs that package again with every scale in split bf16 and its
+    tickets return THAT result with a RuntimeWarning: equal, bit for bit, to an eager precision='bf16x3' network on the
+    same batch, and finite; packages around it are untouched (fp16 path),
+    the out= tensors of the submit hold the corrected result, a ticket whose slot was reused still raises."""
+    cfgs, syn = pkg("configs"), pkg("synthetic")
+    arch = cfgs.KITTI_3DSSD_ARCH
+    params = syn.random_backbone_params(arch)
+    P = pkg("pipeline")
+    pipe = P.SAPipeline(arch, params, gpu, batch=1, points=16384, streams=2, coalesce=2,
+                        max_translate_range=cfgs.KITTI_MAX_TRANSLATE_RANGE)
+    safe = pkg("backbone").SABackbone(arch, params, gpu, cfgs.KITTI_MAX_TRANSLATE_RANGE, precision="bf16x3")
+    dev = [torch.from_numpy(h).to(gpu) for h in _batches("default", 4, 1, first=40)]
+    hot = dev[1].clone()
+    hot[:, :, 3] *= 3.0e7                                       # intensities up to 3e7: the activations entering layer 3 pass 65504
+    ref_hot = safe(hot)
+    ref_cold = safe(dev[0])
+    torch.cuda.synchronize()
+    safe.raise_if_overflow()
+    outs = (torch.empty((1, 256, 3), device=gpu), torch.empty((1, 256, 512), device=gpu))
+    t0, t1 = pipe.submit(dev[0]), pipe.submit(hot, out=outs)    # one package: the cold batch shares the hot one's fate
+    t2, t3 = pipe.submit(dev[2]), pipe.submit(dev[3])           # the next package: untouched
+    with pytest.warns(RuntimeWarning, match="split bf16"):
+        x1, f1 = t1.result()
+    assert pipe.reruns == 1
+    assert torch.equal(f1, ref_hot[1][-1]) and torch.equal(x1, ref_hot[0][-1]) and torch.isfinite(f1).all()
+    assert torch.equal(outs[1], ref_hot[1][-1])
+    il = t1.all_outputs()[2]
+    assert torch.equal(il[1], ref_hot[2][1])                    # the FPS indices of the re-run, not of the fp16 run
+    x0, f0 = t0.result(copy=True)                               # same package: it was re-run as a whole (once), frames are independent
+    assert pipe.reruns == 1 and torch.equal(f0, ref_cold[1][-1]) and torch.equal(x0, ref_cold[0][-1])
+    import warnings as _w
+    with _w.catch_warnings():
+        _w.simplefilter("error")                                # the clean package raises nothing and warns nothing
+        assert torch.isfinite(t2.result()[1]).all() and torch.isfinite(t3.result()[1]).all()
+    # a ticket whose slot has been reused cannot be re-run: the old behaviour
+    ta = pipe.submit(hot)
+    pipe.flush()
+    for _ in range(2 * pipe.nslots):
+        pipe.submit(dev[2])
+    pipe.flush()
+    with pytest.raises(FloatingPointError, match="reused"):
+        ta.result()
+    pipe.drain()
 
 
 def test_inputs_may_be_dropped_right_after_submit(gpu, pipe6):
