@@ -232,6 +232,10 @@ extern "C" int sa_ffps_fly_ex(int b, int n, int c1, int m, const float *xyz, lon
         __atomic_store_n(&g_cap64, cap, __ATOMIC_RELEASE);
     }
     if (cap < G) return SA_ERR_UNSUPPORTED;
+    if (!err_word) {                                        // no error word (its allocation is refused during a capture): never run unchecked under one
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return SA_ERR_UNSUPPORTED; }
+    }
     const int per_launch = cap / G;
     if (hipMemsetAsync(workspace, 0, sa_ffps_fly_ws_bytes(b, n), stream) != hipSuccess) return SA_ERR_LAUNCH;
     for (int f0 = 0; f0 < b; f0 += per_launch) {

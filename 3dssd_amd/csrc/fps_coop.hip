@@ -194,6 +194,7 @@ static int fps_coop_launch(int b, int n, int c, int m, const float *inp, float *
     }
     const bool capturing = cs != hipStreamCaptureStatusNone;   // -> plain launches (header comment), opt-in
     if (capturing && !capture_ok) return SA_ERR_UNSUPPORTED;
+    if (capturing && !err_word) return SA_ERR_UNSUPPORTED;     // no error word (its allocation is refused during a capture): never run unchecked
     int cap = __atomic_load_n(&v->cap, __ATOMIC_ACQUIRE);
     if (cap == 0) {                                     // first use (two threads may both query: same answer)
         int dev = 0, cus = 0, per_cu = 0, coop = 0;

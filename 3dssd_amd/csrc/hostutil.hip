@@ -5,25 +5,33 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <mutex>
 
 #include "sa_common.h"
 
 namespace sa {
 int *coop_error_word() {
-    static int *word = nullptr;
-    static std::once_flag once;
-    std::call_once(once, [] {
-        void *p = nullptr;
-        // pinned + mapped: the device stores into it directly, the host reads it without a synchronisation
-        if (hipHostMalloc(&p, 64, hipHostMallocMapped) == hipSuccess && p) {
-            word = (int *)p;
-            *word = 0;
-        } else {
-            (void)hipGetLastError();
-        }
-    });
-    return word;
+    // Allocated on first use and RETRIED until it succeeds (under call_once a first use inside a global-mode
+    // stream capture -- where hipHostMalloc is refused -- left the word null for the life of the process, and a partner
+    // loss then went unreported).  3dssd_amd.utils._native.lib() asks for it when the library is loaded on a GPU box.
+    static std::atomic<int *> word{nullptr};
+    static std::mutex mu;
+    int *w = word.load(std::memory_order_acquire);
+    if (w) return w;
+    std::lock_guard<std::mutex> lock(mu);
+    w = word.load(std::memory_order_acquire);
+    if (w) return w;
+    void *p = nullptr;
+    // pinned + mapped: the device stores into it directly, the host reads it without a synchronisation
+    if (hipHostMalloc(&p, 64, hipHostMallocMapped) == hipSuccess && p) {
+        w = (int *)p;
+        *w = 0;
+        word.store(w, std::memory_order_release);
+    } else {
+        (void)hipGetLastError();
+    }
+    return w;
 }
 }  // namespace sa
 

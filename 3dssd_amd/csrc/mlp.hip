@@ -1574,7 +1574,7 @@ static bool scale_takes_rowwave(int b, int n, int m, int ns, int c, int nl, cons
     const long max_tiles = (sa_plan_max_granules((long)b * m, ns) + 3) / 4;
     int st = SA_OK;
     if (fp16 && !(flags & 8) && ((flags & 32) || (long)b * m * ns >= 4096) &&
-        sa_wide128_try(b, n, m, ns, c, nullptr, (const float *)wpack, nullptr, nullptr, nullptr, nl, dims, wpack, bias3, nullptr, 0, 0,
+        sa_wide128_try(b, n, m, ns, c, nullptr, nullptr, nullptr, nullptr, nullptr, nl, dims, wpack, bias3, nullptr, 0, 0,
                        nullptr, nullptr, max_tiles, 1, (flags & 32) ? 1 : 0, 1, nullptr, nullptr, &st))
         return false;
     return sa_rowwave_try(b, n, m, ns, c, nullptr, nullptr, nullptr, nullptr, nullptr, nl, dims, wpack, bias3, nullptr, 0, 0,

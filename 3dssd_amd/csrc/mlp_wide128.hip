@@ -500,7 +500,9 @@ int sa_wide128_try(int b, int n, int m, int ns, int c, const float *xyz, const f
                    const int *idx, const int *cnt, int nl, const int *dims, const void *const *wpack,
                    const float *const *bias, float *out, int out_stride, int out_off, const int *plan_hdr,
                    const int *plan_gran, long max_tiles, int fp16, int force, int dry, int *overflow, hipStream_t stream, int *st) {
-    if (!fp16 || nl != 3 || c < 8 || (c & 7) || !feat) return 0;
+    // shape / eligibility first -- the `dry` question (sa_group_mlp_granule_rows: which kernel WOULD take the scale) is
+    // answered from the scalars alone, before any pointer is looked at
+    if (!fp16 || nl != 3 || c < 8 || (c & 7)) return 0;
     if (dims[1] != 32 * kH1W || (dims[2] & 31) || dims[2] > 512 || dims[2] < 128 || dims[3] < 32 * 16 || dims[3] > 2048) return 0;
     // measured on layer4 of 3dssd.yaml: 259-256-512-1024 96 -> 88 us against group_mlp_wide_kernel's 105; 259-256-256-512
     // 48 us against mlp_rs_kernel's 35 (LDS-streamed weights win while the whole scale's weights are small): the narrower
@@ -526,7 +528,8 @@ int sa_wide128_try(int b, int n, int m, int ns, int c, const float *xyz, const f
     P.ksplit = kHalfKS;
     const size_t lds = (size_t)3 * kRows * P.rstride + 16;
     if (lds > 160 * 1024) return 0;
-    if (dry) { *st = SA_OK; return 1; }          // the shape would be taken (nothing launched)
+    if (dry) { *st = SA_OK; return 1; }          // the shape would be taken (nothing launched, no pointer read)
+    if (!feat) return 0;
     (void)hipFuncSetAttribute((const void *)group_mlp_wide128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipGetLastError();
     const long nitems = (max_tiles + kRT - 1) / kRT;

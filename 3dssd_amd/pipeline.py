@@ -117,10 +117,12 @@ class Ticket:
         self.wait()
         r = self._round
         pipe = r.slot.pipe
-        if N.lib().sa_coop_error_state(0) != 0:
+        if pipe.uses_coop_samplers and N.lib().sa_coop_error_state(0) != 0:
+            # the word is process-wide and sticky; only a network with multi-workgroup samplers (frames beyond 16384
+            # points) consults it, and SAPipeline.clear_sampler_error() resets it once the cause is dealt with
             raise RuntimeError("SA backbone: a multi-workgroup sampler launch gave up waiting for its partner workgroups "
                                "(csrc/fps_coop.hip / ffps_fly.hip: such launches must stay on one stream) -- the results of "
-                               "the packages in flight are invalid; sa_coop_error_state(1) clears the sticky word")
+                               "the packages in flight are invalid; SAPipeline.clear_sampler_error() clears the sticky word")
         if pipe.check_overflow and int(pipe._flags[r.flag]) != 0 and r.redo is None:
             # fp16 scales guard their operand range (csrc/mlp_act.h): this round's own word, already on the host.  The
             # package is run again with every scale in split bf16 (no range limit, ~1e-5 of fp32) while its input is still
@@ -240,6 +242,8 @@ class SAPipeline:
             tail = tail(self.net)
         self.tail = tail
         self.check_overflow = bool(check_overflow)
+        # multi-workgroup samplers (csrc/fps_coop.hip) run for frames of more than 16384 points only (ffps_fly is refused above)
+        self.uses_coop_samplers = int(points) > 16384
         self.rerun_overflow = bool(rerun_overflow)
         self._safe_net = None
         self._net_args = (arch, max_translate_range, aggregation_sa_feature)
@@ -388,12 +392,15 @@ class SAPipeline:
         return torch.cuda.Event(enable_timing=timing)
 
     # ------------------------------------------------------------------------------------------------ use
-    def submit(self, batch, out=None, sync_source=True):
+    def submit(self, batch, out=None, sync_source=True, defer_copy=False):
         """Enqueue one batch [B, points, channels] fp32 (device tensor; a pinned host tensor is copied
         asynchronously).  Returns immediately.  sync_source=False skips the event that orders the copy behind the
-        stream that produced `batch` (for inputs known to be complete, e.g. a resident pool); such a batch is copied when
-        its PACKAGE is launched (one launch for the whole package), so it must stay unchanged until then -- the executor
-        keeps the tensor alive, the caller may drop its reference at once.
+        stream that produced `batch` (for inputs known to be complete, e.g. a resident pool).  defer_copy=True (with
+        sync_source=False, a dense 16-byte-aligned device batch) only NOTES the source: it is copied when its PACKAGE is
+        launched -- one launch for the whole package instead of one per batch -- so the caller promises to leave the
+        tensor's CONTENTS unchanged until the package has been launched (the submit that fills it, flush(), or a
+        result()); the executor keeps the tensor alive, the reference may be dropped at once.  Without it the copy is
+        enqueued by submit itself, as it always was (the deferred form used to be implicit).
         out = (xyz [B,m,3], feat [B,m,C]): the results are additionally copied there on the slot's stream.
         With coalesce > 1 the package is launched by the submit that fills it (or by flush / drain / result)."""
         T.require(isinstance(batch, torch.Tensor) and tuple(batch.shape) == (self.batch, self.points, self.channels),
@@ -407,7 +414,7 @@ class SAPipeline:
             self._flag_next = (self._flag_next + 1) % _FLAG_RING
         part = r.fill
         st = s.stream_a
-        fast = (batch.is_cuda and batch.is_contiguous() and not sync_source and (batch.data_ptr() & 15) == 0 and
+        fast = (defer_copy and batch.is_cuda and batch.is_contiguous() and not sync_source and (batch.data_ptr() & 15) == 0 and
                 (self._part_bytes & 15) == 0)
         if fast:
             # resident, dense, already complete: the submit only NOTES the source (the round keeps the tensor alive); the
@@ -600,6 +607,13 @@ class SAPipeline:
     def forward_eager(self, batch):
         """The same network, eager launches on the current stream (the reference result of the tests)."""
         return self.net(batch)
+
+    def clear_sampler_error(self):
+        """Reset the process-wide sticky word a multi-workgroup sampler raises when it loses its partner workgroups
+        (-> the value it held).  Call after the packages in flight have been drained and discarded: tickets of later
+        packages are valid again."""
+        self.drain()
+        return int(N.lib().sa_coop_error_state(1))
 
     def _rerun_bf16x3(self, r):
         """The package of round `r` again, eager launches on its main stream, every grouped-MLP scale in split bf16: the

@@ -87,6 +87,7 @@ _ERRORS = {-1: "invalid argument", -2: "kernel launch failed (hipGetLastError)",
                "such launches must stay on one stream -- sa_coop_error_state(1) clears the sticky word)"}
 _LIB = None
 _EXTRA = None
+_COOP_WORD_ASKED = [False]
 
 
 class NativeLibraryError(RuntimeError):
@@ -125,6 +126,18 @@ def lib():
         h.sa_host_crc32c.argtypes = [_vp, ctypes.c_size_t, ctypes.c_uint32]          # host helper: returns the CRC
         h.sa_host_crc32c.restype = ctypes.c_uint32
         _LIB = h
+    if not _COOP_WORD_ASKED[0]:
+        # the sticky error word of the multi-workgroup samplers is pinned host memory: ask for it NOW, outside any stream
+        # capture (hipHostMalloc is refused inside a global-mode capture -- ADVICE r5), as soon as a GPU is there
+        try:
+            import torch
+            if not torch.cuda.is_available():
+                _COOP_WORD_ASKED[0] = True                  # no device: nothing to allocate, do not ask again
+            elif not torch.cuda.is_current_stream_capturing():
+                _COOP_WORD_ASKED[0] = True
+                _LIB.sa_coop_error_state(0)
+        except Exception:  # noqa: BLE001 -- the library itself retries on the first sampler call
+            _COOP_WORD_ASKED[0] = True
     return _LIB
 
 

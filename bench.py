@@ -805,7 +805,7 @@ def verify_pipeline(pipe, batches, nverify, submit_from=None):
     equal, first = True, None
     per_round = pipe.nslots * pipe.coalesce                     # every slot full: that many batches in flight
     for r0 in range(0, nverify, per_round):
-        tickets = [(i, pipe.submit(submit_from[i], sync_source=False)) for i in range(r0, min(r0 + per_round, nverify))]
+        tickets = [(i, pipe.submit(submit_from[i], sync_source=False, defer_copy=True)) for i in range(r0, min(r0 + per_round, nverify))]
         pipe.flush()
         for i, t in tickets:
             x, f = t.result()
@@ -890,7 +890,7 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag, detect
         # filled one by flush()
         tickets = [None] * k
         for i in range(k):
-            tickets[i] = pipe.submit(sub[cursor[0] % nb], sync_source=False)
+            tickets[i] = pipe.submit(sub[cursor[0] % nb], sync_source=False, defer_copy=True)   # the pool is never rewritten
             cursor[0] += 1
         pipe.flush()
         return tickets

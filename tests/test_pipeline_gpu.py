@@ -265,8 +265,9 @@ def test_inputs_may_be_dropped_right_after_submit(gpu, pipe6):
 
 @pytest.mark.parametrize("mode", ["staged", "slots"])
 def test_resident_inputs_are_copied_at_package_launch_by_one_launch(gpu, mode):
-    # round 5: submit(sync_source=False) only notes a resident, dense, 16-byte aligned batch; sa_copy_batches fills the
-    # package in front of its first stage.  Dropped inputs, a package mixing both kinds of submit (runs of parts broken by
+    # round 5: submit(sync_source=False, defer_copy=True) only notes a resident, dense, 16-byte aligned batch; sa_copy_batches
+    # fills the package in front of its first stage (opt-in since round 6, ADVICE r5: the caller promises not to rewrite
+    # the tensor before the package launches; without it the copy is enqueued by submit, see the last lines).  Dropped inputs, a package mixing both kinds of submit (runs of parts broken by
     # a copy made at submit), a misaligned view (copied at submit), and a partly filled package must all equal eager.
     cfgs, syn = pkg("configs"), pkg("synthetic")
     arch = cfgs.KITTI_3DSSD_ARCH
@@ -288,14 +289,22 @@ def test_resident_inputs_are_copied_at_package_launch_by_one_launch(gpu, mode):
             v.copy_(t)
             torch.cuda.synchronize()
             assert v.data_ptr() % 16 == 4
-            tickets.append(pipe.submit(v, out=outs[i], sync_source=False))
+            tickets.append(pipe.submit(v, out=outs[i], sync_source=False, defer_copy=True))
             torch.cuda.synchronize()                   # `odd` is reused by a later batch: its copy (at submit) has run
         else:
-            tickets.append(pipe.submit(t, out=outs[i], sync_source=False))
+            tickets.append(pipe.submit(t, out=outs[i], sync_source=False, defer_copy=True))
         del t                                          # the round keeps the tensor until the package's copy ran
     assert not tickets[-1].done()                      # batches 12, 13: a package of four that holds two
     for i, tk in enumerate(tickets):
         assert torch.equal(tk.result()[1], eager[i]), i
+    pipe.drain()
+    # WITHOUT defer_copy a recycled buffer may be rewritten as soon as submit's copy has run, package launched or not
+    buf = torch.from_numpy(host[0]).to(gpu)
+    torch.cuda.synchronize()
+    tk = pipe.submit(buf, sync_source=False)           # first part of a package of four: not launched yet
+    torch.cuda.synchronize()                           # the copy made at submit is complete
+    buf.copy_(torch.from_numpy(host[1]).to(gpu))       # the caller recycles its buffer
+    assert torch.equal(tk.result()[1], eager[0])
     pipe.drain()
 
 
