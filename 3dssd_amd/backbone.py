@@ -56,19 +56,30 @@ class SABackbone:
 
     __call__ = forward
 
-    def forward_staged(self, point_cloud):
+    def forward_staged(self, point_cloud, split_layer2_sampler=False):
         """forward() as a generator with ONE yield, between the sampling half of the first row (input split + layer-1
         D-FPS + centres: a latency-bound chain on one CU per frame) and everything else: the staged executor
         (pipeline.py) enqueues / captures the two halves on different streams.  The generator's return value
-        (StopIteration.value) is forward()'s result; the kernels and their order are exactly forward()'s."""
+        (StopIteration.value) is forward()'s result; the kernels and their order are exactly forward()'s.
+        split_layer2_sampler: THREE yields -- also around the sampling half of the second row (the F-FPS || D-FPS of
+        layer 2), so that an executor can keep every launch of the on-the-fly F-FPS (ffps_fly: multi-workgroup, its
+        launches must never overlap) on one dedicated stream."""
         l0_xyz, l0_points = self.split_input(point_cloud)
         xyz_list, feature_list, fps_idx_list = [l0_xyz], [l0_points], [None]
         pre = self.layers[0].sample(xyz_list, feature_list, fps_idx_list)
         yield
         out = {}
-        for i, layer in enumerate(self.layers):
-            xyz_list, feature_list, fps_idx_list = layer.build_layer(xyz_list, feature_list, fps_idx_list, None, out,
-                                                                     presampled=pre if i == 0 else None)
+        first = 0
+        if split_layer2_sampler and len(self.layers) > 1:
+            xyz_list, feature_list, fps_idx_list = self.layers[0].build_layer(xyz_list, feature_list, fps_idx_list, None, out,
+                                                                              presampled=pre)
+            yield
+            pre = self.layers[1].sample(xyz_list, feature_list, fps_idx_list)
+            yield
+            first = 1
+        for i in range(first, len(self.layers)):
+            xyz_list, feature_list, fps_idx_list = self.layers[i].build_layer(xyz_list, feature_list, fps_idx_list, None, out,
+                                                                              presampled=pre if i == first else None)
         return xyz_list, feature_list, fps_idx_list
 
     def raise_if_overflow(self):

@@ -1825,6 +1825,19 @@ extern "C" int sa_dense(long rows, int K, int N, const float *x, const void *wpa
     // three chunks of lookahead where the shape allows, 64-column blocks with two for the narrow 128 -> 64 layer
     if (rows < (1l << 31) && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {      // 16-byte row pieces in and out
         const long blocks = (rows + 127) / 128;
+        // 256-column blocks (round 6; a wave = one column tile x FOUR row tiles, two chunks of lookahead: 212 registers): a
+        // weight fragment is fetched once per 128 rows instead of twice and the rows are converted to split bf16 for half
+        // as many column blocks -- 65536 x 768 -> 256 126 -> 95 us, 32768 x 1536 -> 512 204 -> 154 us (128 frames; three
+        // chunks of lookahead: 100 / 160), bit-identical
+        static const int wide_knob = SA_KNOB("SA_D128_WIDE", 1);
+        if (wide_knob && K % (kD128KC * 2) == 0 && N % 256 == 0 && blocks * (N / 256) >= 192) {
+            auto kern = dense128_kernel<8, 8, 2>;
+            (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kD128Lds);
+            (void)hipGetLastError();
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks, N / 256), dim3(512), kD128Lds, stream, P);
+            SA_CHECK_LAUNCH();
+            return SA_OK;
+        }
         if (K % (kD128KC * 3) == 0 && N % 128 == 0 && blocks * (N / 128) >= 192) {
             auto kern = dense128_kernel<8, 4, 3>;
             (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kD128Lds);

@@ -186,7 +186,7 @@ class Ticket:
 class _Slot:
     # graphs: {package size (batches): (stage-A graph or None, stage-B / whole graph)}; lists: {size: forward()'s lists}
     __slots__ = ("pipe", "index", "stream_a", "stream_b", "inp", "overflow", "graphs", "lists", "round", "last_event",
-                 "copy_batches", "src_ptrs", "inp_ptr", "extras")
+                 "copy_batches", "src_ptrs", "inp_ptr", "extras", "mid")
 
 
 class SAPipeline:
@@ -226,10 +226,11 @@ class SAPipeline:
         # spin on partner workgroups and must never be in flight on two streams -- the layer-2 sampler runs on the
         # alternating main streams here, so a network built with ffps_fly is refused; the layer-1 sampler of large frames
         # runs on the ONE sampler stream of mode="staged" only
+        self.fly_stage = bool(net is not None and net.settings.get("ffps_fly"))
         if net is not None:
-            T.require(not net.settings.get("ffps_fly"),
-                      "SAPipeline cannot run a network built with ffps_fly=True: the on-the-fly F-FPS needs all its launches "
-                      "on one stream, the executor alternates that layer between streams (use the default matrix sampler)")
+            T.require(not net.settings.get("ffps_fly") or mode == "staged",
+                      "SAPipeline(mode='slots') cannot run a network built with ffps_fly=True: the on-the-fly F-FPS needs all its "
+                      "launches on one stream; mode='staged' gives the layer-2 sampler a stage and a stream of its own")
             T.require(not net.settings.get("coop_capture") or (mode == "staged" and int(points) > 16384),
                       "coop_capture is the staged executor's own setting for frames of more than 16384 points")
         self.net = net if net is not None else SABackbone(arch, params, self.device, max_translate_range,
@@ -287,10 +288,14 @@ class SAPipeline:
             self.sampler_streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_samp)]
             self.sampler_stream = self.sampler_streams[0]
             self.main_streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_main)]
+            # a network with the on-the-fly F-FPS (measurement builds): FOUR stages per package -- A (layer-1 sampler) on
+            # the sampler stream, B1 (layer 1) on a main stream, F (layer-2 sampler: every ffps_fly launch of the process)
+            # on ONE stream of its own, B2 (the rest) on the main stream again
+            self.fly_stream = torch.cuda.Stream(device=dev) if self.fly_stage else None
         self.slots = []
         for i in range(self.nslots):
             s = _Slot()
-            s.pipe, s.index, s.graphs, s.lists, s.extras = self, i, {}, {}, {}
+            s.pipe, s.index, s.graphs, s.lists, s.extras, s.mid = self, i, {}, {}, {}, {}
             if self.mode == "staged":
                 s.stream_a, s.stream_b = self.sampler_streams[i % self.n_samp], self.main_streams[i % self.n_main]
             else:
@@ -324,11 +329,19 @@ class SAPipeline:
                 kw = {} if pool is None else {"pool": pool}
                 with self._flag_word(s):
                     if self.mode == "staged":
-                        gen = self.net.forward_staged(view)
+                        gen = self.net.forward_staged(view, self.fly_stage)
                         ga = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(ga, stream=s.stream_a, **kw):
                             next(gen)
                         pool = pool or ga.pool()
+                        if self.fly_stage:                            # B1 on the main stream, F on the fly stream
+                            mid = []
+                            for st in (s.stream_b, self.fly_stream):
+                                g = torch.cuda.CUDAGraph()
+                                with torch.cuda.graph(g, stream=st, pool=pool):
+                                    next(gen)
+                                mid.append((st, g))
+                            s.mid[size] = mid
                         gb = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(gb, stream=s.stream_b, pool=pool):
                             try:
@@ -356,6 +369,10 @@ class SAPipeline:
                 if ga is not None:
                     with torch.cuda.stream(s.stream_a):
                         ga.replay()
+                    torch.cuda.synchronize(dev)
+                for st, g in s.mid.get(size, []):
+                    with torch.cuda.stream(st):
+                        g.replay()
                     torch.cuda.synchronize(dev)
                 with torch.cuda.stream(s.stream_b):
                     gb.replay()
@@ -501,7 +518,7 @@ class SAPipeline:
                     if ga is not None:
                         ga.replay()
                     else:
-                        gen = self.net.forward_staged(view)
+                        gen = self.net.forward_staged(view, self.fly_stage)
                         with self._flag_word(s):
                             next(gen)
                     stamp("launch:stage_A")
@@ -509,6 +526,17 @@ class SAPipeline:
                     ev.record(a)
                     if tl:
                         marks.append(ev)
+                if self.fly_stage:                                # B1 on the main stream, F on the one fly stream, each behind an event
+                    for j, st in enumerate((b, self.fly_stream)):
+                        st.wait_event(ev)
+                        with torch.cuda.stream(st):
+                            if ga is not None:
+                                s.mid[size][j][1].replay()
+                            else:
+                                with self._flag_word(s):
+                                    next(gen)
+                            ev = self._event(False)
+                            ev.record(st)
                 b.wait_event(ev)
                 stamp("launch:event_A_to_B")
             with torch.cuda.stream(b):

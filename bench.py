@@ -852,7 +852,13 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag, detect
     capture_error = None
 
     def make(graphs):
-        return P.SAPipeline(arch, params, dev, batch=args.batch, points=points, channels=4, streams=max(1, args.streams),
+        net = None
+        if args.ffps_fly:
+            # measurement only: the layer-2 F-FPS without the distance matrix, as a stage of its own on
+            # ONE dedicated stream of the staged executor (its multi-workgroup launches must never overlap)
+            net = pkg("backbone").SABackbone(arch, params, dev, cfgs.KITTI_MAX_TRANSLATE_RANGE, True, None, dfps_side_stream=5,
+                                             ffps_fly=True)
+        return P.SAPipeline(arch, params, dev, batch=args.batch, points=points, channels=4, streams=max(1, args.streams), net=net,
                             graphs=graphs, max_translate_range=cfgs.KITTI_MAX_TRANSLATE_RANGE,
                             coalesce=max(1, args.coalesce), mode=args.executor, linear_graphs=args.linear_graphs,
                             main_streams=args.main_streams, sampler_streams=args.sampler_streams, tail=tail)
@@ -1076,7 +1082,7 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag, detect
              ("frames_per_step_per_gpu", args.batch), ("data", args.data), ("pool_frames_per_gpu", nb * args.batch),
              ("inputs", "pinned host memory, copied per step (PCIe-inclusive)" if args.host_input else "resident in HBM"),
              ("slots", pipe.nslots), ("streams_used", pipe.streams_used()), ("hw_queues", P.hw_queues()),
-             ("graph_capture_error", capture_error), ("graphs_note", graphs_note), ("batches_per_replay", C), ("linear_graphs", pipe.linear_graphs),
+             ("graph_capture_error", capture_error), ("graphs_note", graphs_note), ("ffps_fly", bool(args.ffps_fly)), ("batches_per_replay", C), ("linear_graphs", pipe.linear_graphs),
              ("gc", "frozen across the timed bracket"), ("load_avg_1min", round(os.getloadavg()[0], 2)), ("host_cores", os.cpu_count()),
              ("sharding", "frame f -> rank f mod N, no data-path collective"),
              ("executor_note", EXECUTOR_NOTES[args.executor] % {"C": C, "B": args.batch, "n": pipe.nslots}),
@@ -1331,6 +1337,9 @@ def main():
     ap.add_argument("--extras-budget", type=float, default=75.0,
                     help="seconds for the secondary measurements the configs[1] line carries as flat scalars (steady state, rings64, "
                          "dense, detector, configs[2] / [4], group HBM fractions, RCCL smoke), each a sub-run of this script; 0: none")
+    ap.add_argument("--ffps-fly", type=int, default=0,
+                    help="1: layer-2 F-FPS without the distance matrix (csrc/ffps_fly.hip) as a fourth stage on a stream of its own "
+                         "(staged executor only; a measurement, not the default: DESIGN.md section 6)")
     ap.add_argument("--share-grid", action="store_true",
                     help="--workload group: the per-band ball-query calls of a layer share one grid (tf_grouping.shared_grid(); off by default)")
     ap.add_argument("--data", default="default", choices=list(pkg("synthetic").DATA_VARIANTS),

@@ -368,3 +368,33 @@ def test_detector_through_the_executor_equals_the_eager_detector(gpu, mode, grap
     with pytest.raises(ValueError, match="no tail"):
         pkg("pipeline").SAPipeline(arch, params, gpu, batch=2, points=16384, streams=1, graphs=False, net=pipe.net).submit(dev[0]).detections()
     pipe.drain()
+
+
+@pytest.mark.parametrize("graphs", [True, False])
+def test_matrix_free_ffps_as_a_stage_of_its_own_equals_the_matrix_path(gpu, graphs):
+    """a network built with ffps_fly=True (layer-2 F-FPS without the distance matrix, csrc/ffps_fly.hip)
+    runs through the staged executor as FOUR stages -- its multi-workgroup launches all on ONE dedicated stream -- and every
+    output equals, bit for bit, the DEFAULT network's (distance matrix + matrix sampler) on the same batch.  mode='slots'
+    still refuses such a network.  (Measured and not adopted: profiles/r06_ffps_fly_in_executor.txt.)"""
+    cfgs, syn = pkg("configs"), pkg("synthetic")
+    arch = cfgs.KITTI_3DSSD_ARCH
+    params = syn.random_backbone_params(arch)
+    B, P = pkg("backbone"), pkg("pipeline")
+    fly = B.SABackbone(arch, params, gpu, cfgs.KITTI_MAX_TRANSLATE_RANGE, True, None, dfps_side_stream=5, ffps_fly=True)
+    ref = B.SABackbone(arch, params, gpu, cfgs.KITTI_MAX_TRANSLATE_RANGE)
+    pipe = P.SAPipeline(arch, params, gpu, batch=2, points=16384, streams=3, coalesce=2, graphs=graphs, net=fly)
+    assert pipe.fly_stage and pipe.fly_stream is not None
+    dev = [torch.from_numpy(h).to(gpu) for h in _batches("default", 7, 2, first=5200)]
+    want = []
+    for t in dev:
+        xl, fl, il = ref(t)
+        want.append((xl[-1].clone(), fl[-1].clone(), il[2].clone()))
+    torch.cuda.synchronize()
+    tickets = [pipe.submit(t) for t in dev]
+    for i, tk in enumerate(tickets):
+        x, f = tk.result(copy=True)
+        assert torch.equal(f, want[i][1]) and torch.equal(x, want[i][0]), "batch %d" % i
+    assert torch.equal(tickets[-1].all_outputs()[2][2], want[-1][2])            # the layer-2 picks themselves ([F-FPS || D-FPS])
+    pipe.drain()
+    with pytest.raises(ValueError, match="slots"):
+        P.SAPipeline(arch, params, gpu, batch=2, points=16384, streams=2, mode="slots", graphs=False, net=fly)
