@@ -1185,7 +1185,13 @@ __global__ void vote_translate_kernel(long total, const float *__restrict__ xyz,
 // Next fit is a sequential rule; it is evaluated in parallel as a scan over FUNCTIONS phase -> (phase, advance) (phase =
 // fill of the current tile, 0..GPT-1): a thread folds its 8 balls for each of the GPT start phases, waves scan by
 // composition.
-constexpr int kPlanThreads = 512, kPlanBallsPerThread = 8;
+#ifndef SA_PLAN_THREADS
+#define SA_PLAN_THREADS 512
+#endif
+#ifndef SA_PLAN_BPT
+#define SA_PLAN_BPT 8
+#endif
+constexpr int kPlanThreads = SA_PLAN_THREADS, kPlanBallsPerThread = SA_PLAN_BPT;
 constexpr int kPlanChunk = kPlanThreads * kPlanBallsPerThread;      // 4096 balls per workgroup
 
 template <int GPT> struct PlanFn { int t[GPT]; };     // t[p] = advance << SH | end phase, for start phase p
