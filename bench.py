@@ -53,7 +53,7 @@ MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 / fp16 MFMA
 VALU_F32_PEAK_TF = 157.3
 MAX_CLOCK_MHZ = 2400.0      # MI355X_MICROARCH.md "Max clock"; cycles_per_pick is quoted at this clock (DVFS runs lower)
 FPS_FLOP_PER_PAIR = 11      # 3 sub + 3 mul/fma + min + compare/select chain, SURVEY.md 8d (3c + 2 with c = 3)
-TRAFFIC_PROFILES = [os.path.join("profiles", "r05_traffic.json"), os.path.join("profiles", "r04_traffic.json")]
+TRAFFIC_PROFILES = [os.path.join("profiles", "r06_traffic.json"), os.path.join("profiles", "r05_traffic.json"), os.path.join("profiles", "r04_traffic.json")]
 
 
 def pkg(name):

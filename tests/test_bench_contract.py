@@ -126,3 +126,42 @@ def test_data_variants_move_the_data_dependent_counters():
     assert dense["config"]["data"] == "dense" and dup["config"]["data"] == "dup10"
     assert dense["mlp_rows_per_step"]["evaluated_frac"] > 0.95 > 0.5 > base["mlp_rows_per_step"]["evaluated_frac"]
     assert dense["value"] < base["value"]               # the uniform box is the slow case, and the line shows it
+
+
+# ---- round 6: the driver's one command carries the other claims as flat scalars ---------------------------------
+R06_EXTRA_KEYS = ["steady512_frames_s", "rings64_frames_s", "detector_frames_s", "configs4_frames_s", "configs2_frames_s",
+                  "group_b128_hbm_frac", "group_b32_hbm_frac", "group_b8_hbm_frac", "dense_frames_s", "rccl_smoke"]
+
+
+@pytest.mark.parametrize("name", ["r06_bench_20steps_cold.json", "r06_bench_20steps.json"])
+def test_r06_headline_line_carries_the_secondary_measurements_in_its_first_twenty_config_keys(name):
+    d = _line(name)
+    c = d["config"]
+    first = list(c)[:20]
+    assert first[0] == "workload" and "configs[1]" in c["workload"] and d["steps"] == 20 and d["warmup"] == 5
+    for k in R06_EXTRA_KEYS + ["cgroup_cpu_quota_cores", "cgroup_nr_throttled", "timed_window_ms", "probe_window_ms"]:
+        assert k in first, (k, first)
+    for k in R06_EXTRA_KEYS[:-1]:
+        assert isinstance(c[k], (int, float)) and c[k] > 0, (k, c[k])
+    assert c["rccl_smoke"] == "ok"                                            # backend "nccl" (RCCL) initialised and ran its collectives on the box
+    assert d["extras"]["runs"]["rccl_smoke"]["gather_check"]["backend"] == "nccl (RCCL)"
+    # the secondary figures are what the stand-alone runs of the same lease say (within run-to-run spread)
+    assert c["steady512_frames_s"] > 1.2 * d["value"] and c["rings64_frames_s"] < c["steady512_frames_s"]
+    assert 0.9 < c["detector_frames_s"] / c["steady512_frames_s"] <= 1.02    # points -> boxes costs ~1 % over the backbone
+    assert c["group_b128_hbm_frac"] >= 0.40 > c["group_b8_hbm_frac"]         # the north star's 40 % of HBM: met where calls are large
+    assert d["extras"]["seconds"] <= d["extras"]["budget_s"] + 15 and not d["extras"]["skipped"]
+    # the contract fields are untouched
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["verify"]["all_equal_eager"] is True
+
+
+def test_r06_detector_line():
+    d = _line("r06_bench_detector.json")
+    assert "points -> boxes" in d["metric"] and d["config"]["workload"].startswith("detector")
+    v = d["verify"]
+    assert v["all_equal_eager"] is True and set(v["tail_outputs_compared"]) >= {"pred_3d_bbox", "pred_3d_score", "nms_idx", "nms_cnt"}
+    assert d["detections"]["max_output_num"] == 100
+    names = [s["kernel"] for s in d["stages"]]
+    assert names[-3:] == ["sa_decode_anchor_free", "sa_nms_bev", "sa_nms_gather"]           # the tail is C-ABI launches, nothing else
