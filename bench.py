@@ -1120,7 +1120,7 @@ def workload_backbone(args, sh, rank, world, dev, points, graphs_ok, tag, detect
         dom = max(stages, key=lambda s: s["avg_ms"] * s["calls_per_step"])
         mlp = [s for s in stages if s["kernel"] in MLP_CALLS]
         mlp_only_ms = sum(s["avg_ms"] * s["calls_per_step"] for s in mlp)
-        plan_ms = sum(s["avg_ms"] * s["calls_per_step"] for s in stages if s["kernel"] == "sa_group_mlp_plan")
+        plan_ms = sum(s["avg_ms"] * s["calls_per_step"] for s in stages if s["kernel"] in ("sa_group_mlp_plan", "sa_group_mlp_plan2"))
         mlp_ms = mlp_only_ms + plan_ms
         mlp_fl = sum(s["gflop"] * s["calls_per_step"] for s in mlp)
         bq = [s for s in stages if s["kernel"] in ("sa_query_ball_point_multi", "sa_query_ball_point_grid", "sa_query_ball_point_grid_ex")]
