@@ -69,25 +69,28 @@ class PostProcessor:
         bev_all = torch.empty((bs, n, k, 4), dtype=torch.float32, device=boxes4.device)
         st = N.lib().sa_boxes_to_bev(bs * n * k, boxes4.data_ptr(), bev_all.data_ptr(), N.current_stream())
         N.check(st, "boxes_to_bev")
-        gb_l, sc_l, cat_l, idx_l, cnt_l = [], [], [], [], []
+        idx_l, cnt_l = [], []
         for i in range(C):
             r = min(i, k - 1)
             s_i = pred_score[:, :, i:i + 1].contiguous()
             sub = PostProcessor(0, 1, K, self.nms_threshold)
             idx, cnt = sub.nms(bev_all[:, :, r].contiguous(), s_i)                    # [bs,1,K], [bs,1]
-            valid = idx >= 0
-            safe = idx.clamp(min=0).long().reshape(bs, K)
-            gb_l.append(torch.gather(boxes4[:, :, r], 1, safe[..., None].expand(-1, -1, 7)) * valid.reshape(bs, K, 1))
-            sc_l.append(torch.gather(s_i[:, :, 0], 1, safe) * valid.reshape(bs, K))
-            cat_l.append(torch.where(valid.reshape(bs, K), torch.full((bs, K), i, dtype=torch.int32, device=idx.device),
-                                     torch.full((bs, K), -1, dtype=torch.int32, device=idx.device)))
             idx_l.append(idx)
             cnt_l.append(cnt)
-        output_dict.setdefault("pred_3d_bbox", []).append(torch.cat(gb_l, 1))
-        output_dict.setdefault("pred_3d_score", []).append(torch.cat(sc_l, 1))
-        output_dict.setdefault("pred_3d_cls_category", []).append(torch.cat(cat_l, 1))
-        output_dict.setdefault("nms_idx", []).append(torch.cat(idx_l, 1))
-        output_dict.setdefault("nms_cnt", []).append(torch.cat(cnt_l, 1))
+        idx_all, cnt_all = torch.cat(idx_l, 1).contiguous(), torch.cat(cnt_l, 1)      # [bs,C,K], [bs,C]
+        # the kept rows of every class from ITS box set (min(i, k-1)): one launch (csrc/head.hip, sa_nms_gather with kbox = k)
+        scores = pred_score.contiguous()
+        gb = torch.empty((bs, C * K, 7), dtype=torch.float32, device=boxes4.device)
+        sc = torch.empty((bs, C * K), dtype=torch.float32, device=boxes4.device)
+        cat = torch.empty((bs, C * K), dtype=torch.int32, device=boxes4.device)
+        st = N.lib().sa_nms_gather(bs, n, C, K, k, boxes4.contiguous().data_ptr(), scores.data_ptr(), idx_all.data_ptr(), gb.data_ptr(),
+                                   sc.data_ptr(), cat.data_ptr(), N.current_stream())
+        N.check(st, "nms_gather")
+        output_dict.setdefault("pred_3d_bbox", []).append(gb)
+        output_dict.setdefault("pred_3d_score", []).append(sc)
+        output_dict.setdefault("pred_3d_cls_category", []).append(cat)
+        output_dict.setdefault("nms_idx", []).append(idx_all)
+        output_dict.setdefault("nms_cnt", []).append(cnt_all)
         return output_dict
 
     def _forward_agnostic(self, pred_anchors_3d, pred_score, output_dict, bev=None):
