@@ -1221,11 +1221,15 @@ __device__ __forceinline__ int plan_state_apply(int st, int y) {
     constexpr int SH = PlanSh<GPT>::SH;
     return (((st >> SH) + (y >> SH)) << SH) | (y & (GPT - 1));
 }
-// one ball of g granules placed from phase ph: returns the padding in front of it; updates ph
+// one ball of g granules placed from phase ph: returns the padding in front of it; updates ph.  nextfit (rounds 2-5): a
+// ball of <= GPT granules never straddles a tile boundary -- the open tile is padded instead.  Round 6 default: TIGHT --
+// no padding at all; a ball that crosses a tile boundary is a split ball (its partial maxima meet through the atomic
+// max that balls of more than 32 rows always used).  On the generator's frames next fit padded 5-22 % of the rows of
+// the wide scales (layer 4 scale 1: 11 296 rows per two frames against 9 280; tools/plan_padding_sim.py).
 template <int GPT>
-__device__ __forceinline__ int plan_place(int g, int &ph) {
+__device__ __forceinline__ int plan_place(int g, int &ph, int nextfit) {
     int pad = 0;
-    if (g <= GPT && ph + g > GPT) { pad = GPT - ph; ph = 0; }
+    if (nextfit && g <= GPT && ph + g > GPT) { pad = GPT - ph; ph = 0; }
     ph = (ph + g) & (GPT - 1);
     return pad;
 }
@@ -1273,12 +1277,13 @@ struct PlanJob {
 struct PlanJobs {
     PlanJob j[kPlanMaxScales];
     int nballs, dense, out_stride;
+    int nextfit;                     // 1: the next-fit packing of rounds 2-5 (flags bit 7; A/B measurements, tests)
     float *out;
 };
 
 // this thread's 8 balls of the chunk: granules, distinct rows, and their fold for the GPT start phases
 template <int GPT>
-__device__ __forceinline__ PlanFn<GPT> plan_fold_thread(const PlanJob &job, int ball0, int nballs, int dense,
+__device__ __forceinline__ PlanFn<GPT> plan_fold_thread(const PlanJob &job, int ball0, int nballs, int dense, int nextfit,
                                                         int (&g)[kPlanBallsPerThread], int &rows, int &nsp) {
     constexpr int SH = PlanSh<GPT>::SH;
 #pragma unroll
@@ -1292,7 +1297,7 @@ __device__ __forceinline__ PlanFn<GPT> plan_fold_thread(const PlanJob &job, int 
         int ph = p, adv = 0;
 #pragma unroll
         for (int k = 0; k < kPlanBallsPerThread; ++k)
-            if (g[k] > 0) { adv += plan_place<GPT>(g[k], ph); adv += g[k]; }
+            if (g[k] > 0) { adv += plan_place<GPT>(g[k], ph, nextfit); adv += g[k]; }
         f.t[p] = (adv << SH) | ph;
     }
     return f;
@@ -1304,7 +1309,7 @@ __device__ __forceinline__ void plan_summary_body(const PlanJobs &J, const PlanJ
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int chunk0 = blockIdx.x * kPlanChunk;
     int g[kPlanBallsPerThread], rows = 0, nsp = 0;
-    const PlanFn<GPT> f = plan_fold_thread<GPT>(job, chunk0 + tid * kPlanBallsPerThread, J.nballs, J.dense, g, rows, nsp);
+    const PlanFn<GPT> f = plan_fold_thread<GPT>(job, chunk0 + tid * kPlanBallsPerThread, J.nballs, J.dense, J.nextfit, g, rows, nsp);
     const PlanFn<GPT> incl = plan_wave_scan<GPT>(f, lane);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { rows += __shfl_xor(rows, d); nsp += __shfl_xor(nsp, d); }
@@ -1391,7 +1396,7 @@ __device__ __forceinline__ void plan_pack_body(const PlanJobs &J, const PlanJob 
     // ---- this chunk
     const int ball0 = chunk0 + tid * kPlanBallsPerThread;
     int g[kPlanBallsPerThread], rows = 0, nsp_unused = 0;
-    const PlanFn<GPT> f = plan_fold_thread<GPT>(job, ball0, nballs, J.dense, g, rows, nsp_unused);
+    const PlanFn<GPT> f = plan_fold_thread<GPT>(job, ball0, nballs, J.dense, J.nextfit, g, rows, nsp_unused);
     const PlanFn<GPT> incl = plan_wave_scan<GPT>(f, lane);
     int rsum = rows;
 #pragma unroll
@@ -1420,22 +1425,24 @@ __device__ __forceinline__ void plan_pack_body(const PlanJobs &J, const PlanJob 
     for (int k = 0; k < kPlanBallsPerThread; ++k) {
         if (g[k] > 0) {
             const int ball = ball0 + k;
-            const int pad = plan_place<GPT>(g[k], ph);
+            const int ph0 = ph;
+            const int pad = plan_place<GPT>(g[k], ph, J.nextfit);
             for (int j = 0; j < pad; ++j) job.gran[pos + j] = -1;
             pos += pad;
-            const int split = g[k] > GPT ? 1 : 0;
+            // split: the ball's granules lie in more than one tile (always for > GPT granules; tight packing: whenever it
+            // crosses a tile boundary) -- its rows are zeroed below and its partial maxima meet through atomic max
+            const int split = (J.nextfit ? g[k] > GPT : ph0 + g[k] > GPT) ? 1 : 0;
             for (int j = 0; j < g[k]; ++j) job.gran[pos + j] = (ball << 7) | (j << 1) | split;
             pos += g[k];
-            if (split) split_ball[atomicAdd(&nsplit_s, 1)] = ball;
+            if (split) atomicAdd(&nsplit_s, 1);
         }
     }
     __syncthreads();
-    // rows of split balls are zeroed (their partial maxima meet through an atomic max): all threads, coalesced
+    // (the rows of split balls are zeroed by mlp_plan_zero_kernel, over the whole chip: with tight packing a ball is split
+    //  at almost every tile boundary of the wide scales -- 150 MB of rows per 128 frames -- and the few workgroups of this
+    //  kernel took 0.37 ms for them)
     const int nsp = nsplit_s;
-    for (int e = tid; e < nsp * job.N; e += kPlanThreads) {         // (ball, channel) pairs over all threads
-        const int i = e / job.N, c = e - i * job.N;
-        J.out[(size_t)split_ball[i] * J.out_stride + job.out_off + c] = 0.0f;
-    }
+    (void)split_ball;
     // header (the workgroup of the last chunk): granules padded to whole tiles with invalid entries, split balls, rows
     if (last_chunk && tid == 0) {
         const int used = bend >> SH, total = (used + GPT - 1) & ~(GPT - 1);
@@ -1453,6 +1460,25 @@ __global__ __launch_bounds__(kPlanThreads) void mlp_plan_kernel(PlanJobs J) {
     if (blockIdx.x * kPlanChunk >= J.nballs) return;
     if (job.gr4) plan_pack_body<8>(J, job, wfn, wsum, nsplit_s, split_ball);
     else plan_pack_body<4>(J, job, wfn, wsum, nsplit_s, split_ball);
+}
+
+// Rows of split balls are zeroed: their partial maxima meet through an atomic max (mlp_plan.h).  One wave per 64 plan
+// entries; the first granule of a split ball (ordinal 0) names the row.
+__global__ __launch_bounds__(256) void mlp_plan_zero_kernel(PlanJobs J) {
+    const PlanJob job = J.j[blockIdx.y];
+    const int lane = threadIdx.x & 63;
+    const int ngran = __builtin_amdgcn_readfirstlane(job.hdr[0]);
+    for (int base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; base < ngran; base += gridDim.x * 256) {
+        const int e = base + lane < ngran ? job.gran[base + lane] : -1;
+        unsigned long long m = __ballot(e >= 0 && (e & 1) && ((e >> 1) & (sa::kPlanMaxOrd - 1)) == 0);
+        while (m != 0ull) {
+            const int l = (int)__builtin_ctzll(m);
+            m &= m - 1ull;
+            const int ball = __builtin_amdgcn_readlane(e, l) >> 7;
+            float *row = J.out + (size_t)ball * J.out_stride + job.out_off;
+            for (int c = lane; c < job.N; c += 64) row[c] = 0.0f;
+        }
+    }
 }
 
 int roundup(int x, int q) { return (x + q - 1) / q * q; }
@@ -1503,6 +1529,10 @@ static void launch_plan(const PlanJobs &J, int nscale, hipStream_t stream) {
     const unsigned chunks = (unsigned)((J.nballs + kPlanChunk - 1) / kPlanChunk);
     if (chunks > 1) hipLaunchKernelGGL(mlp_plan_summary_kernel, dim3(chunks - 1, nscale), dim3(kPlanThreads), 0, stream, J);
     hipLaunchKernelGGL(mlp_plan_kernel, dim3(chunks, nscale), dim3(kPlanThreads), 0, stream, J);
+    // the rows of split balls, zeroed over the whole chip (the entry list is at most 2 x the 4-row granules of the balls)
+    long zg = ((long)J.nballs * 4 + 255) / 256;
+    if (zg > 2048) zg = 2048;
+    hipLaunchKernelGGL(mlp_plan_zero_kernel, dim3((unsigned)zg, nscale), dim3(256), 0, stream, J);
 }
 
 // mlp_gemm.hip: the wide scales as a chain of three large-tile GEMMs over packed fp16 intermediates
@@ -1556,7 +1586,7 @@ extern "C" int sa_group_mlp_plan2(int b, int m, int nscale, const int *ns, const
         J.j[i].sum = (int *)ws[i] + sa_plan_sum_offset_ints(nballs, ns[i]);
         J.j[i].ns = ns[i]; J.j[i].out_off = out_off[i]; J.j[i].N = nout[i]; J.j[i].gr4 = gr4;
     }
-    J.nballs = (int)nballs; J.dense = flags & 1; J.out_stride = out_stride; J.out = out;
+    J.nballs = (int)nballs; J.dense = flags & 1; J.nextfit = (flags >> 7) & 1; J.out_stride = out_stride; J.out = out;
     launch_plan(J, nscale, stream);
     SA_CHECK_LAUNCH();
     return SA_OK;
@@ -1632,7 +1662,7 @@ extern "C" int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float 
         J.j[0].cnt = cnt; J.j[0].hdr = hdr; J.j[0].gran = gran; J.j[0].ns = ns; J.j[0].out_off = out_off; J.j[0].N = dims[nl];
         J.j[0].gr4 = gr4 ? 1 : 0;
         J.j[0].sum = hdr + sa_plan_sum_offset_ints(nballs, ns);
-        J.nballs = (int)nballs; J.dense = flags & 1; J.out_stride = out_stride; J.out = out;
+        J.nballs = (int)nballs; J.dense = flags & 1; J.nextfit = (flags >> 7) & 1; J.out_stride = out_stride; J.out = out;
         launch_plan(J, 1, stream);
         SA_CHECK_LAUNCH();
     }

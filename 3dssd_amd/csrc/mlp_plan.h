@@ -20,6 +20,13 @@
 //                     with wave-uniform branches and written (plain store, or atomic max for split balls).
 // `dense` plans (every ball gets ceil(ns/8) granules) reproduce the old behaviour for A/B measurements.
 //
+// Round 6: TIGHT packing is the default.  Next fit padded the open tile whenever the next ball did not fit -- a ball of
+// three granules followed by one of two wastes a quarter of a tile -- which cost 5-22 % of the evaluated rows of the wide
+// scales on the generator's frames (layer 4 scale 1: 11 296 rows per two frames instead of 9 280; on ring-structured frames
+// 10-20 % in every layer: tools/plan_padding_sim.py, profiles/r06_plan_padding_sim.txt).  Now granules follow one another
+// without padding; a ball whose granules lie in two tiles carries the `split` bit like a ball of more than 32 rows, and
+// mlp_plan_zero_kernel zeroes the rows of split balls over the whole chip.  Flags bit 7 of the plan call keeps next fit.
+//
 // Round 5: granules of FOUR rows (GR = 4, eight per tile) for the scales the row-wave kernels of mlp_rowwave.hip take.
 // On KITTI-like frames the inner bands of layer 1 / layer 2 hold 1.0-1.7 points per ball: eight-row granules evaluate
 // 4.7-8x the distinct rows there, four-row granules half of that.  A four-row granule is one lane half of a register

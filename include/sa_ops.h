@@ -206,7 +206,10 @@ unsigned long sa_group_mlp_max_ws_bytes(int b, int m, int ns);
 unsigned long sa_group_mlp_gemm_ws_bytes(int b, int m, int ns, int c, int nl, const int *dims);
 /* The row plans of all scales of a layer in ONE launch: cnt[i] = pts_cnt of scale i, ws[i] = that scale's scratch,
  * out_off[i] / nout[i] = where scale i's channels go in out.  The layer's sa_group_mlp_max calls then pass
- * flags | 2 (plan already built). */
+ * flags | 2 (plan already built).  flags bit 7 (128): the next-fit packing of rounds 2-5 (a ball of <= 32 rows never crosses
+ * a 32-row tile; the open tile is padded instead) for A/B measurements; default since round 6: TIGHT packing -- no padding,
+ * a ball that crosses a tile boundary is combined through the atomic max that balls of more than 32 rows always used (its
+ * row of `out` is zeroed by the plan launch).  Same results, 5-22 % fewer rows on the wide scales. */
 int sa_group_mlp_plan(int b, int m, int nscale, const int *ns, const int *const *cnt, void *const *ws, float *out,
                       int out_stride, const int *out_off, const int *nout, int flags, sa_stream_t stream);
 /* The same with a granule size per scale: bit 6 (64) of scale_flags[i] builds scale i's plan in granules of FOUR rows
