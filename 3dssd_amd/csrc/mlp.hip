@@ -1303,6 +1303,33 @@ __device__ __forceinline__ PlanFn<GPT> plan_fold_thread(const PlanJob &job, int 
     return f;
 }
 
+// TIGHT packing needs no phase functions: a ball's position is the plain prefix sum of the granule counts in front of it
+// (the phase is position mod GPT).  Summary of a chunk: o[0] = its granules, o[8] = rows, o[9] = balls of > GPT granules.
+template <int GPT>
+__device__ __forceinline__ void plan_summary_tight(const PlanJobs &J, const PlanJob &job, int (*wsum)[2], int (*wg)[8]) {
+    constexpr int NWV = kPlanThreads / 64;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int ball0 = blockIdx.x * kPlanChunk + tid * kPlanBallsPerThread;
+    int gs = 0, rows = 0, nsp = 0;
+#pragma unroll
+    for (int k = 0; k < kPlanBallsPerThread; ++k) {
+        const int g = plan_granules_of<GPT>(job.cnt, ball0 + k, J.nballs, job.ns, J.dense, rows);
+        gs += g;
+        nsp += g > GPT;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { gs += __shfl_xor(gs, d); rows += __shfl_xor(rows, d); nsp += __shfl_xor(nsp, d); }
+    if (lane == 0) { wsum[w][0] = rows; wsum[w][1] = nsp; wg[w][0] = gs; }
+    __syncthreads();
+    if (tid == 0) {
+        int G = 0, r = 0, n = 0;
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) { G += wg[i][0]; r += wsum[i][0]; n += wsum[i][1]; }
+        int *o = job.sum + (size_t)blockIdx.x * kPlanSumInts;
+        o[0] = G; o[8] = r; o[9] = n;
+    }
+}
+
 template <int GPT>
 __device__ __forceinline__ void plan_summary_body(const PlanJobs &J, const PlanJob &job, int (*wfn)[8], int (*wsum)[2]) {
     constexpr int NWV = kPlanThreads / 64;
@@ -1337,8 +1364,76 @@ __global__ __launch_bounds__(kPlanThreads) void mlp_plan_summary_kernel(PlanJobs
     __shared__ int wsum[kPlanThreads / 64][2];
     const PlanJob job = J.j[blockIdx.y];
     if (blockIdx.x * kPlanChunk + kPlanChunk >= J.nballs) return;   // nobody reads the last chunk's summary
+    if (!J.nextfit) {
+        if (job.gr4) plan_summary_tight<8>(J, job, wsum, wfn);
+        else plan_summary_tight<4>(J, job, wsum, wfn);
+        return;
+    }
     if (job.gr4) plan_summary_body<8>(J, job, wfn, wsum);
     else plan_summary_body<4>(J, job, wfn, wsum);
+}
+
+template <int GPT>
+__device__ __forceinline__ void plan_pack_tight(const PlanJobs &J, const PlanJob &job, int (*wg)[8], int (*wsum)[2], int &nsplit_s) {
+    constexpr int NWV = kPlanThreads / 64;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nballs = J.nballs;
+    const int chunk0 = blockIdx.x * kPlanChunk;
+    const bool last_chunk = chunk0 + kPlanChunk >= nballs;
+    if (tid == 0) nsplit_s = 0;
+    // ---- granules, rows and > GPT balls of the chunks in front of this one: plain sums of their summaries
+    int base = 0, rows_before = 0, nsplit_before = 0;
+    if (blockIdx.x > 0) {
+        int G = 0, r = 0, n = 0;
+        for (int c = tid; c < (int)blockIdx.x; c += kPlanThreads) {
+            const int *o = job.sum + (size_t)c * kPlanSumInts;
+            G += o[0]; r += o[8]; n += o[9];
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { G += __shfl_xor(G, d); r += __shfl_xor(r, d); n += __shfl_xor(n, d); }
+        if (lane == 0) { wg[w][0] = G; wsum[w][0] = r; wsum[w][1] = n; }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) { base += wg[i][0]; rows_before += wsum[i][0]; nsplit_before += wsum[i][1]; }
+        __syncthreads();
+    }
+    // ---- this chunk: exclusive prefix sum of the threads' granule counts
+    const int ball0 = chunk0 + tid * kPlanBallsPerThread;
+    int g[kPlanBallsPerThread], gs = 0, rows = 0;
+#pragma unroll
+    for (int k = 0; k < kPlanBallsPerThread; ++k) { g[k] = plan_granules_of<GPT>(job.cnt, ball0 + k, nballs, job.ns, J.dense, rows); gs += g[k]; }
+    int incl = gs;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+    int rsum = rows;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) rsum += __shfl_xor(rsum, d);
+    if (lane == 63) wg[w][0] = incl;
+    if (lane == 0) wsum[w][0] = rsum;
+    __syncthreads();
+    int pos = base + incl - gs, used = base, rows_chunk = 0;
+#pragma unroll
+    for (int i = 0; i < NWV; ++i) { if (i < w) pos += wg[i][0]; used += wg[i][0]; rows_chunk += wsum[i][0]; }
+    int nsp_mine = 0;
+#pragma unroll
+    for (int k = 0; k < kPlanBallsPerThread; ++k) {
+        if (g[k] > 0) {
+            const int ball = ball0 + k;
+            const int split = (pos & (GPT - 1)) + g[k] > GPT ? 1 : 0;     // its granules lie in more than one tile
+            for (int j = 0; j < g[k]; ++j) job.gran[pos + j] = (ball << 7) | (j << 1) | split;
+            pos += g[k];
+            nsp_mine += split;
+        }
+    }
+    if (last_chunk) {                                              // the header needs the chunk's split count
+        if (nsp_mine) atomicAdd(&nsplit_s, nsp_mine);
+        __syncthreads();
+        if (tid == 0) {
+            const int total = (used + GPT - 1) & ~(GPT - 1);
+            for (int q = used; q < total; ++q) job.gran[q] = -1;
+            job.hdr[0] = total; job.hdr[1] = nsplit_before + nsplit_s; job.hdr[2] = rows_before + rows_chunk; job.hdr[3] = 32 / GPT;
+        }
+    }
 }
 
 template <int GPT>
@@ -1458,6 +1553,11 @@ __global__ __launch_bounds__(kPlanThreads) void mlp_plan_kernel(PlanJobs J) {
     __shared__ int split_ball[kPlanChunk];
     const PlanJob job = J.j[blockIdx.y];
     if (blockIdx.x * kPlanChunk >= J.nballs) return;
+    if (!J.nextfit) {
+        if (job.gr4) plan_pack_tight<8>(J, job, wfn, wsum, nsplit_s);
+        else plan_pack_tight<4>(J, job, wfn, wsum, nsplit_s);
+        return;
+    }
     if (job.gr4) plan_pack_body<8>(J, job, wfn, wsum, nsplit_s, split_ball);
     else plan_pack_body<4>(J, job, wfn, wsum, nsplit_s, split_ball);
 }
