@@ -48,14 +48,13 @@ DFPS_SIDE_STREAM = 6
 PLAN_LOG = None     # set to a list to collect (b, m, nsample, MACs per row, plan tensor) of every fused-MLP call
 CONCAT_LOG = None   # set to a list to collect (scope, pooled concat tensor [B,m,sum N], offsets, widths, precisions) per SA layer
 MLP_PLAN_FLAGS = 0  # sa_group_mlp_max flag bit 0 (all nsample rows instead of the distinct ones), A/B measurements
-# Row plans in granules of 4 rows for the scales the row-wave kernels take (csrc/mlp_plan.h; flag bit 6).  Built in round 5,
-# bit-identical, MEASURED and left off (profiles/r05_granule4_ab.txt, 128 frames per launch): on the sparse default frames
-# layer 1 / layer 2 run 18 % / 23 % faster (half the padding rows), layer 3 / 4 do not move (eight pooled entries per tile
-# cost what the saved tiles gave), the plan kernels cost 65 % more (an 8-phase next-fit scan, twice the entries) -- net
-# -65 us of 6.8 ms; on ring-structured frames (8-33 rows per ball) every layer is 1-8 % SLOWER.  Opt-in for sparse data:
-# True, or a set of npoint values = the layers to apply it to ({1024} = layer 2 alone, in the executor: default frames 0 to
-# +2 %, rings64 -1.3 %, dense +0.6 % -- no rule that is right for both kinds of frame).
-MLP_GRANULE4 = False
+# Row plans in granules of 4 rows for the scales the row-wave kernels take (csrc/mlp_plan.h; flag bit 6): True, or a set of
+# npoint values = the layers to apply it to.  Built in round 5 and left off then: the 8-phase next-fit scan of its plans cost
+# what the saved rows gave.  Round 6 packs plans tight with a plain prefix sum (the plan's cost no longer depends on the granule
+# size), and per 128 frames (tools/stages_at.py): layer 2 (npoint 1024) 499 -> 396-403 us on default / dup10 frames, 945 -> 910
+# on rings64 -- ON for that layer; layer 1 (npoint 4096) 325 -> 261 on default but 934 -> 987 on rings64 (8-33 rows per ball:
+# eight pooled entries per tile cost more than the saved rows) -- stays at 8 rows; layers 3 / 4 do not take 4-row plans.
+MLP_GRANULE4 = {1024}
 GRID_BALL_QUERY_MIN_N = 1024   # round 5: the 1024-point frames of layer 3 through the grid too (120 -> 77 us per 128 frames; 512-point frames are faster brute force: 28 vs 42 us)
 MLP_GEMM_CHAIN = False  # True: eligible fp16 scales (layer4) run as three large-tile GEMM launches (flags bit 4); measured slower
 MAX_TRANSLATE_RANGE = (-3.0, -2.0, -3.0)
