@@ -1911,11 +1911,13 @@ extern "C" int sa_group_mlp_max_layer(int nscale, int b, int n, int m, const int
             max_tiles[i] = (sa_plan_max_granules((long)b * m, ns[i]) + 3) / 4;
             fp16[i] = (flags[i] & 4) ? 1 : 0;
         }
-        ok = ok && (flags[0] & 64) == (flags[1] & 64) && (flags[0] & 64) == (flags[2] & 64);   // one granule size for the launch
         if (ok) {
+            // granule size per scale: bit i of the mask = scale i's plan holds 4-row granules (the instantiated combinations:
+            // none, all, and the mixed ones of mlp_rowwave.hip -- any other mask falls through to the scale-by-scale calls)
+            const int gmask = ((flags[0] & 64) ? 1 : 0) | ((flags[1] & 64) ? 2 : 0) | ((flags[2] & 64) ? 4 : 0);
             int st = SA_OK;
             if (sa_rowwave_try_layer(b, n, m, ns, c, xyz, feat, new_xyz, idx, cnt, dims, wpack, bias, out, out_stride,
-                                     out_off, hdr, gran, max_tiles, fp16, (flags[0] & 64) ? 1 : 0, overflow, stream, &st))
+                                     out_off, hdr, gran, max_tiles, fp16, gmask, overflow, stream, &st))
                 return st;
         }
     }

@@ -48,13 +48,17 @@ DFPS_SIDE_STREAM = 6
 PLAN_LOG = None     # set to a list to collect (b, m, nsample, MACs per row, plan tensor) of every fused-MLP call
 CONCAT_LOG = None   # set to a list to collect (scope, pooled concat tensor [B,m,sum N], offsets, widths, precisions) per SA layer
 MLP_PLAN_FLAGS = 0  # sa_group_mlp_max flag bit 0 (all nsample rows instead of the distinct ones), A/B measurements
-# Row plans in granules of 4 rows for the scales the row-wave kernels take (csrc/mlp_plan.h; flag bit 6): True, or a set of
-# npoint values = the layers to apply it to.  Built in round 5 and left off then: the 8-phase next-fit scan of its plans cost
-# what the saved rows gave.  Round 6 packs plans tight with a plain prefix sum (the plan's cost no longer depends on the granule
-# size), and per 128 frames (tools/stages_at.py): layer 2 (npoint 1024) 499 -> 396-403 us on default / dup10 frames, 945 -> 910
-# on rings64 -- ON for that layer; layer 1 (npoint 4096) 325 -> 261 on default but 934 -> 987 on rings64 (8-33 rows per ball:
-# eight pooled entries per tile cost more than the saved rows) -- stays at 8 rows; layers 3 / 4 do not take 4-row plans.
-MLP_GRANULE4 = {1024}
+# Row plans in granules of 4 rows for the scales the row-wave kernels take (csrc/mlp_plan.h; flag bit 6): True (every such
+# scale), a set of npoint values (= layers), or {npoint: True | tuple of scale indices}.  Built in round 5 and left off then:
+# the 8-phase next-fit scan of its plans cost what the saved rows gave.  Round 6 packs plans tight with a plain prefix sum (the
+# plan's cost no longer depends on the granule size) and the one-launch layer kernels take a granule size PER SCALE.  Per 128
+# frames (tools/stages_at.py), default / rings64 / dense(32):
+#   layer 2 (npoint 1024), all scales: 499 -> 396-403 us | 945 -> 910 | a wash            -> ON
+#   layer 1 (npoint 4096), scales 0 / 1 (the inner bands: 1-2 points per ball, 65 536 rows evaluated for 9 010 distinct at
+#   8 rows): 325 -> 283 | 930 -> 930 | 394 -> 403                                         -> ON; with scale 2 as well: 261 | 987: off
+#   layer 3 (npoint 512), scale 0: 622 -> 600 | 1 007 -> 1 018; all scales 590 | 1 050    -> off; layer 4: never taken
+# The keys are the npoint values of configs/kitti/3dssd/3dssd.yaml; other networks keep 8 rows unless told otherwise.
+MLP_GRANULE4 = {1024: True, 4096: (0, 1)}
 GRID_BALL_QUERY_MIN_N = 1024   # round 5: the 1024-point frames of layer 3 through the grid too (120 -> 77 us per 128 frames; 512-point frames are faster brute force: 28 vs 42 us)
 MLP_GEMM_CHAIN = False  # True: eligible fp16 scales (layer4) run as three large-tile GEMM launches (flags bit 4); measured slower
 MAX_TRANSLATE_RANGE = (-3.0, -2.0, -3.0)
@@ -472,14 +476,23 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
             acc += ls[-1].N
         have_plans = nscale <= 4
         base_flags = [MLP_PLAN_FLAGS | (16 if MLP_GEMM_CHAIN else 0) | (2 if have_plans else 0) | W.scale_flags(ls) for ls in layers]
-        if have_plans and (MLP_GRANULE4 is True or (MLP_GRANULE4 and m in MLP_GRANULE4)):      # True, or the set of npoint values (layers) to apply it to
+        g4 = MLP_GRANULE4
+        g4_scales = None                                     # None: every scale of the layer; else the scale indices that take 4-row granules
+        if isinstance(g4, dict):
+            g4_scales = g4.get(m)
+            g4 = g4_scales is not None
+            if g4_scales is True:
+                g4_scales = None
+        if have_plans and (g4 is True or (g4 and m in g4)):      # True, a set of npoint values (layers), or {npoint: True | scale indices}
             # granule size per scale: 4 rows where a row-wave kernel will take the scale (the library says which), else 8
             for i, ls in enumerate(layers):
+                if g4_scales is not None and i not in g4_scales:
+                    continue
                 d_ = (ctypes.c_int * (len(ls) + 1))(*([c_feat + 3] + [l.N for l in ls]))
                 wp_ = (ctypes.c_void_p * len(ls))(*[l.w.data_ptr() for l in ls])
                 if lib.sa_group_mlp_granule_rows(bs, n_all, m, int(nsample_list[i]), c_feat, len(ls), d_, wp_, plans[i][1], base_flags[i]) == 4:
                     base_flags[i] |= 64
-            if nscale == 3 and len({f & 64 for f in base_flags}) != 1:      # the one-launch layer kernels want one granule size
+            if nscale == 3 and g4_scales is None and len({f & 64 for f in base_flags}) != 1:      # "all scales" asked for, not all possible: none
                 base_flags = [f & ~64 for f in base_flags]
         if have_plans:
             st = lib.sa_group_mlp_plan2(bs, m, nscale, nsa, cntp, (ctypes.c_void_p * nscale)(*[p[0].data_ptr() for p in plans]),

@@ -237,21 +237,35 @@ def test_four_row_granules_change_the_rows_evaluated_not_the_results(gpu, varian
     net = B.SABackbone(arch, syn.random_backbone_params(arch), gpu, cfgs.KITTI_MAX_TRANSLATE_RANGE)
     pts = torch.from_numpy(np.stack([syn.frame_of(variant, f, 16384) for f in range(3)])).to(gpu)
 
-    def run(flag):
+    def run(flag, plan_flags=0):
         default = lu.MLP_GRANULE4
-        lu.MLP_GRANULE4, lu.PLAN_LOG = flag, []
+        lu.MLP_GRANULE4, lu.PLAN_LOG, lu.MLP_PLAN_FLAGS = flag, [], plan_flags
         try:
             xl, fl, il = net(pts)
             torch.cuda.synchronize()
             hdrs = [p[4][:4].cpu().tolist() for p in lu.PLAN_LOG]
         finally:
-            lu.MLP_GRANULE4, lu.PLAN_LOG = default, None
+            lu.MLP_GRANULE4, lu.PLAN_LOG, lu.MLP_PLAN_FLAGS = default, None, 0
         return [t.clone() for t in fl], [None if t is None else t.clone() for t in il], hdrs
 
     f8, i8, h8 = run(False)
     f4, i4, h4 = run(True)
     assert all(h[3] == 8 for h in h8)
     assert [h[3] for h in h4] == [4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 8]      # layer1-3 x 3 scales, layer4 scale 0; the 96-row kernel keeps 8
+    # round 6: the shipped setting -- layer 2 at 4 rows, layer 1 scales 0 / 1 at 4 and scale 2 at 8 (a MIXED one-launch layer
+    # kernel), layers 3 / 4 at 8 -- and the next-fit packing of rounds 2-5 (plan flag bit 7) against the tight default
+    fm, im, hm = run(lu.MLP_GRANULE4)
+    assert [h[3] for h in hm] == [4, 4, 8, 4, 4, 4, 8, 8, 8, 8, 8]
+    fn, in_, hn = run(False, plan_flags=128)
+    for f_, i_ in ((fm, im), (fn, in_)):
+        for a, b in zip(i8, i_):
+            assert (a is None and b is None) or torch.equal(a, b)
+        for a, b in zip(f8, f_):
+            assert torch.equal(a, b)
+    rows_nextfit = sum(h[0] * h[3] for h in hn)
+    assert sum(h[0] * h[3] for h in h8) <= rows_nextfit                  # tight never evaluates more rows than next fit
+    if variant == "rings64":
+        assert sum(h[0] * h[3] for h in h8) < 0.93 * rows_nextfit        # ... and 10-20 % fewer on ring-structured frames
     for a, b in zip(i8, i4):
         assert (a is None and b is None) or torch.equal(a, b)
     for a, b in zip(f8, f4):
