@@ -133,7 +133,7 @@ R06_EXTRA_KEYS = ["steady512_frames_s", "rings64_frames_s", "detector_frames_s",
                   "group_b128_hbm_frac", "group_b32_hbm_frac", "group_b8_hbm_frac", "dense_frames_s", "rccl_smoke"]
 
 
-@pytest.mark.parametrize("name", ["r06_bench_20steps_cold.json", "r06_bench_20steps.json"])
+@pytest.mark.parametrize("name", ["r06_bench_20steps_cold.json", "r06_bench_20steps.json", "r06_cold_1.json", "r06_cold_2.json", "r06_cold_3.json"])
 def test_r06_headline_line_carries_the_secondary_measurements_in_its_first_twenty_config_keys(name):
     d = _line(name)
     c = d["config"]
