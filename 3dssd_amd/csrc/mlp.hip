@@ -1272,7 +1272,7 @@ struct PlanJob {
     const int *cnt;
     int *hdr, *gran, *sum;
     int ns, out_off, N;
-    int gr4;                         // 1: granules of 4 rows (8 per tile), 0: of 8 rows (4 per tile)
+    int gr4;                         // 0: granules of 8 rows (4 per tile), 1: of 4 rows (8 per tile), 2: of 2 rows (16 per tile; tight packing only)
 };
 struct PlanJobs {
     PlanJob j[kPlanMaxScales];
@@ -1365,7 +1365,8 @@ __global__ __launch_bounds__(kPlanThreads) void mlp_plan_summary_kernel(PlanJobs
     const PlanJob job = J.j[blockIdx.y];
     if (blockIdx.x * kPlanChunk + kPlanChunk >= J.nballs) return;   // nobody reads the last chunk's summary
     if (!J.nextfit) {
-        if (job.gr4) plan_summary_tight<8>(J, job, wsum, wfn);
+        if (job.gr4 == 2) plan_summary_tight<16>(J, job, wsum, wfn);
+        else if (job.gr4) plan_summary_tight<8>(J, job, wsum, wfn);
         else plan_summary_tight<4>(J, job, wsum, wfn);
         return;
     }
@@ -1554,7 +1555,8 @@ __global__ __launch_bounds__(kPlanThreads) void mlp_plan_kernel(PlanJobs J) {
     const PlanJob job = J.j[blockIdx.y];
     if (blockIdx.x * kPlanChunk >= J.nballs) return;
     if (!J.nextfit) {
-        if (job.gr4) plan_pack_tight<8>(J, job, wfn, wsum, nsplit_s);
+        if (job.gr4 == 2) plan_pack_tight<16>(J, job, wfn, wsum, nsplit_s);
+        else if (job.gr4) plan_pack_tight<8>(J, job, wfn, wsum, nsplit_s);
         else plan_pack_tight<4>(J, job, wfn, wsum, nsplit_s);
         return;
     }
@@ -1605,10 +1607,11 @@ static long sa_plan_max_granules(long nballs, int ns) {
     const long g = nballs * ((ns + 7) / 8);
     return (ns <= 8 ? g : 2 * g) + 8;
 }
-// ... and in granules of 4 rows: what the entry list of a scale's scratch is sized for (either granule size fits)
+// ... and in granules of 4 rows: what the entry list of a scale's scratch is sized for (any granule size fits: a tight
+// 2-row plan holds nballs * ceil(ns / 2) <= 2 nballs * ceil(ns / 4) entries + the padding of the last tile)
 static long sa_plan_max_entries(long nballs, int ns) {
     const long g = nballs * ((ns + 3) / 4);
-    return (ns <= 4 ? g : 2 * g) + 16;
+    return 2 * g + 16;
 }
 
 // ints in front of the chunk summaries of a scale's scratch: header + one int per granule of the densest plan, 16-byte
@@ -1680,8 +1683,10 @@ extern "C" int sa_group_mlp_plan2(int b, int m, int nscale, const int *ns, const
     PlanJobs J{};
     for (int i = 0; i < nscale; ++i) {
         if (ns[i] <= 0 || !cnt[i] || !ws[i] || nout[i] <= 0) return SA_ERR_INVALID;
-        const int gr4 = scale_flags && (scale_flags[i] & 64) ? 1 : 0;
-        if (ns[i] > (gr4 ? 4 : 8) * sa::kPlanMaxOrd) return SA_ERR_UNSUPPORTED;
+        // granule size of the scale's plan: bit 6 (64) = 4 rows, bit 8 (256) = 2 rows (round 6; tight packing only)
+        const int gr4 = !scale_flags ? 0 : (scale_flags[i] & 256) ? 2 : (scale_flags[i] & 64) ? 1 : 0;
+        if (gr4 == 2 && (flags & 128)) return SA_ERR_UNSUPPORTED;
+        if (ns[i] > (8 >> gr4) * sa::kPlanMaxOrd) return SA_ERR_UNSUPPORTED;
         J.j[i].cnt = cnt[i]; J.j[i].hdr = (int *)ws[i]; J.j[i].gran = (int *)ws[i] + sa::kPlanHeaderInts;
         J.j[i].sum = (int *)ws[i] + sa_plan_sum_offset_ints(nballs, ns[i]);
         J.j[i].ns = ns[i]; J.j[i].out_off = out_off[i]; J.j[i].N = nout[i]; J.j[i].gr4 = gr4;
@@ -1754,6 +1759,7 @@ extern "C" int sa_group_mlp_max(int b, int n, int m, int ns, int c, const float 
     int *hdr = (int *)ws, *gran = hdr + sa::kPlanHeaderInts;
     // granule size: flags bit 6 = 4-row granules (opt-in: mlp_plan.h; only the row-wave kernels read such plans), for a
     // plan built by the caller (flags bit 1) and for the plan of this call alike
+    if (flags & 256) return SA_ERR_UNSUPPORTED;             // 2-row plans: sa_group_mlp_max_layer's one-launch kernels only
     const bool gr4 = (flags & 64) != 0;
     if (gr4 && !(flags & 2) && !scale_takes_rowwave(b, n, m, ns, c, nl, dims, wpack, ws_bytes, flags & ~64)) return SA_ERR_UNSUPPORTED;
     // ---- the row plan of this call (unless sa_group_mlp_plan built the plans of the whole layer already)
@@ -1882,7 +1888,7 @@ int sa_rowwave_try_layer(int b, int n, int m, const int *ns, int c, const float 
                          const float *new_xyz, const int *const *idx, const int *const *cnt, const int *dims,
                          const void *const *wpack, const float *const *bias, float *out, int out_stride,
                          const int *out_off, const int *const *plan_hdr, const int *const *plan_gran,
-                         const long *max_tiles, const int *fp16, int gr4, int *overflow, hipStream_t stream, int *st);
+                         const long *max_tiles, const int *fp16, const int *gr, int *overflow, hipStream_t stream, int *st);
 
 // All scales of one SA layer (layers_util.py:134-181): scale i has nsample ns[i], index / count tensors idx[i] /
 // cnt[i], layer widths dims[i*(nl+1) ..], weights wpack[i*nl ..] / bias[i*nl ..], output slice out_off[i], plan
@@ -1912,13 +1918,15 @@ extern "C" int sa_group_mlp_max_layer(int nscale, int b, int n, int m, const int
             fp16[i] = (flags[i] & 4) ? 1 : 0;
         }
         if (ok) {
-            // granule size per scale: bit i of the mask = scale i's plan holds 4-row granules (the instantiated combinations:
-            // none, all, and the mixed ones of mlp_rowwave.hip -- any other mask falls through to the scale-by-scale calls)
-            const int gmask = ((flags[0] & 64) ? 1 : 0) | ((flags[1] & 64) ? 2 : 0) | ((flags[2] & 64) ? 4 : 0);
+            // granule size per scale (bit 6 of a scale's flags = 4 rows, bit 8 = 2 rows): the instantiated combinations of
+            // mlp_rowwave.hip run as ONE launch, any other falls through to the scale-by-scale calls (8 / 4 rows only)
+            int gr[3];
+            for (int i = 0; i < 3; ++i) gr[i] = (flags[i] & 256) ? 2 : (flags[i] & 64) ? 4 : 8;
             int st = SA_OK;
             if (sa_rowwave_try_layer(b, n, m, ns, c, xyz, feat, new_xyz, idx, cnt, dims, wpack, bias, out, out_stride,
-                                     out_off, hdr, gran, max_tiles, fp16, gmask, overflow, stream, &st))
+                                     out_off, hdr, gran, max_tiles, fp16, gr, overflow, stream, &st))
                 return st;
+            if (gr[0] == 2 || gr[1] == 2 || gr[2] == 2) return SA_ERR_UNSUPPORTED;    // 2-row plans: the one-launch layer kernels only
         }
     }
     // two wide scales (layer4 of 3dssd.yaml) whose plans are built: the GEMM chain of both in three launches

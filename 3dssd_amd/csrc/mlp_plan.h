@@ -38,7 +38,7 @@
 
 namespace sa {
 
-constexpr int kPlanHeaderInts = 4;     // [0] granules, [1] split balls, [2] distinct rows, [3] rows per granule (8 or 4)
+constexpr int kPlanHeaderInts = 4;     // [0] granules, [1] split balls, [2] distinct rows, [3] rows per granule (8, 4 or 2)
 constexpr int kPlanMaxOrd = 64;        // ordinal field: 6 bits -> nsample <= 512 (8-row granules), <= 256 (4-row)
 
 __device__ __forceinline__ int plan_entry(const int *gran, int ngran, int G) { return G < ngran ? gran[G] : -1; }
@@ -75,6 +75,22 @@ __device__ __forceinline__ void granule_max4(const plan_f32x16 &a, float (&qm)[8
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
         qm[2 * q] = __uint_as_float(sw[0]);
         qm[2 * q + 1] = __uint_as_float(sw[1]);
+    }
+}
+
+// the 2-row form (round 6): qm[4q + 2h + j] = maximum over rows 8q + 4h + 2j, + 1 (registers 4q + 2j, + 1 of lane half h), in
+// EVERY lane -- sixteen granules per tile for the scales whose balls mostly hold a single point
+__device__ __forceinline__ void granule_max2(const plan_f32x16 &a, float (&qm)[16]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float a0 = fmax_nn(a[4 * q], a[4 * q + 1]);
+        const float a1 = fmax_nn(a[4 * q + 2], a[4 * q + 3]);
+        const auto s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a0), __float_as_uint(a0), false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a1), __float_as_uint(a1), false, false);
+        qm[4 * q + 0] = __uint_as_float(s0[0]);
+        qm[4 * q + 1] = __uint_as_float(s1[0]);
+        qm[4 * q + 2] = __uint_as_float(s0[1]);
+        qm[4 * q + 3] = __uint_as_float(s1[1]);
     }
 }
 

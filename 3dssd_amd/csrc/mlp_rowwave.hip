@@ -151,7 +151,8 @@ __device__ __forceinline__ void pool_tile(const f32x16 &acc, const int (&ent)[32
                                           int c, const RwParams &P, int lane) {
     float qm[32 / GR];
     if constexpr (GR == 8) sa::granule_max(acc, qm);
-    else sa::granule_max4(acc, qm);
+    else if constexpr (GR == 4) sa::granule_max4(acc, qm);
+    else sa::granule_max2(acc, qm);
     sa::pool_write_tile<32 / GR>(qm, ent, cn, bias_c, c, P.N3, P.out, P.out_stride, P.out_off, lane);
 }
 
@@ -782,14 +783,14 @@ static bool rowwave_contiguous(const ScaleSig &S, const void *const *wpack, int 
 
 // The three scales of a layer in one launch (mlp_multi_kernel) for the layer shapes of 3dssd.yaml; 0 when the layer
 // is not one of them (the caller then launches scale by scale).
-// gr4: bit i = the plan of scale i holds 4-row granules (mlp_plan.h).  Instantiated: 0, 7 (all), and per layer the mixed
-// mask that pays on every kind of frame -- layer 1: scales 0 / 1 (the inner bands: 1-2 points per ball) at 4 rows, scale 2
-// at 8; layer 3: scale 0 at 4 rows.  Other masks: 0 is returned (the caller then goes scale by scale).
+// gr[i]: rows per granule of scale i's plan (8, 4 or 2: mlp_plan.h).  Instantiated: all 8, all 4, and per layer the mixed
+// combinations that were measured -- layer 1: the inner bands (1-2 points per ball) at 4 or 2 rows, the outer band at 8;
+// layer 2: (2, 2, 4); layer 3: scale 0 at 4 or 2.  Any other combination: 0 is returned (the caller goes scale by scale).
 int sa_rowwave_try_layer(int b, int n, int m, const int *ns, int c, const float *xyz, const float *feat,
                          const float *new_xyz, const int *const *idx, const int *const *cnt, const int *dims,
                          const void *const *wpack, const float *const *bias, float *out, int out_stride,
                          const int *out_off, const int *const *plan_hdr, const int *const *plan_gran,
-                         const long *max_tiles, const int *fp16, int gr4, int *overflow, hipStream_t stream, int *st) {
+                         const long *max_tiles, const int *fp16, const int *gr, int *overflow, hipStream_t stream, int *st) {
     static const bool on = SA_KNOB("SA_MLP_MULTI", 1) != 0;
     static const bool stream_enabled = SA_KNOB("SA_MLP_ROWSTREAM", 1) != 0;
     if (!on) return 0;
@@ -800,22 +801,25 @@ int sa_rowwave_try_layer(int b, int n, int m, const int *ns, int c, const float 
         if (!rowwave_scale(b, n, m, ns[i], c, xyz, feat, new_xyz, idx[i], cnt[i], 3, dims + 4 * i, wpack + 3 * i,
                            bias + 3 * i, out, out_stride, out_off[i], plan_hdr[i], plan_gran[i], max_tiles[i], overflow, P[i], S[i]))
             return 0;
-        if (((gr4 >> i) & 1) && ns[i] > 4 * sa::kPlanMaxOrd) return 0;
+        if (ns[i] > gr[i] * sa::kPlanMaxOrd) return 0;
         mt[i] = max_tiles[i];
     }
     const bool all16 = fp16[0] && fp16[1] && fp16[2], none16 = !fp16[0] && !fp16[1] && !fp16[2];
+    const int gkey = gr[0] * 100 + gr[1] * 10 + gr[2];        // 888, 444, 448, 228, ...
     if (none16 && c == 1 && sig_is(S[0], 1, 1, 1, 1, 1, 1) && sig_is(S[1], 1, 1, 1, 1, 1, 1) && sig_is(S[2], 1, 1, 2, 1, 2, 2)) {
         // layer1: 4 -> 16 -> 16 -> 32 (x2), 4 -> 32 -> 32 -> 64
-        if (gr4 == 7) *st = launch_multi<RwBody<1, 1, 1, 1, 1, 1, 4, 4, 1, 4>, RwBody<1, 1, 1, 1, 1, 1, 4, 4, 1, 4>, RwBody<1, 1, 2, 1, 2, 2, 4, 4, 1, 4>, 4, 4>(P, mt, 4, stream);
-        else if (gr4 == 3) *st = launch_multi<RwBody<1, 1, 1, 1, 1, 1, 4, 4, 1, 4>, RwBody<1, 1, 1, 1, 1, 1, 4, 4, 1, 4>, RwBody<1, 1, 2, 1, 2, 2, 4, 4, 1, 8>, 4, 4>(P, mt, 4, stream);
-        else if (gr4) return 0;
+        if (gkey == 444) *st = launch_multi<RwBody<1, 1, 1, 1, 1, 1, 4, 4, 1, 4>, RwBody<1, 1, 1, 1, 1, 1, 4, 4, 1, 4>, RwBody<1, 1, 2, 1, 2, 2, 4, 4, 1, 4>, 4, 4>(P, mt, 4, stream);
+        else if (gkey == 448) *st = launch_multi<RwBody<1, 1, 1, 1, 1, 1, 4, 4, 1, 4>, RwBody<1, 1, 1, 1, 1, 1, 4, 4, 1, 4>, RwBody<1, 1, 2, 1, 2, 2, 4, 4, 1, 8>, 4, 4>(P, mt, 4, stream);
+        else if (gkey == 228) *st = launch_multi<RwBody<1, 1, 1, 1, 1, 1, 4, 4, 1, 2>, RwBody<1, 1, 1, 1, 1, 1, 4, 4, 1, 2>, RwBody<1, 1, 2, 1, 2, 2, 4, 4, 1, 8>, 4, 4>(P, mt, 4, stream);
+        else if (gkey != 888) return 0;
         else *st = launch_multi<RwBody<1, 1, 1, 1, 1, 1, 4, 4, 1, 8>, RwBody<1, 1, 1, 1, 1, 1, 4, 4, 1, 8>, RwBody<1, 1, 2, 1, 2, 2, 4, 4, 1, 8>, 4, 4>(P, mt, 4, stream);
         return 1;
     }
     if (none16 && c != 1 && sig_is(S[0], 5, 2, 4, 2, 4, 4) && sig_is(S[1], 5, 2, 4, 2, 4, 4) && sig_is(S[2], 5, 2, 4, 3, 6, 4)) {
         // layer2: 67 -> 64 -> 64 -> 128 (x2), 67 -> 64 -> 96 -> 128
-        if (gr4 == 7) *st = launch_multi<RwBody<5, 2, 4, 2, 4, 4, 8, 2, 0, 4>, RwBody<5, 2, 4, 2, 4, 4, 8, 2, 0, 4>, RwBody<5, 2, 4, 3, 6, 4, 8, 2, 0, 4>, 8, 2>(P, mt, 1, stream);
-        else if (gr4) return 0;
+        if (gkey == 444) *st = launch_multi<RwBody<5, 2, 4, 2, 4, 4, 8, 2, 0, 4>, RwBody<5, 2, 4, 2, 4, 4, 8, 2, 0, 4>, RwBody<5, 2, 4, 3, 6, 4, 8, 2, 0, 4>, 8, 2>(P, mt, 1, stream);
+        else if (gkey == 224) *st = launch_multi<RwBody<5, 2, 4, 2, 4, 4, 8, 2, 0, 2>, RwBody<5, 2, 4, 2, 4, 4, 8, 2, 0, 2>, RwBody<5, 2, 4, 3, 6, 4, 8, 2, 0, 4>, 8, 2>(P, mt, 1, stream);
+        else if (gkey != 888) return 0;
         else *st = launch_multi<RwBody<5, 2, 4, 2, 4, 4, 8, 2, 0, 8>, RwBody<5, 2, 4, 2, 4, 4, 8, 2, 0, 8>, RwBody<5, 2, 4, 3, 6, 4, 8, 2, 0, 8>, 8, 2>(P, mt, 1, stream);
         return 1;
     }
@@ -823,9 +827,10 @@ int sa_rowwave_try_layer(int b, int n, int m, const int *ns, int c, const float 
         sig_is(S[2], 9, 4, 8, 8, 16, 8) && rowwave_contiguous(S[0], wpack, 1) && rowwave_contiguous(S[1], wpack + 3, 1) &&
         rowwave_contiguous(S[2], wpack + 6, 1)) {
         // layer3, fp16
-        if (gr4 == 7) *st = launch_multi<RsBody<9, 4, 8, 4, 8, 8, 8, 2, 2, 1, 12, 1, 4>, RsBody<9, 4, 8, 6, 12, 8, 8, 2, 2, 1, 12, 1, 4>, RsBody<9, 4, 8, 8, 16, 8, 8, 2, 2, 1, 12, 1, 4>, 8, 2>(P, mt, 1, stream);
-        else if (gr4 == 1) *st = launch_multi<RsBody<9, 4, 8, 4, 8, 8, 8, 2, 2, 1, 12, 1, 4>, RsBody<9, 4, 8, 6, 12, 8, 8, 2, 2, 1, 12, 1, 8>, RsBody<9, 4, 8, 8, 16, 8, 8, 2, 2, 1, 12, 1, 8>, 8, 2>(P, mt, 1, stream);
-        else if (gr4) return 0;
+        if (gkey == 444) *st = launch_multi<RsBody<9, 4, 8, 4, 8, 8, 8, 2, 2, 1, 12, 1, 4>, RsBody<9, 4, 8, 6, 12, 8, 8, 2, 2, 1, 12, 1, 4>, RsBody<9, 4, 8, 8, 16, 8, 8, 2, 2, 1, 12, 1, 4>, 8, 2>(P, mt, 1, stream);
+        else if (gkey == 488) *st = launch_multi<RsBody<9, 4, 8, 4, 8, 8, 8, 2, 2, 1, 12, 1, 4>, RsBody<9, 4, 8, 6, 12, 8, 8, 2, 2, 1, 12, 1, 8>, RsBody<9, 4, 8, 8, 16, 8, 8, 2, 2, 1, 12, 1, 8>, 8, 2>(P, mt, 1, stream);
+        else if (gkey == 288) *st = launch_multi<RsBody<9, 4, 8, 4, 8, 8, 8, 2, 2, 1, 12, 1, 2>, RsBody<9, 4, 8, 6, 12, 8, 8, 2, 2, 1, 12, 1, 8>, RsBody<9, 4, 8, 8, 16, 8, 8, 2, 2, 1, 12, 1, 8>, 8, 2>(P, mt, 1, stream);
+        else if (gkey != 888) return 0;
         else *st = launch_multi<RsBody<9, 4, 8, 4, 8, 8, 8, 2, 2, 1, 12, 1, 8>, RsBody<9, 4, 8, 6, 12, 8, 8, 2, 2, 1, 12, 1, 8>, RsBody<9, 4, 8, 8, 16, 8, 8, 2, 2, 1, 12, 1, 8>, 8, 2>(P, mt, 1, stream);
         return 1;
     }

@@ -57,6 +57,8 @@ MLP_PLAN_FLAGS = 0  # sa_group_mlp_max flag bit 0 (all nsample rows instead of t
 #   layer 1 (npoint 4096), scales 0 / 1 (the inner bands: 1-2 points per ball, 65 536 rows evaluated for 9 010 distinct at
 #   8 rows): 325 -> 283 | 930 -> 930 | 394 -> 403                                         -> ON; with scale 2 as well: 261 | 987: off
 #   layer 3 (npoint 512), scale 0: 622 -> 600 | 1 007 -> 1 018; all scales 590 | 1 050    -> off; layer 4: never taken
+# {npoint: {scale index: 4 | 2}} asks for granules of TWO rows on a scale (flag bit 8; sixteen entries per tile): built and
+# bit-identical, 41 % fewer rows on default frames for 0.6 % of the time, +80 us on rings64 (profiles/r06_granule2_ab.txt): off.
 # The keys are the npoint values of configs/kitti/3dssd/3dssd.yaml; other networks keep 8 rows unless told otherwise.
 MLP_GRANULE4 = {1024: True, 4096: (0, 1)}
 GRID_BALL_QUERY_MIN_N = 1024   # round 5: the 1024-point frames of layer 3 through the grid too (120 -> 77 us per 128 frames; 512-point frames are faster brute force: 28 vs 42 us)
@@ -477,22 +479,24 @@ def pointnet_sa_module_msg(xyz, points, radius_list, nsample_list, mlp_list, is_
         have_plans = nscale <= 4
         base_flags = [MLP_PLAN_FLAGS | (16 if MLP_GEMM_CHAIN else 0) | (2 if have_plans else 0) | W.scale_flags(ls) for ls in layers]
         g4 = MLP_GRANULE4
-        g4_scales = None                                     # None: every scale of the layer; else the scale indices that take 4-row granules
+        g4_rows = None                                       # {scale index: rows per granule (4 or 2)}; None: 4 rows on every scale
         if isinstance(g4, dict):
-            g4_scales = g4.get(m)
-            g4 = g4_scales is not None
-            if g4_scales is True:
-                g4_scales = None
-        if have_plans and (g4 is True or (g4 and m in g4)):      # True, a set of npoint values (layers), or {npoint: True | scale indices}
-            # granule size per scale: 4 rows where a row-wave kernel will take the scale (the library says which), else 8
+            v = g4.get(m)
+            g4 = v is not None
+            if isinstance(v, dict):
+                g4_rows = dict(v)
+            elif v is not None and v is not True:
+                g4_rows = {int(i): 4 for i in v}
+        if have_plans and (g4 is True or (g4 and m in g4)):      # True, a set of npoint values (layers), or {npoint: True | scale indices | {scale: rows}}
+            # granule size per scale where a row-wave kernel will take the scale (the library says which), else 8
             for i, ls in enumerate(layers):
-                if g4_scales is not None and i not in g4_scales:
+                if g4_rows is not None and i not in g4_rows:
                     continue
                 d_ = (ctypes.c_int * (len(ls) + 1))(*([c_feat + 3] + [l.N for l in ls]))
                 wp_ = (ctypes.c_void_p * len(ls))(*[l.w.data_ptr() for l in ls])
                 if lib.sa_group_mlp_granule_rows(bs, n_all, m, int(nsample_list[i]), c_feat, len(ls), d_, wp_, plans[i][1], base_flags[i]) == 4:
-                    base_flags[i] |= 64
-            if nscale == 3 and g4_scales is None and len({f & 64 for f in base_flags}) != 1:      # "all scales" asked for, not all possible: none
+                    base_flags[i] |= 256 if (g4_rows is not None and g4_rows[i] == 2) else 64
+            if nscale == 3 and g4_rows is None and len({f & 64 for f in base_flags}) != 1:      # "all scales" asked for, not all possible: none
                 base_flags = [f & ~64 for f in base_flags]
         if have_plans:
             st = lib.sa_group_mlp_plan2(bs, m, nscale, nsa, cntp, (ctypes.c_void_p * nscale)(*[p[0].data_ptr() for p in plans]),

@@ -216,7 +216,10 @@ int sa_group_mlp_plan(int b, int m, int nscale, const int *ns, const int *const 
  * instead of eight (half the padding on balls of 1-4 distinct rows: the inner bands of layer 1 / layer 2 on KITTI-like
  * frames).  Only the row-wave kernels read such plans: ask sa_group_mlp_granule_rows() which scales they take, and pass
  * the same bit 6 in that scale's flags to sa_group_mlp_max / sa_group_mlp_max_layer (a scale whose flags say "4 rows"
- * but which no row-wave kernel can take returns -3).  scale_flags == NULL: eight rows everywhere (= sa_group_mlp_plan). */
+ * but which no row-wave kernel can take returns -3).  scale_flags == NULL: eight rows everywhere (= sa_group_mlp_plan).
+ * Bit 8 (256) of scale_flags[i]: granules of TWO rows (round 6; tight packing only -- flags bit 7 with it returns -3 --
+ * and read by sa_group_mlp_max_layer's one-launch kernels only: the combinations instantiated in mlp_rowwave.hip, any
+ * other returns -3; sa_group_mlp_max refuses such a plan). */
 int sa_group_mlp_plan2(int b, int m, int nscale, const int *ns, const int *const *cnt, void *const *ws, float *out,
                        int out_stride, const int *out_off, const int *nout, int flags, const int *scale_flags,
                        sa_stream_t stream);

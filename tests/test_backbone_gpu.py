@@ -257,7 +257,12 @@ def test_four_row_granules_change_the_rows_evaluated_not_the_results(gpu, varian
     fm, im, hm = run(lu.MLP_GRANULE4)
     assert [h[3] for h in hm] == [4, 4, 8, 4, 4, 4, 8, 8, 8, 8, 8]
     fn, in_, hn = run(False, plan_flags=128)
-    for f_, i_ in ((fm, im), (fn, in_)):
+    # ... and granules of TWO rows on the inner bands (opt-in: {npoint: {scale: rows}}; profiles/r06_granule2_ab.txt has why
+    # it is not the default): sixteen entries per tile, the same maxima
+    f2, i2, h2 = run({4096: {0: 2, 1: 2}, 1024: {0: 2, 1: 2, 2: 4}, 512: {0: 2}})
+    assert [h[3] for h in h2] == [2, 2, 8, 2, 2, 4, 2, 8, 8, 8, 8]
+    assert sum(h[2] for h in h2) == sum(h[2] for h in h8) <= sum(h[0] * h[3] for h in h2) <= sum(h[0] * h[3] for h in hm)
+    for f_, i_ in ((fm, im), (fn, in_), (f2, i2)):
         for a, b in zip(i8, i_):
             assert (a is None and b is None) or torch.equal(a, b)
         for a, b in zip(f8, f_):
