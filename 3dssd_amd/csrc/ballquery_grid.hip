@@ -19,6 +19,7 @@
 // the coordinate, so |dx| <= r_max implies a cell difference of at most 1 (the margin absorbs the fp32 rounding of
 // the product), and clamping only merges cells.  y is not gridded (LiDAR frames are flat); it enters through d2.
 #include <math.h>
+#include <string.h>
 
 #include "sa_common.h"
 
@@ -37,15 +38,17 @@ struct GBands {
     int *cnt[kMaxBands];
     float thi_max;
     int nbands, dilated;
+    unsigned blo[kMaxBands], bwd[kMaxBands];     // the dilated band test on the bits of d2 (bq_grid_sort_kernel): bits(tlo), bits(thi) - bits(tlo)
 };
 
 __device__ __forceinline__ float wave_allmin_f(float x) { return -sa::wave_allmax(-x); }
 
 // workspace per frame (in ints): cell_start[kNC + 1] (+3 padding) | sorted[n] float4 = (x, y, z, index bits) in cell
-// order | params[4] floats (minx, minz, inv, cell size).  Round 5: the cell lists hold the POINTS, not their indices -- a query's
+// order | params[4] floats (minx, minz, inv, cell size) | one float4 "point" at 1e30 (sorted[n + 1]: what the lanes past a
+// query's last candidate read -- its distance is +inf, no band takes it; round 6).  Round 5: the cell lists hold the POINTS, not their indices -- a query's
 // chain was bounds -> sorted index -> point (a scattered 12-byte gather); it is now bounds -> one coalesced 16-byte read.
 constexpr int kCellInts = kNC + 4;
-__host__ __device__ __forceinline__ size_t ws_stride(int n) { return (size_t)kCellInts + 4 * (size_t)n + 4; }
+__host__ __device__ __forceinline__ size_t ws_stride(int n) { return (size_t)kCellInts + 4 * (size_t)n + 8; }
 
 // reuse != 0: the workspace is stated to hold the grid of these very points from an earlier call; it is kept if its cells
 // are at least cell_min wide (params[3] = the cell size it was built with), rebuilt otherwise -- decided here, on the
@@ -83,7 +86,10 @@ __global__ __launch_bounds__(1024) void bq_grid_build_kernel(int n, float cell_m
     float cs = sa::fmax_nn(cell_min, sa::fmax_nn(mxx - mnx, mxz - mnz) / (float)(kNX - 2));
     cs = sa::fmax_nn(cs, 1e-20f);
     const float inv = 1.0f / cs;
-    if (tid == 0) { params[0] = mnx; params[1] = mnz; params[2] = inv; params[3] = cs; }
+    if (tid == 0) {
+        params[0] = mnx; params[1] = mnz; params[2] = inv; params[3] = cs;
+        sorted[n + 1] = make_float4(1e30f, 1e30f, 1e30f, 0.0f);
+    }
 
     for (int k = tid; k < n; k += 1024) {
         const int cx = min(kNX - 1, max(0, (int)((p[k * 3 + 0] - mnx) * inv)));
@@ -333,6 +339,257 @@ __global__ __launch_bounds__(kQWaves * 64, 8) void bq_grid_query_kernel(int n, i
     }
 }
 
+// ---- round 6: the SORTING form of the query kernel -------------------------------------------------------------------
+// The kernel above spends ~900 of its ~1 000 vector instructions per query (ring-structured frames: 290 candidates, 54 hits)
+// on bookkeeping: the hits go from the per-query list into per-band lists (ballot -> count -> append per band and
+// 64-entry chunk), and every band then RANKS its hits with a serial loop (v_readlane + compare + add-with-carry + loop
+// control per hit: 8 instructions, 5 of them on the scalar side).  Here the query keeps ONE list of keys
+// `index << 4 | band mask`, and when the walk is over the list is SORTED once, in registers, by a bitonic network over the
+// wave (63 vector instructions for 64 keys whatever the bands; only the phases the entry count needs; up to 256 keys in
+// four registers per lane).  In index order a band's output slot is a prefix count of its mask bit (ballot + mbcnt): no
+// ranking loop, no per-band lists (15 KB of LDS per workgroup -> 4), no scalar work per hit.  A list about to overflow
+// (> 192 keys; near the sensor, or `dense` frames) is sorted too, cut to the keys that can still be output (the first
+// nsample of every band) and the nsample-th key of a saturated band becomes its admission bound, as before.
+// Needs sum(nsample) <= 192 (3dssd.yaml: 128); the kernel above stays for larger ones.
+constexpr int kSortCap = 256;              // keys per query list = 4 per lane
+constexpr int kKeyShift = 4;               // key = index << 4 | band mask (kMaxBands bits)
+constexpr unsigned kKeySentinel = 0xFFFFFFF0u;     // sorts behind every key, belongs to no band
+
+template <int BIT> __device__ __forceinline__ constexpr unsigned long long lane_bit_mask() {
+    return BIT == 0 ? 0xAAAAAAAAAAAAAAAAull : BIT == 1 ? 0xCCCCCCCCCCCCCCCCull : BIT == 2 ? 0xF0F0F0F0F0F0F0F0ull
+         : BIT == 3 ? 0xFF00FF00FF00FF00ull : BIT == 4 ? 0xFFFF0000FFFF0000ull : 0xFFFFFFFF00000000ull;
+}
+// compare-exchange with the partner's value p: lanes whose bit BIT is clear keep the smaller, the others the larger
+// (v_min_u32_dpp + v_max_u32_dpp + v_cndmask on an SGPR-pair constant when p is a DPP move of x)
+template <int BIT> __device__ __forceinline__ unsigned key_ce(unsigned x, unsigned p) {
+    const unsigned lo = x < p ? x : p, hi = x < p ? p : x;
+    return __builtin_amdgcn_inverse_ballot_w64(lane_bit_mask<BIT>()) ? hi : lo;
+}
+template <int CTRL> __device__ __forceinline__ unsigned key_dpp(unsigned x) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, true);
+}
+template <int PATTERN> __device__ __forceinline__ unsigned key_swz(unsigned x) {
+    return (unsigned)__builtin_amdgcn_ds_swizzle((int)x, PATTERN);
+}
+// DPP controls: quad_perm [1,0,3,2] = 0xB1 (lane ^ 1), [2,3,0,1] = 0x4E (lane ^ 2), [3,2,1,0] = 0x1B (mirror of 4);
+// row_half_mirror 0x141 (mirror of 8), row_mirror 0x140 (mirror of 16), row_ror:8 0x128 (lane ^ 8).  ds_swizzle bit
+// mode and | or << 5 | xor << 10: lane ^ 4 = 0x101F, lane ^ 16 = 0x401F, mirror of 32 (lane ^ 31) = 0x7C1F.
+__device__ __forceinline__ unsigned key_tail2(unsigned x) {            // the half-cleaners of distance 2, 1
+    x = key_ce<1>(x, key_dpp<0x4E>(x));
+    return key_ce<0>(x, key_dpp<0xB1>(x));
+}
+// 64 keys, one per lane (lanes >= U hold the sentinel), ascending by lane.  Bitonic network in the "mirror" form (the
+// first step of a merge phase compares i with its mirror image inside the block: every exchange is ascending); a phase
+// over blocks of B lanes is only needed when more than B / 2 lanes hold keys.  mir64: (63 - lane) << 2.
+__device__ __forceinline__ unsigned key_sort64(unsigned x, int U, unsigned mir64) {
+    if (U > 1) x = key_ce<0>(x, key_dpp<0xB1>(x));
+    if (U > 2) { x = key_ce<1>(x, key_dpp<0x1B>(x)); x = key_ce<0>(x, key_dpp<0xB1>(x)); }
+    if (U > 4) { x = key_ce<2>(x, key_dpp<0x141>(x)); x = key_tail2(x); }
+    if (U > 8) { x = key_ce<3>(x, key_dpp<0x140>(x)); x = key_ce<2>(x, key_swz<0x101F>(x)); x = key_tail2(x); }
+    if (U > 16) {
+        x = key_ce<4>(x, key_swz<0x7C1F>(x));
+        x = key_ce<3>(x, key_dpp<0x128>(x)); x = key_ce<2>(x, key_swz<0x101F>(x)); x = key_tail2(x);
+    }
+    if (U > 32) {
+        x = key_ce<5>(x, (unsigned)__builtin_amdgcn_ds_bpermute((int)mir64, (int)x));
+        x = key_ce<4>(x, key_swz<0x401F>(x));
+        x = key_ce<3>(x, key_dpp<0x128>(x)); x = key_ce<2>(x, key_swz<0x101F>(x)); x = key_tail2(x);
+    }
+    return x;
+}
+// a BITONIC sequence of 64 keys -> ascending: half-cleaners of distance 32 (v_permlane32_swap: [0] = the lower half's
+// keys in both halves, [1] = the upper half's), 16, 8, 4, 2, 1
+__device__ __forceinline__ unsigned key_clean64(unsigned x) {
+    const auto sw = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    const unsigned a = sw[0], b = sw[1];
+    const unsigned lo = a < b ? a : b, hi = a < b ? b : a;
+    x = __builtin_amdgcn_inverse_ballot_w64(lane_bit_mask<5>()) ? hi : lo;
+    x = key_ce<4>(x, key_swz<0x401F>(x));
+    x = key_ce<3>(x, key_dpp<0x128>(x)); x = key_ce<2>(x, key_swz<0x101F>(x));
+    return key_tail2(x);
+}
+// two ascending registers -> ascending over (a, b)
+__device__ __forceinline__ void key_merge2(unsigned &a, unsigned &b, unsigned mir64) {
+    const unsigned bm = (unsigned)__builtin_amdgcn_ds_bpermute((int)mir64, (int)b);
+    const unsigned lo = a < bm ? a : bm, hi = a < bm ? bm : a;
+    a = key_clean64(lo); b = key_clean64(hi);
+}
+// v[0..4): the first U entries of `list` (U <= kSortCap) ascending over (register, lane), sentinels behind them
+__device__ __forceinline__ void key_sort_list(const unsigned *list, int U, int lane, unsigned mir64, unsigned (&v)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = kKeySentinel;
+    if (lane < U) v[0] = list[lane];
+    v[0] = key_sort64(v[0], U, mir64);
+    if (U <= 64) return;
+    if (64 + lane < U) v[1] = list[64 + lane];
+    v[1] = key_sort64(v[1], U - 64, mir64);
+    key_merge2(v[0], v[1], mir64);
+    if (U <= 128) return;
+    if (128 + lane < U) v[2] = list[128 + lane];
+    v[2] = key_sort64(v[2], U - 128, mir64);
+    if (U > 192) {
+        if (192 + lane < U) v[3] = list[192 + lane];
+        v[3] = key_sort64(v[3], U - 192, mir64);
+    }
+    key_merge2(v[2], v[3], mir64);
+    // (v0, v1) and (v2, v3) ascending: against the reversed second pair, then two bitonic sequences of 128
+    const unsigned m3 = (unsigned)__builtin_amdgcn_ds_bpermute((int)mir64, (int)v[3]);
+    const unsigned m2 = (unsigned)__builtin_amdgcn_ds_bpermute((int)mir64, (int)v[2]);
+    const unsigned l0 = v[0] < m3 ? v[0] : m3, h0 = v[0] < m3 ? m3 : v[0];
+    const unsigned l1 = v[1] < m2 ? v[1] : m2, h1 = v[1] < m2 ? m2 : v[1];
+    v[0] = key_clean64(l0 < l1 ? l0 : l1); v[1] = key_clean64(l0 < l1 ? l1 : l0);
+    v[2] = key_clean64(h0 < h1 ? h0 : h1); v[3] = key_clean64(h0 < h1 ? h1 : h0);
+}
+
+// candidate j of a query's flattened 3 x 3 neighbourhood (three index ranges of `sorted`; the far point past T)
+__device__ __forceinline__ float4 key_cand(const char *sorted, int j, int rc0, int c01, int T, int offA, int offB, int offC, int sent) {
+    int off = j >= rc0 ? offB : offA;
+    off = j >= c01 ? offC : off;
+    const int pos = j < T ? j + off : sent;
+    return *(const float4 *)(sorted + (unsigned)pos * 16u);
+}
+
+template <int NB, bool DIL>
+__global__ __launch_bounds__(kQWaves * 64, 8) void bq_grid_sort_kernel(int n, int m, const float *__restrict__ xyz2,
+                                                                    const int *__restrict__ ws, GBands B) {
+    __shared__ unsigned s_keys[kQWaves][kSortCap];
+    int b = blockIdx.y, bx = blockIdx.x;
+    if ((gridDim.x & 7) == 0 && (gridDim.y & 7) == 0) {                 // XCD-aware, as above
+        const unsigned L = blockIdx.y * gridDim.x + blockIdx.x, G8 = 8u * gridDim.x;
+        b = (int)(8u * (L / G8) + (L & 7u));
+        bx = (int)((L % G8) >> 3);
+    }
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int *cell_start = ws + (size_t)b * ws_stride(n);
+    const char *sorted = (const char *)(cell_start + kCellInts);
+    const float *params = (const float *)(sorted + (size_t)n * 16);
+    const float mnx = params[0], mnz = params[1], inv = params[2];
+    unsigned *list = s_keys[w];
+    const unsigned mir64 = (unsigned)(63 - lane) << 2;
+    // band tests on the BITS of d2 (d2 >= +0 or NaN: unsigned order = float order, a NaN passes no test either way):
+    // dilated: tlo <= d2 < thi  <=>  bits(d2) - bits(tlo) < bits(thi) - bits(tlo) (unsigned; empty when thi <= tlo)
+    // (B.blo / B.bwd, from the host)
+    constexpr unsigned kAll = (1u << NB) - 1u;
+    const int sent = n + 1;                               // float4 index of the far "point" behind the params
+
+    for (int q = bx * kQWaves + w; q < m; q += gridDim.x * kQWaves) {
+        const size_t qi = (size_t)b * m + q;
+        const float x2 = xyz2[qi * 3 + 0], y2 = xyz2[qi * 3 + 1], z2 = xyz2[qi * 3 + 2];
+        const int cx = min(kNX - 1, max(0, (int)((x2 - mnx) * inv)));
+        const int cz = min(kNX - 1, max(0, (int)((z2 - mnz) * inv)));
+        const int x_lo = max(cx - 1, 0), x_hi = min(cx + 1, kNX - 1);
+        int rs[3], rc[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int iz = cz - 1 + r;
+            const bool in = iz >= 0 && iz < kNX;
+            const int izc = in ? iz : cz;
+            const int s = cell_start[izc * kNX + x_lo], e = cell_start[izc * kNX + x_hi + 1];
+            rs[r] = s;
+            rc[r] = in ? e - s : 0;
+        }
+        const int c01 = rc[0] + rc[1], T = c01 + rc[2];
+        const int offA = rs[0], offB = rs[1] - rc[0], offC = rs[2] - c01;
+        const int rc0 = rc[0];
+        int tau[NB];                                       // admission bound of a band whose first nsample keys are known
+#pragma unroll
+        for (int i = 0; i < NB; ++i) tau[i] = 0x7FFFFFFF;
+        bool filtered = false;
+        int nlist = 0;
+        // the list is about to overflow: sort it, keep what can still be output, remember the bounds
+        auto cut = [&]() {
+            __builtin_amdgcn_wave_barrier();
+            unsigned v[4], nm[4] = {0u, 0u, 0u, 0u};
+            key_sort_list(list, nlist, lane, mir64, v);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int nsi = B.ns[i];
+                int base = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool inb = ((v[r] >> i) & 1u) != 0u;
+                    const unsigned long long bal = __ballot(inb);
+                    if (bal == 0ull) continue;
+                    const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                    if (inb && slot < nsi) nm[r] |= 1u << i;
+                    const unsigned long long last = __ballot(inb && slot == nsi - 1);
+                    if (last != 0ull) tau[i] = (int)(__builtin_amdgcn_readlane((int)v[r], (int)__builtin_ctzll(last)) >> kKeyShift);
+                    base += (int)__popcll(bal);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            int cb = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool keep = nm[r] != 0u;
+                const unsigned long long bal = __ballot(keep);
+                const int pos = cb + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                if (keep) list[pos] = (v[r] & ~((1u << kKeyShift) - 1u)) | nm[r];
+                cb += (int)__popcll(bal);
+            }
+            nlist = cb;
+            filtered = true;
+            __builtin_amdgcn_wave_barrier();
+        };
+
+        float4 nxt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (T > 0) nxt = key_cand(sorted, lane, rc0, c01, T, offA, offB, offC, sent);
+        for (int base = 0; base < T; base += 64) {
+            const float4 cur = nxt;
+            if (base + 64 < T) nxt = key_cand(sorted, base + 64 + lane, rc0, c01, T, offA, offB, offC, sent);
+            const int k = __float_as_int(cur.w);
+            const float dx = x2 - cur.x, dy = y2 - cur.y, dz = z2 - cur.z;
+            const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));   // as ballquery.hip
+            const unsigned u = __float_as_uint(d2);
+            unsigned mask = 0u;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                if (DIL) mask |= (u - B.blo[i]) < B.bwd[i] ? (1u << i) : 0u;
+                else mask |= d2 < B.thi[i] ? (1u << i) : 0u;
+            }
+            if (DIL) mask = u == 0u ? kAll : mask;
+            if (filtered) {
+#pragma unroll
+                for (int i = 0; i < NB; ++i) mask = k > tau[i] ? (mask & ~(1u << i)) : mask;
+            }
+            const bool hit = mask != 0u;
+            const unsigned long long hm = __ballot(hit);
+            if (hm == 0ull) continue;
+            const int at = nlist + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u));
+            if (hit) list[at] = ((unsigned)k << kKeyShift) | mask;                        // at < kSortCap: >= 64 entries were free
+            nlist += (int)__popcll(hm);
+            if (nlist > kSortCap - 64) cut();
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- the keys in index order; a band's output slot = the number of its keys in front
+        unsigned v[4];
+        key_sort_list(list, nlist, lane, mir64, v);
+        const int R = (nlist + 63) >> 6;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int nsi = B.ns[i];
+            int *row = B.idx[i] + qi * nsi;
+            int base = 0, kmin = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (r >= R || base >= nsi) break;
+                const bool inb = ((v[r] >> i) & 1u) != 0u;
+                const unsigned long long bal = __ballot(inb);
+                if (bal == 0ull) continue;
+                if (base == 0) kmin = __builtin_amdgcn_readlane((int)v[r], (int)__builtin_ctzll(bal)) >> kKeyShift;
+                const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                if (inb && slot < nsi) row[slot] = (int)(v[r] >> kKeyShift);
+                base += (int)__popcll(bal);
+            }
+            const int c = min(base, nsi);
+            for (int l = c + lane; l < nsi; l += 64) row[l] = kmin;        // padding: the first hit (0 for an empty ball)
+            if (lane == 0) B.cnt[i][qi] = c;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 float sqrt_ge_threshold_g(float r) {
     if (!(r > 0.0f)) return 0.0f;
     float x = r * r;
@@ -381,6 +638,12 @@ extern "C" int sa_query_ball_point_grid_ex(int b, int n, int m, int nbands, cons
         B.tlo[i] = on && dilated ? sqrt_ge_threshold_g(rmin[i]) : 0.0f;
         B.thi[i] = on ? ((!dilated && rmax[i] <= 1e-20f) ? 0.0f : sqrt_ge_threshold_g(rmax[i])) : 0.0f;
         B.ns[i] = on ? ns[i] : 0;
+        {
+            unsigned lo_bits, hi_bits;
+            memcpy(&lo_bits, &B.tlo[i], 4); memcpy(&hi_bits, &B.thi[i], 4);
+            B.blo[i] = lo_bits;
+            B.bwd[i] = B.thi[i] > B.tlo[i] ? hi_bits - lo_bits : 0u;
+        }
         B.idx[i] = on ? idx[i] : nullptr;
         B.cnt[i] = on ? cnt[i] : nullptr;
         if (on && B.thi[i] > B.thi_max) B.thi_max = B.thi[i];
@@ -398,9 +661,24 @@ extern "C" int sa_query_ball_point_grid_ex(int b, int n, int m, int nbands, cons
     int gx = (m + kQWaves * per_wave - 1) / (kQWaves * per_wave);
     if (gx > 4096) gx = 4096;
     if (gx > 8) gx = (gx + 7) & ~7;                                       // multiples of 8: the XCD-aware frame mapping
+    // the sorting form (round 6) when the bands' nsample fit its key list after a cut; SA_BQ_SORT=0: the list form, for A/B runs
+#ifdef SA_BQ_FORCE_LIST
+    static const bool sort_on = false;
+#else
+    static const bool sort_on = SA_KNOB("SA_BQ_SORT", 1) != 0;
+#endif
+    int ns_sum = 0;
+    for (int i = 0; i < nbands; ++i) ns_sum += ns[i];
+    const bool sorting = sort_on && ns_sum <= kSortCap - 64;
 #define SA_BQ_LAUNCH(NB_, DIL_)                                                                                         \
-    hipLaunchKernelGGL((bq_grid_query_kernel<NB_, DIL_>), dim3(gx, b), dim3(kQWaves * 64), 0, stream, n, m, xyz1, xyz2, \
-                       (const int *)workspace, B)
+    do {                                                                                                                \
+        if (sorting)                                                                                                    \
+            hipLaunchKernelGGL((bq_grid_sort_kernel<NB_, DIL_>), dim3(gx, b), dim3(kQWaves * 64), 0, stream, n, m,      \
+                               xyz2, (const int *)workspace, B);                                                        \
+        else                                                                                                            \
+            hipLaunchKernelGGL((bq_grid_query_kernel<NB_, DIL_>), dim3(gx, b), dim3(kQWaves * 64), 0, stream, n, m,     \
+                               xyz1, xyz2, (const int *)workspace, B);                                                  \
+    } while (0)
     switch (nbands * 2 + (dilated ? 1 : 0)) {
         case 2: SA_BQ_LAUNCH(1, false); break;
         case 3: SA_BQ_LAUNCH(1, true); break;
