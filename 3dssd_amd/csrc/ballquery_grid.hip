@@ -449,9 +449,46 @@ __device__ __forceinline__ float4 key_cand(const char *sorted, int j, int rc0, i
     return *(const float4 *)(sorted + (unsigned)pos * 16u);
 }
 
-template <int NB, bool DIL>
-__global__ __launch_bounds__(kQWaves * 64, 8) void bq_grid_sort_kernel(int n, int m, const float *__restrict__ xyz2,
-                                                                    const int *__restrict__ ws, GBands B) {
+// Per-query set-up as a pass of its own (one THREAD per query): the centre's cell, the bounds of the three z-rows of its
+// 3 x 3 neighbourhood and the offsets that flatten them into one candidate list -- 70 scalar + 10 vector instructions and
+// two dependent scalar-load round trips per query when the query's WAVE did them (the kernel is bound by instruction
+// issue: 0.87 of the scalar pipe on sparse frames).  Record (12 dwords, behind the frames' grids in the workspace):
+//   x, y, z | offA, offB, offC (candidate j lives at sorted[j + off], off by range) | rc0, c01, T (range ends) | 3 unused
+constexpr int kPrepInts = 12;
+__global__ __launch_bounds__(256) void bq_grid_prep_kernel(int n, int m, const float *__restrict__ xyz2,
+                                                           const int *__restrict__ ws, int *__restrict__ prep) {
+    const int b = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= m) return;
+    const int *cell_start = ws + (size_t)b * ws_stride(n);
+    const float *params = (const float *)(cell_start + kCellInts + 4 * (size_t)n);
+    const float mnx = params[0], mnz = params[1], inv = params[2];
+    const size_t qi = (size_t)b * m + q;
+    const float x2 = xyz2[qi * 3 + 0], y2 = xyz2[qi * 3 + 1], z2 = xyz2[qi * 3 + 2];
+    const int cx = min(kNX - 1, max(0, (int)((x2 - mnx) * inv)));
+    const int cz = min(kNX - 1, max(0, (int)((z2 - mnz) * inv)));
+    const int x_lo = max(cx - 1, 0), x_hi = min(cx + 1, kNX - 1);
+    int rs[3], rc[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int iz = cz - 1 + r;
+        const bool in = iz >= 0 && iz < kNX;
+        const int izc = in ? iz : cz;
+        const int s = cell_start[izc * kNX + x_lo], e = cell_start[izc * kNX + x_hi + 1];
+        rs[r] = s;
+        rc[r] = in ? e - s : 0;
+    }
+    const int c01 = rc[0] + rc[1], T = c01 + rc[2];
+    int4 *o = (int4 *)(prep + qi * kPrepInts);
+    o[0] = make_int4(__float_as_int(x2), __float_as_int(y2), __float_as_int(z2), rs[0]);
+    o[1] = make_int4(rs[1] - rc[0], rs[2] - c01, rc[0], c01);
+    o[2] = make_int4(T, 0, 0, 0);
+}
+
+// CONTIG (dilated only): the bands are [0, t1), [t1, t2), ... -- the reference's dilated groups -- so a candidate's mask is
+// one-hot: start at band 0 and move up once per threshold passed (two instructions per threshold instead of three per band)
+template <int NB, bool DIL, bool CONTIG>
+__global__ __launch_bounds__(kQWaves * 64, 8) void bq_grid_sort_kernel(int n, int m, const int *__restrict__ ws,
+                                                                    const int *__restrict__ prep, GBands B) {
     __shared__ unsigned s_keys[kQWaves][kSortCap];
     int b = blockIdx.y, bx = blockIdx.x;
     if ((gridDim.x & 7) == 0 && (gridDim.y & 7) == 0) {                 // XCD-aware, as above
@@ -461,10 +498,7 @@ __global__ __launch_bounds__(kQWaves * 64, 8) void bq_grid_sort_kernel(int n, in
     }
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int *cell_start = ws + (size_t)b * ws_stride(n);
-    const char *sorted = (const char *)(cell_start + kCellInts);
-    const float *params = (const float *)(sorted + (size_t)n * 16);
-    const float mnx = params[0], mnz = params[1], inv = params[2];
+    const char *sorted = (const char *)(ws + (size_t)b * ws_stride(n) + kCellInts);
     unsigned *list = s_keys[w];
     const unsigned mir64 = (unsigned)(63 - lane) << 2;
     // band tests on the BITS of d2 (d2 >= +0 or NaN: unsigned order = float order, a NaN passes no test either way):
@@ -472,26 +506,17 @@ __global__ __launch_bounds__(kQWaves * 64, 8) void bq_grid_sort_kernel(int n, in
     // (B.blo / B.bwd, from the host)
     constexpr unsigned kAll = (1u << NB) - 1u;
     const int sent = n + 1;                               // float4 index of the far "point" behind the params
+    // (host: b * m * max(kPrepInts, nsample) * 4 < 2^32 -- query records and output rows are addressed with 32-bit offsets)
+    const unsigned q0 = (unsigned)b * (unsigned)m;
 
     for (int q = bx * kQWaves + w; q < m; q += gridDim.x * kQWaves) {
-        const size_t qi = (size_t)b * m + q;
-        const float x2 = xyz2[qi * 3 + 0], y2 = xyz2[qi * 3 + 1], z2 = xyz2[qi * 3 + 2];
-        const int cx = min(kNX - 1, max(0, (int)((x2 - mnx) * inv)));
-        const int cz = min(kNX - 1, max(0, (int)((z2 - mnz) * inv)));
-        const int x_lo = max(cx - 1, 0), x_hi = min(cx + 1, kNX - 1);
-        int rs[3], rc[3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int iz = cz - 1 + r;
-            const bool in = iz >= 0 && iz < kNX;
-            const int izc = in ? iz : cz;
-            const int s = cell_start[izc * kNX + x_lo], e = cell_start[izc * kNX + x_hi + 1];
-            rs[r] = s;
-            rc[r] = in ? e - s : 0;
-        }
-        const int c01 = rc[0] + rc[1], T = c01 + rc[2];
-        const int offA = rs[0], offB = rs[1] - rc[0], offC = rs[2] - c01;
-        const int rc0 = rc[0];
+        const unsigned qi = q0 + (unsigned)q;
+        const int4 *rec = (const int4 *)((const char *)prep + qi * (unsigned)(kPrepInts * 4));
+        const int4 r0 = rec[0], r1 = rec[1];
+        const int T = rec[2].x;
+        asm volatile("" ::"s"(r0.x), "s"(r1.x), "s"(T));        // one wait for the whole record (hipcc sinks the first two loads behind a test of T)
+        const float x2 = __int_as_float(r0.x), y2 = __int_as_float(r0.y), z2 = __int_as_float(r0.z);
+        const int offA = r0.w, offB = r1.x, offC = r1.y, rc0 = r1.z, c01 = r1.w;
         int tau[NB];                                       // admission bound of a band whose first nsample keys are known
 #pragma unroll
         for (int i = 0; i < NB; ++i) tau[i] = 0x7FFFFFFF;
@@ -533,20 +558,24 @@ __global__ __launch_bounds__(kQWaves * 64, 8) void bq_grid_sort_kernel(int n, in
             __builtin_amdgcn_wave_barrier();
         };
 
-        float4 nxt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (T > 0) nxt = key_cand(sorted, lane, rc0, c01, T, offA, offB, offC, sent);
-        for (int base = 0; base < T; base += 64) {
-            const float4 cur = nxt;
-            if (base + 64 < T) nxt = key_cand(sorted, base + 64 + lane, rc0, c01, T, offA, offB, offC, sent);
+        // one step = 64 candidates: distances, band bits, the hits appended to the key list
+        auto step = [&](const float4 &cur) {
             const int k = __float_as_int(cur.w);
             const float dx = x2 - cur.x, dy = y2 - cur.y, dz = z2 - cur.z;
             const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));   // as ballquery.hip
             const unsigned u = __float_as_uint(d2);
             unsigned mask = 0u;
+            if (CONTIG) {
+                mask = 1u;
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                if (DIL) mask |= (u - B.blo[i]) < B.bwd[i] ? (1u << i) : 0u;
-                else mask |= d2 < B.thi[i] ? (1u << i) : 0u;
+                for (int i = 1; i < NB; ++i) mask = u >= B.blo[i] ? (1u << i) : mask;
+                mask = u >= B.blo[NB - 1] + B.bwd[NB - 1] ? 0u : mask;
+            } else {
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    if (DIL) mask |= (u - B.blo[i]) < B.bwd[i] ? (1u << i) : 0u;
+                    else mask |= d2 < B.thi[i] ? (1u << i) : 0u;
+                }
             }
             if (DIL) mask = u == 0u ? kAll : mask;
             if (filtered) {
@@ -555,36 +584,77 @@ __global__ __launch_bounds__(kQWaves * 64, 8) void bq_grid_sort_kernel(int n, in
             }
             const bool hit = mask != 0u;
             const unsigned long long hm = __ballot(hit);
-            if (hm == 0ull) continue;
-            const int at = nlist + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u));
-            if (hit) list[at] = ((unsigned)k << kKeyShift) | mask;                        // at < kSortCap: >= 64 entries were free
-            nlist += (int)__popcll(hm);
+            if (hm != 0ull) {
+                const int at = nlist + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u));
+                if (hit) list[at] = ((unsigned)k << kKeyShift) | mask;                    // at < kSortCap: >= 64 entries were free
+                nlist += (int)__popcll(hm);
+            }
+        };
+        // the walk, two steps' candidates in flight (a step's 40 instructions do not cover a load's round trip: with one
+        // step ahead a wave waited ~a microsecond per step); lanes / steps past T read the far point.  A list about to
+        // overflow leaves the inner loop, is cut, and the walk resumes (reloading) where it stopped.
+        int base = 0;
+        while (base < T) {
+            float4 c0 = key_cand(sorted, base + lane, rc0, c01, T, offA, offB, offC, sent);
+            float4 c1 = c0;
+            if (base + 64 < T) c1 = key_cand(sorted, base + 64 + lane, rc0, c01, T, offA, offB, offC, sent);
+            for (;;) {
+                step(c0); base += 64;
+                if (base >= T || nlist > kSortCap - 64) break;
+                c0 = key_cand(sorted, base + 64 + lane, rc0, c01, T, offA, offB, offC, sent);
+                step(c1); base += 64;
+                if (base >= T || nlist > kSortCap - 64) break;
+                c1 = key_cand(sorted, base + 64 + lane, rc0, c01, T, offA, offB, offC, sent);
+            }
             if (nlist > kSortCap - 64) cut();
         }
         __builtin_amdgcn_wave_barrier();
         // ---- the keys in index order; a band's output slot = the number of its keys in front
         unsigned v[4];
+#ifdef SA_BQ_DBG_NOSORT
+        for (int r = 0; r < 4; ++r) v[r] = r * 64 + lane < nlist ? list[r * 64 + lane] : kKeySentinel;
+#else
         key_sort_list(list, nlist, lane, mir64, v);
+#endif
         const int R = (nlist + 63) >> 6;
+#ifdef SA_BQ_DBG_NOOUT
+        if (lane == 0) B.cnt[0][qi] = (int)(v[0] + v[1] + v[2] + v[3]) + R;
+        continue;
+#endif
+        // a band's keys are compacted through the (now free) LDS list -- slot = prefix count of its bit -- and its row leaves
+        // as whole 256-byte pieces: lane l writes entry l, or the first hit behind the last one (0 for an empty ball)
+        int *ilist = (int *)list;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int nsi = B.ns[i];
-            int *row = B.idx[i] + qi * nsi;
-            int base = 0, kmin = 0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (r >= R || base >= nsi) break;
-                const bool inb = ((v[r] >> i) & 1u) != 0u;
+            int base = 0;
+            auto place = [&](unsigned key) {
+                const bool inb = ((key >> i) & 1u) != 0u;
                 const unsigned long long bal = __ballot(inb);
-                if (bal == 0ull) continue;
-                if (base == 0) kmin = __builtin_amdgcn_readlane((int)v[r], (int)__builtin_ctzll(bal)) >> kKeyShift;
-                const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-                if (inb && slot < nsi) row[slot] = (int)(v[r] >> kKeyShift);
-                base += (int)__popcll(bal);
+                if (bal != 0ull) {
+                    const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                    if (inb && slot < nsi) ilist[slot] = (int)(key >> kKeyShift);
+                    base += (int)__popcll(bal);
+                }
+            };
+            place(v[0]);
+            if (R > 1) {
+                place(v[1]);
+                if (R > 2) { place(v[2]); place(v[3]); }
             }
             const int c = min(base, nsi);
-            for (int l = c + lane; l < nsi; l += 64) row[l] = kmin;        // padding: the first hit (0 for an empty ball)
-            if (lane == 0) B.cnt[i][qi] = c;
+            if (c == 0 && lane == 0) ilist[0] = 0;
+            __builtin_amdgcn_wave_barrier();
+            char *row = (char *)B.idx[i];
+            const unsigned rbase = qi * (unsigned)nsi;
+#pragma unroll
+            for (int p = 0; p < (kSortCap - 64) / 64; ++p) {
+                if (p * 64 >= nsi) break;
+                const int l = p * 64 + lane;
+                if (l < nsi) *(int *)(row + ((rbase + (unsigned)l) << 2)) = ilist[l < c ? l : 0];
+            }
+            if (lane == 0) *(int *)((char *)B.cnt[i] + (qi << 2)) = c;
+            __builtin_amdgcn_wave_barrier();
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -604,8 +674,7 @@ float sqrt_ge_threshold_g(float r) {
 // Bytes of device workspace sa_query_ball_point_grid needs for (b, n, m).
 extern "C" size_t sa_query_ball_point_grid_ws_bytes(int b, int n, int m) {
     if (b <= 0 || n <= 0 || m <= 0) return 0;
-    (void)m;
-    return (size_t)b * ws_stride(n) * sizeof(int);
+    return ((size_t)b * ws_stride(n) + (size_t)b * m * kPrepInts) * sizeof(int);      // the frames' grids | the queries' records
 }
 
 extern "C" int sa_query_ball_point_multi(int b, int n, int m, int nbands, const float *rmin, const float *rmax,
@@ -669,12 +738,27 @@ extern "C" int sa_query_ball_point_grid_ex(int b, int n, int m, int nbands, cons
 #endif
     int ns_sum = 0;
     for (int i = 0; i < nbands; ++i) ns_sum += ns[i];
-    const bool sorting = sort_on && ns_sum <= kSortCap - 64;
+    int ns_max = kPrepInts;
+    for (int i = 0; i < nbands; ++i) ns_max = ns[i] > ns_max ? ns[i] : ns_max;
+    const bool sorting = sort_on && ns_sum <= kSortCap - 64 && (size_t)b * m * ns_max * 4 < ((size_t)1 << 32);
+    int *prep = (int *)workspace + (size_t)b * ws_stride(n);
+    if (sorting) {
+        hipLaunchKernelGGL(bq_grid_prep_kernel, dim3((m + 255) / 256, b), dim3(256), 0, stream, n, m, xyz2, (const int *)workspace, prep);
+        SA_CHECK_LAUNCH();
+    }
+    bool contig = dilated != 0 && B.blo[0] == 0u;            // bands [0, t1), [t1, t2), ...: the one-hot band test
+    for (int i = 0; i < nbands; ++i) {
+        contig = contig && B.bwd[i] != 0u;
+        if (i > 0) contig = contig && B.blo[i] == B.blo[i - 1] + B.bwd[i - 1];
+    }
 #define SA_BQ_LAUNCH(NB_, DIL_)                                                                                         \
     do {                                                                                                                \
-        if (sorting)                                                                                                    \
-            hipLaunchKernelGGL((bq_grid_sort_kernel<NB_, DIL_>), dim3(gx, b), dim3(kQWaves * 64), 0, stream, n, m,      \
-                               xyz2, (const int *)workspace, B);                                                        \
+        if (sorting && DIL_ && contig)                                                                                  \
+            hipLaunchKernelGGL((bq_grid_sort_kernel<NB_, DIL_, DIL_>), dim3(gx, b), dim3(kQWaves * 64), 0, stream, n,   \
+                               m, (const int *)workspace, (const int *)prep, B);                                        \
+        else if (sorting)                                                                                               \
+            hipLaunchKernelGGL((bq_grid_sort_kernel<NB_, DIL_, false>), dim3(gx, b), dim3(kQWaves * 64), 0, stream, n,  \
+                               m, (const int *)workspace, (const int *)prep, B);                                        \
         else                                                                                                            \
             hipLaunchKernelGGL((bq_grid_query_kernel<NB_, DIL_>), dim3(gx, b), dim3(kQWaves * 64), 0, stream, n, m,     \
                                xyz1, xyz2, (const int *)workspace, B);                                                  \
