@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void bq_grid_prep_kernel(int n, int m, const f
 // CONTIG (dilated only): the bands are [0, t1), [t1, t2), ... -- the reference's dilated groups -- so a candidate's mask is
 // one-hot: start at band 0 and move up once per threshold passed (two instructions per threshold instead of three per band)
 template <int NB, bool DIL, bool CONTIG>
-__global__ __launch_bounds__(kQWaves * 64, 8) void bq_grid_sort_kernel(int n, int m, const int *__restrict__ ws,
+__global__ __launch_bounds__(kQWaves * 64, 8) void bq_grid_sort_kernel(int n, int m, int qpw, const int *__restrict__ ws,
                                                                     const int *__restrict__ prep, GBands B) {
     __shared__ unsigned s_keys[kQWaves][kSortCap];
     int b = blockIdx.y, bx = blockIdx.x;
@@ -509,8 +509,16 @@ __global__ __launch_bounds__(kQWaves * 64, 8) void bq_grid_sort_kernel(int n, in
     // (host: b * m * max(kPrepInts, nsample) * 4 < 2^32 -- query records and output rows are addressed with 32-bit offsets)
     const unsigned q0 = (unsigned)b * (unsigned)m;
 
-    for (int q = bx * kQWaves + w; q < m; q += gridDim.x * kQWaves) {
-        const unsigned qi = q0 + (unsigned)q;
+    // a wave takes qpw CONSECUTIVE queries: their counts leave as one store per band and 64 queries (a 4-byte store per
+    // query and band was 3 of the 6 store instructions of a query)
+    const int q_first = (bx * kQWaves + w) * qpw, q_end = min(q_first + qpw, m);
+    for (int qs0 = q_first; qs0 < q_end; qs0 += 64) {
+    int cntv[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) cntv[i] = 0;
+    const int nq = min(64, q_end - qs0);
+    for (int t = 0; t < nq; ++t) {
+        const unsigned qi = q0 + (unsigned)(qs0 + t);
         const int4 *rec = (const int4 *)((const char *)prep + qi * (unsigned)(kPrepInts * 4));
         const int4 r0 = rec[0], r1 = rec[1];
         const int T = rec[2].x;
@@ -606,7 +614,11 @@ __global__ __launch_bounds__(kQWaves * 64, 8) void bq_grid_sort_kernel(int n, in
                 if (base >= T || nlist > kSortCap - 64) break;
                 c1 = key_cand(sorted, base + 64 + lane, rc0, c01, T, offA, offB, offC, sent);
             }
+#ifdef SA_BQ_DBG_NOCUT
+            if (nlist > kSortCap - 64) nlist = kSortCap - 64;
+#else
             if (nlist > kSortCap - 64) cut();
+#endif
         }
         __builtin_amdgcn_wave_barrier();
         // ---- the keys in index order; a band's output slot = the number of its keys in front
@@ -618,7 +630,7 @@ __global__ __launch_bounds__(kQWaves * 64, 8) void bq_grid_sort_kernel(int n, in
 #endif
         const int R = (nlist + 63) >> 6;
 #ifdef SA_BQ_DBG_NOOUT
-        if (lane == 0) B.cnt[0][qi] = (int)(v[0] + v[1] + v[2] + v[3]) + R;
+        cntv[0] = lane == t ? (int)(v[0] + v[1] + v[2] + v[3]) + R : cntv[0];
         continue;
 #endif
         // a band's keys are compacted through the (now free) LDS list -- slot = prefix count of its bit -- and its row leaves
@@ -653,10 +665,14 @@ __global__ __launch_bounds__(kQWaves * 64, 8) void bq_grid_sort_kernel(int n, in
                 const int l = p * 64 + lane;
                 if (l < nsi) *(int *)(row + ((rbase + (unsigned)l) << 2)) = ilist[l < c ? l : 0];
             }
-            if (lane == 0) *(int *)((char *)B.cnt[i] + (qi << 2)) = c;
+            cntv[i] = lane == t ? c : cntv[i];
             __builtin_amdgcn_wave_barrier();
         }
         __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+        if (lane < nq) *(int *)((char *)B.cnt[i] + ((q0 + (unsigned)(qs0 + lane)) << 2)) = cntv[i];
     }
 }
 
@@ -751,14 +767,15 @@ extern "C" int sa_query_ball_point_grid_ex(int b, int n, int m, int nbands, cons
         contig = contig && B.bwd[i] != 0u;
         if (i > 0) contig = contig && B.blo[i] == B.blo[i - 1] + B.bwd[i - 1];
     }
+    const int sort_qpw = (m + gx * kQWaves - 1) / (gx * kQWaves);           // consecutive queries per wave (sorting form)
 #define SA_BQ_LAUNCH(NB_, DIL_)                                                                                         \
     do {                                                                                                                \
         if (sorting && DIL_ && contig)                                                                                  \
             hipLaunchKernelGGL((bq_grid_sort_kernel<NB_, DIL_, DIL_>), dim3(gx, b), dim3(kQWaves * 64), 0, stream, n,   \
-                               m, (const int *)workspace, (const int *)prep, B);                                        \
+                               m, sort_qpw, (const int *)workspace, (const int *)prep, B);                              \
         else if (sorting)                                                                                               \
             hipLaunchKernelGGL((bq_grid_sort_kernel<NB_, DIL_, false>), dim3(gx, b), dim3(kQWaves * 64), 0, stream, n,  \
-                               m, (const int *)workspace, (const int *)prep, B);                                        \
+                               m, sort_qpw, (const int *)workspace, (const int *)prep, B);                              \
         else                                                                                                            \
             hipLaunchKernelGGL((bq_grid_query_kernel<NB_, DIL_>), dim3(gx, b), dim3(kQWaves * 64), 0, stream, n, m,     \
                                xyz1, xyz2, (const int *)workspace, B);                                                  \
