@@ -441,7 +441,13 @@ __device__ __forceinline__ void key_sort_list(const unsigned *list, int U, int l
     v[2] = key_clean64(h0 < h1 ? h0 : h1); v[3] = key_clean64(h0 < h1 ? h1 : h0);
 }
 
-// candidate j of a query's flattened 3 x 3 neighbourhood (three index ranges of `sorted`; the far point past T)
+// candidate j of a query's flattened 3 x 3 neighbourhood (three index ranges of `sorted`; the far point past T): its byte offset
+__device__ __forceinline__ unsigned key_cand_off(int j, int rc0, int c01, int T, int offA, int offB, int offC, int sent) {
+    int off = j >= rc0 ? offB : offA;
+    off = j >= c01 ? offC : off;
+    const int pos = j < T ? j + off : sent;
+    return (unsigned)pos * 16u;
+}
 __device__ __forceinline__ float4 key_cand(const char *sorted, int j, int rc0, int c01, int T, int offA, int offB, int offC, int sent) {
     int off = j >= rc0 ? offB : offA;
     off = j >= c01 ? offC : off;
@@ -574,21 +580,31 @@ __global__ __launch_bounds__(kQWaves * 64, 8) void bq_grid_sort_kernel(int n, in
             const unsigned u = __float_as_uint(d2);
             unsigned mask = 0u;
             if (CONTIG) {
+                // one-hot: the band the candidate lies in, and -- once lists were cut -- THAT band's admission bound with it
                 mask = 1u;
+                // (readfirstlane: the bounds as VALUES -- a select between the array's elements makes hipcc move the array to LDS)
+                int tsel = __builtin_amdgcn_readfirstlane(tau[0]);
 #pragma unroll
-                for (int i = 1; i < NB; ++i) mask = u >= B.blo[i] ? (1u << i) : mask;
+                for (int i = 1; i < NB; ++i) {
+                    const bool up = u >= B.blo[i];
+                    const int ti = __builtin_amdgcn_readfirstlane(tau[i]);
+                    mask = up ? (1u << i) : mask;
+                    if (filtered) tsel = up ? ti : tsel;
+                }
                 mask = u >= B.blo[NB - 1] + B.bwd[NB - 1] ? 0u : mask;
+                if (filtered) mask = k > tsel ? 0u : mask;
+                mask = u == 0u ? kAll : mask;                 // the centre itself: every band (never filtered: admitting a key is always safe)
             } else {
 #pragma unroll
                 for (int i = 0; i < NB; ++i) {
                     if (DIL) mask |= (u - B.blo[i]) < B.bwd[i] ? (1u << i) : 0u;
                     else mask |= d2 < B.thi[i] ? (1u << i) : 0u;
                 }
-            }
-            if (DIL) mask = u == 0u ? kAll : mask;
-            if (filtered) {
+                if (DIL) mask = u == 0u ? kAll : mask;
+                if (filtered) {
 #pragma unroll
-                for (int i = 0; i < NB; ++i) mask = k > tau[i] ? (mask & ~(1u << i)) : mask;
+                    for (int i = 0; i < NB; ++i) mask = k > tau[i] ? (mask & ~(1u << i)) : mask;
+                }
             }
             const bool hit = mask != 0u;
             const unsigned long long hm = __ballot(hit);
@@ -601,24 +617,46 @@ __global__ __launch_bounds__(kQWaves * 64, 8) void bq_grid_sort_kernel(int n, in
         // the walk, two steps' candidates in flight (a step's 40 instructions do not cover a load's round trip: with one
         // step ahead a wave waited ~a microsecond per step); lanes / steps past T read the far point.  A list about to
         // overflow leaves the inner loop, is cut, and the walk resumes (reloading) where it stopped.
+        // The walk, in blocks of up to four steps whose candidates are requested together (a step's ~35 instructions do
+        // not cover a load's round trip).  Wherever the next 256 candidates lie inside ONE of the three ranges (near the
+        // sensor; `dense` frames: thousands of candidates) they are four loads off one address (immediate offsets) and the
+        // steps need no range select, bounds test or far-point select.  A list about to overflow is cut at the top of
+        // the loop (ONE site: the cut is 600 instructions) and the walk resumes where it stopped.
         int base = 0;
+        if (T <= 64) {                                        // sparse frames: one step, no loop (and no cut: <= 64 keys)
+            step(*(const float4 *)(sorted + key_cand_off(lane, rc0, c01, T, offA, offB, offC, sent)));
+            base = 64;
+        }
         while (base < T) {
-            float4 c0 = key_cand(sorted, base + lane, rc0, c01, T, offA, offB, offC, sent);
-            float4 c1 = c0;
-            if (base + 64 < T) c1 = key_cand(sorted, base + 64 + lane, rc0, c01, T, offA, offB, offC, sent);
-            for (;;) {
-                step(c0); base += 64;
-                if (base >= T || nlist > kSortCap - 64) break;
-                c0 = key_cand(sorted, base + 64 + lane, rc0, c01, T, offA, offB, offC, sent);
-                step(c1); base += 64;
-                if (base >= T || nlist > kSortCap - 64) break;
-                c1 = key_cand(sorted, base + 64 + lane, rc0, c01, T, offA, offB, offC, sent);
-            }
 #ifdef SA_BQ_DBG_NOCUT
             if (nlist > kSortCap - 64) nlist = kSortCap - 64;
 #else
             if (nlist > kSortCap - 64) cut();
 #endif
+            const int off = base >= c01 ? offC : (base >= rc0 ? offB : offA);
+            const int end = base >= c01 ? T : (base >= rc0 ? c01 : rc0);
+            // byte offsets of the four steps' candidates first, then ONE unconditional set of loads (loads under tests, or one
+            // set per form, made hipcc wait for a load where it was issued to copy it into the registers the paths share);
+            // steps past T read the far point and are not evaluated
+            unsigned o0, o1, o2, o3;
+            if (base + 256 <= end) {
+                o0 = (unsigned)(base + lane + off) * 16u;
+                o1 = o0 + 1024u; o2 = o0 + 2048u; o3 = o0 + 3072u;
+            } else {
+                o0 = key_cand_off(base + lane, rc0, c01, T, offA, offB, offC, sent);
+                o1 = key_cand_off(base + 64 + lane, rc0, c01, T, offA, offB, offC, sent);
+                o2 = key_cand_off(base + 128 + lane, rc0, c01, T, offA, offB, offC, sent);
+                o3 = key_cand_off(base + 192 + lane, rc0, c01, T, offA, offB, offC, sent);
+            }
+            const float4 a0 = *(const float4 *)(sorted + o0), a1 = *(const float4 *)(sorted + o1);
+            const float4 a2 = *(const float4 *)(sorted + o2), a3 = *(const float4 *)(sorted + o3);
+            step(a0); base += 64;
+            if (base >= T || nlist > kSortCap - 64) continue;
+            step(a1); base += 64;
+            if (base >= T || nlist > kSortCap - 64) continue;
+            step(a2); base += 64;
+            if (base >= T || nlist > kSortCap - 64) continue;
+            step(a3); base += 64;
         }
         __builtin_amdgcn_wave_barrier();
         // ---- the keys in index order; a band's output slot = the number of its keys in front
