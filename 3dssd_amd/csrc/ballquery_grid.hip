@@ -536,35 +536,47 @@ __global__ __launch_bounds__(kQWaves * 64, 8) void bq_grid_sort_kernel(int n, in
         for (int i = 0; i < NB; ++i) tau[i] = 0x7FFFFFFF;
         bool filtered = false;
         int nlist = 0;
-        // the list is about to overflow: sort it, keep what can still be output, remember the bounds
+        // The list is about to overflow (193..256 keys): a band that holds nsample keys or more keeps its nsample smallest --
+        // their largest index, found by BISECTION on the index range with wave ballots (4 compares + ~14 scalar instructions
+        // per round: a full sort of the list is 430 vector instructions, and `dense` frames cut 3-4 times per query), is the
+        // band's admission bound from now on; keys left without a band are dropped.  The list stays unsorted.
         auto cut = [&]() {
             __builtin_amdgcn_wave_barrier();
-            unsigned v[4], nm[4] = {0u, 0u, 0u, 0u};
-            key_sort_list(list, nlist, lane, mir64, v);
+            unsigned v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = r * 64 + lane < nlist ? list[r * 64 + lane] : kKeySentinel;
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const int nsi = B.ns[i];
-                int base = 0;
+                unsigned kb[4];                              // the band's keys as indices, 0xFFFFFFFF elsewhere
+                int have = 0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const bool inb = ((v[r] >> i) & 1u) != 0u;
-                    const unsigned long long bal = __ballot(inb);
-                    if (bal == 0ull) continue;
-                    const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-                    if (inb && slot < nsi) nm[r] |= 1u << i;
-                    const unsigned long long last = __ballot(inb && slot == nsi - 1);
-                    if (last != 0ull) tau[i] = (int)(__builtin_amdgcn_readlane((int)v[r], (int)__builtin_ctzll(last)) >> kKeyShift);
-                    base += (int)__popcll(bal);
+                    kb[r] = inb ? v[r] >> kKeyShift : 0xFFFFFFFFu;
+                    have += (int)__popcll(__ballot(inb));
                 }
+                if (have < nsi) continue;                    // every key of the band can still be output
+                unsigned lo = 0u, hi = (unsigned)n - 1u;     // the nsi-th smallest index lies in [lo, hi]
+                while (lo < hi) {
+                    const unsigned mid = lo + ((hi - lo) >> 1);
+                    int c = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) c += (int)__popcll(__ballot(kb[r] <= mid));
+                    if (c >= nsi) hi = mid; else lo = mid + 1u;
+                }
+                tau[i] = (int)lo;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = kb[r] != 0xFFFFFFFFu && kb[r] > lo ? v[r] & ~(1u << i) : v[r];
             }
             __builtin_amdgcn_wave_barrier();
             int cb = 0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const bool keep = nm[r] != 0u;
+                const bool keep = (v[r] & ((1u << kKeyShift) - 1u)) != 0u;      // (the sentinel carries no band)
                 const unsigned long long bal = __ballot(keep);
                 const int pos = cb + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-                if (keep) list[pos] = (v[r] & ~((1u << kKeyShift) - 1u)) | nm[r];
+                if (keep) list[pos] = v[r];
                 cb += (int)__popcll(bal);
             }
             nlist = cb;

@@ -36,6 +36,7 @@ after it -- a ticket raises for ITS package only.  Nothing here is a collective:
 one pipeline and its share of the frames (sharding.py).
 """
 import ctypes
+import gc
 import os
 import time
 import warnings
@@ -322,6 +323,24 @@ class SAPipeline:
         for s in self.slots:
             s.inp.copy_(warm)
         torch.cuda.synchronize(dev)
+        # No garbage collection INSIDE a capture: a collection that Python starts between two launches of a captured pass
+        # finalises whatever cyclic garbage exists -- an earlier pipeline's graphs, events and streams included -- and
+        # destroying those while a stream of this process is capturing aborts the process inside the HIP runtime (seen as
+        # an intermittent "Fatal Python error: Aborted ... Garbage-collecting" when several pipelines are built in one
+        # process).  torch.cuda.graph collects once on entry; the automatic collector is off until the captures are done.
+        gc_was_on = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        try:
+            self._capture_all()
+        finally:
+            if gc_was_on:
+                gc.enable()
+        torch.cuda.synchronize(dev)
+        # every graph replayed once as part of the set-up (the first replay uploads the executable graph)
+        self._first_replays()
+
+    def _capture_all(self):
         for s in self.slots:
             pool = None
             for size in reversed(self.sizes):                 # the largest first: the smaller ones fit into its pool
@@ -361,8 +380,9 @@ class SAPipeline:
                         pool = pool or g.pool()
                         s.graphs[size] = (None, g)
                 s.lists[size] = lists
-        torch.cuda.synchronize(dev)
-        # every graph replayed once as part of the set-up (the first replay uploads the executable graph)
+
+    def _first_replays(self):
+        dev = self.device
         for s in self.slots:
             for size in self.sizes:
                 ga, gb = s.graphs[size]

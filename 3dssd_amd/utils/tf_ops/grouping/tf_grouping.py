@@ -64,7 +64,7 @@ def _grid_workspace(lib, xyz1, b, n, m, stream):
     if not SHARE_GRID or xyz1.is_inference() or torch.cuda.is_current_stream_capturing():
         return torch.empty((lib.sa_query_ball_point_grid_ws_bytes(b, n, m) + 3) // 4, dtype=torch.int32, device=xyz1.device), 0
     g = _grid_of_last_call
-    key = (xyz1._version, xyz1.data_ptr(), tuple(xyz1.shape), stream)
+    key = (xyz1._version, xyz1.data_ptr(), tuple(xyz1.shape), stream, m)     # m: the workspace also holds one record per query (round 6)
     if g is not None and g[0]() is xyz1 and g[1] == key:
         return g[2], 1
     ws = torch.empty((lib.sa_query_ball_point_grid_ws_bytes(b, n, m) + 3) // 4, dtype=torch.int32, device=xyz1.device)

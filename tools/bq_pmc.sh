@@ -3,7 +3,7 @@
 TAG=${1:-bq_pmc}; DATA=${2:-rings64}; OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp PYTHONUNBUFFERED=1
 [ -n "$3" ] && export SA3D_LIB=$GRAFT_REPO_ROOT/3dssd_amd/csrc/variants/$3
-CMD="python $GRAFT_REPO_ROOT/tools/prof_128f.py $OUT/work $DATA 2"
+CMD="python $GRAFT_REPO_ROOT/tools/bq_bench.py ${FRAMES:-128} $DATA 3"
 cd /tmp
 i=0
 for pass in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" \
