@@ -7,13 +7,17 @@
 // histogram, scan, scatter -- order inside a cell is irrelevant); (2) per query, visit the 3 x 3 cells around it,
 // evaluate exactly the same d2 and thresholds as ballquery.hip on those candidates only, collect the hits of
 // every band in LDS, and place hit h at output slot rank(h) = #{hits with a smaller index} if rank < nsample.
-// A band with more hits than its LDS list holds (kCap; a simulated 64-beam sweep has 300-1000 points inside a 0.8 m
-// ball near the sensor, synthetic.py rings64) is handled IN PLACE since round 4: only the nsample smallest indices can
-// ever be output, so when a list is about to fill up it is cut down to its nsample smallest entries (the nsample-th
-// smallest value by bisection on wave ballots, ~200 instructions) and that value becomes the band's admission bound
-// for the rest of the walk; the total hit count (pts_cnt = min(total, nsample)) is kept separately.  The ranking at
-// the end then never sees more than nsample entries of a band that overflowed.  (Rounds 2-3 redid such a query by an
-// ordered full scan of all n points: correct, and 17x slower on dense frames -- VERDICT r3 weak #8.)
+// Round 6, the SORTING form (bq_grid_sort_kernel, further down; the default whenever sum(nsample) <= 192): a pass with one
+// THREAD per query writes the query's record (centre, the three candidate ranges of its 3 x 3 cells); the query's wave
+// walks the candidates in blocks of four 64-candidate steps, appends the hits of ANY band to one key list
+// (index << 4 | band mask), sorts that list once in registers (bitonic network over the wave) and reads every band's slot
+// as the prefix count of its mask bit.  A list about to overflow (near the sensor, `dense` frames) is cut to the keys that
+// can still be output -- the nsample-th smallest index of a full band, found by bisection on wave ballots, becomes the
+// band's admission bound for the rest of the walk.
+// The LIST form of rounds 4-5 (bq_grid_query_kernel: per-band LDS lists, ranking by v_readlane loops) stays for larger
+// nsample sums: a band with more hits than its LDS list holds (kCap) is cut down IN PLACE to its nsample smallest entries
+// (bisection on wave ballots) and that value becomes the band's admission bound; pts_cnt = min(total, nsample) is kept
+// separately.  (Rounds 2-3 redid such a query by an ordered full scan of all n points: 17x slower on dense frames.)
 //
 // Cell geometry: cell = clamp(int((coord - min) * inv), 0, kNX-1) with cell size >= r_max * (1 + 1e-4): monotone in
 // the coordinate, so |dx| <= r_max implies a cell difference of at most 1 (the margin absorbs the fp32 rounding of
@@ -348,9 +352,13 @@ __global__ __launch_bounds__(kQWaves * 64, 8) void bq_grid_query_kernel(int n, i
 // wave (63 vector instructions for 64 keys whatever the bands; only the phases the entry count needs; up to 256 keys in
 // four registers per lane).  In index order a band's output slot is a prefix count of its mask bit (ballot + mbcnt): no
 // ranking loop, no per-band lists (15 KB of LDS per workgroup -> 4), no scalar work per hit.  A list about to overflow
-// (> 192 keys; near the sensor, or `dense` frames) is sorted too, cut to the keys that can still be output (the first
-// nsample of every band) and the nsample-th key of a saturated band becomes its admission bound, as before.
-// Needs sum(nsample) <= 192 (3dssd.yaml: 128); the kernel above stays for larger ones.
+// (> 192 keys; near the sensor, or `dense` frames) is cut to the keys that can still be output: a band holding nsample keys
+// or more keeps its nsample smallest -- their largest index, found by bisection on wave ballots, is the band's admission
+// bound from then on, as in the list form.  Needs sum(nsample) <= 192 (3dssd.yaml: 128) and 32-bit row offsets; the kernel
+// above stays for the rest.  Measured at the layer-1 shape (128 frames; default / rings64, `dense` per 32 frames), list form
+// 366 / 1 093 / 1 571 us: sorting 290 / 841 / 1 439; + the set-up pass, 32-bit offsets, rows through an LDS compaction,
+// one-hot band test 222 / 774 / 1 282; + consecutive queries per wave, blocks of four steps 200 / 723 / 1 052; + cuts by
+// bisection instead of a full sort 194 / 683 / 986 (profiles/r06_ballquery_sort_ab.txt).
 constexpr int kSortCap = 256;              // keys per query list = 4 per lane
 constexpr int kKeyShift = 4;               // key = index << 4 | band mask (kMaxBands bits)
 constexpr unsigned kKeySentinel = 0xFFFFFFF0u;     // sorts behind every key, belongs to no band
@@ -448,13 +456,6 @@ __device__ __forceinline__ unsigned key_cand_off(int j, int rc0, int c01, int T,
     const int pos = j < T ? j + off : sent;
     return (unsigned)pos * 16u;
 }
-__device__ __forceinline__ float4 key_cand(const char *sorted, int j, int rc0, int c01, int T, int offA, int offB, int offC, int sent) {
-    int off = j >= rc0 ? offB : offA;
-    off = j >= c01 ? offC : off;
-    const int pos = j < T ? j + off : sent;
-    return *(const float4 *)(sorted + (unsigned)pos * 16u);
-}
-
 // Per-query set-up as a pass of its own (one THREAD per query): the centre's cell, the bounds of the three z-rows of its
 // 3 x 3 neighbourhood and the offsets that flatten them into one candidate list -- 70 scalar + 10 vector instructions and
 // two dependent scalar-load round trips per query when the query's WAVE did them (the kernel is bound by instruction

@@ -1106,6 +1106,69 @@ def test_grid_ball_query_bands_with_more_hits_than_the_lds_list(gpu, oracle, var
     assert over > 0                                               # the case really has full balls
 
 
+@pytest.mark.parametrize("rmins,rmaxs,nss,dil", [
+    ([0.0, 0.3, 0.2], [0.5, 0.9, 0.4], [16, 32, 8], True),        # dilated bands that overlap and leave gaps: the per-band bit test
+    ([0.1, 0.4], [0.4, 1.2], [32, 64], True),                     # contiguous but not from 0: not the one-hot form either
+    ([0.0, 0.0, 0.0], [0.3, 0.6, 1.2], [16, 32, 64], False),      # plain (nested) balls: a key carries several band bits
+    ([0.0, 0.4], [0.4, 1.6], [64, 128], True),                    # sum(nsample) = 192: the most the sorting form takes
+    ([0.0, 0.4], [0.4, 1.6], [64, 129], True),                    # 193: the list form
+    ([0.0, 0.2, 0.4, 0.8], [0.2, 0.4, 0.8, 1.6], [8, 16, 32, 64], True),      # four bands
+])
+@pytest.mark.parametrize("variant", ["default", "rings64", "dense"])
+def test_grid_ball_query_sorting_form_band_shapes(gpu, oracle, variant, rmins, rmaxs, nss, dil):
+    # round 6 (ballquery_grid.hip, bq_grid_sort_kernel): one key list per query (index << 4 | band mask), sorted in
+    # registers; a band's slot is the prefix count of its bit; overflowing lists are cut by bisection.  Band geometries the
+    # backbone does not use, on sparse / ring-structured / all-full frames (long walks, cuts, 2- and 4-register sorts);
+    # m = 333: ragged last wave.  Reference: tf_grouping_g.cu:215-255,308-357 through the oracle.
+    syn = pkg("synthetic")
+    n, m = 16384, 333
+    xyz1 = np.stack([syn.frame_of(variant, 31 + i, n)[:, :3] for i in range(2)])
+    rng = np.random.default_rng(len(nss) * 7 + nss[-1])
+    xyz2 = np.ascontiguousarray(np.stack([x[rng.permutation(n)[:m]] for x in xyz1]))
+    xyz2[:, ::5] += rng.normal(0, 0.05, xyz2[:, ::5].shape).astype(np.float32)      # some centres that are not points
+    idx, cnt = _run_grid_bq(gpu, xyz1, xyz2, rmins, rmaxs, nss, dil)
+    for i in range(len(nss)):
+        if dil:
+            ridx, rcnt = oracle.query_ball_point_dilated(rmins[i], rmaxs[i], nss[i], xyz1, xyz2)
+        else:
+            ridx, rcnt = oracle.query_ball_point(rmaxs[i], nss[i], xyz1, xyz2)
+        _check_ball(idx[i], cnt[i], ridx, rcnt)
+
+
+@pytest.mark.parametrize("variant", ["default", "rings64", "dense"])
+def test_grid_ball_query_layer1_shape_equals_the_scan_kernel(gpu, variant):
+    # the layer-1 call of 3dssd.yaml as the backbone makes it (4096 D-FPS centres of 16384 points, dilated 0.2 / 0.4 / 0.8,
+    # nsample 32 / 32 / 64, 8 frames = the XCD-aware mapping, 8 consecutive queries per wave): idx and cnt bit-equal to the
+    # brute-force scan kernel (ballquery.hip), which the oracle tests pin at small sizes
+    import ctypes
+    N, syn = pkg("utils._native"), pkg("synthetic")
+    S = pkg("utils.tf_ops.sampling.tf_sampling")
+    lib = N.lib()
+    b, n, m, nb = 8, 16384, 4096, 3
+    xyz = torch.from_numpy(np.stack([syn.frame_of(variant, 50 + f, n)[:, :3] for f in range(b)])).to(gpu).contiguous()
+    ctr = S.gather_point(xyz, S.farthest_point_sample(m, xyz)).contiguous()
+    nss = [32, 32, 64]
+    args = (b, n, m, nb, (ctypes.c_float * nb)(0.0, 0.2, 0.4), (ctypes.c_float * nb)(0.2, 0.4, 0.8), (ctypes.c_int * nb)(*nss), 1,
+            xyz.data_ptr(), ctr.data_ptr())
+    out = []
+    for which in ("grid", "scan"):
+        idx = [torch.full((b, m, s), -7, dtype=torch.int32, device=gpu) for s in nss]
+        cnt = [torch.full((b, m), -7, dtype=torch.int32, device=gpu) for _ in nss]
+        ptrs = ((ctypes.c_void_p * nb)(*[t.data_ptr() for t in idx]), (ctypes.c_void_p * nb)(*[t.data_ptr() for t in cnt]))
+        if which == "grid":
+            ws = torch.empty((lib.sa_query_ball_point_grid_ws_bytes(b, n, m) + 3) // 4, dtype=torch.int32, device=gpu)
+            assert lib.sa_query_ball_point_grid(*args, *ptrs, ws.data_ptr(), N.current_stream()) == 0
+        else:
+            assert lib.sa_query_ball_point_multi(*args, *ptrs, N.current_stream()) == 0
+        torch.cuda.synchronize()
+        out.append((idx, cnt))
+    for i in range(nb):
+        assert torch.equal(out[0][1][i], out[1][1][i]), "cnt of band %d" % i
+        assert torch.equal(out[0][0][i], out[1][0][i]), "idx of band %d" % i
+    if variant != "default":
+        assert int((out[0][1][2] >= 64).sum()) > 0                     # full balls (cut lists) really occur
+
+
 @pytest.mark.parametrize("b,n,m", [(8, 3000, 64), (16, 2500, 96), (8, 2100, 30), (8, 2200, 40)])
 def test_grid_ball_query_frame_to_xcd_mapping(gpu, oracle, b, n, m):
     # b a multiple of 8 and ceil(m / 4) workgroups per frame a multiple of 8: the query kernel remaps (frame, workgroup) so
