@@ -237,7 +237,7 @@ extern "C" int sa_ffps_fly_ex(int b, int n, int c1, int m, const float *xyz, lon
         if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return SA_ERR_UNSUPPORTED; }
     }
     const int per_launch = cap / G;
-    if (hipMemsetAsync(workspace, 0, sa_ffps_fly_ws_bytes(b, n), stream) != hipSuccess) return SA_ERR_LAUNCH;
+    if (sa::zero_async(workspace, sa_ffps_fly_ws_bytes(b, n), stream) != hipSuccess) return SA_ERR_LAUNCH;
     for (int f0 = 0; f0 < b; f0 += per_launch) {
         const int nf = b - f0 < per_launch ? b - f0 : per_launch;
         FlyArgs A;

@@ -211,12 +211,17 @@ static int fps_coop_launch(int b, int n, int c, int m, const float *inp, float *
     if (cap < G) return SA_ERR_UNSUPPORTED;
     const int per_launch = cap / G;                     // frames per cooperative launch
     if (max_spin == 0) max_spin = kMaxSpin;
-    // every frame of the call has its OWN slots (2 G words), zeroed by one memset in front of the first launch: the
+    // every frame of the call has its OWN slots (2 G words), zeroed by one KERNEL (sa::zero_async: not a memset node, see
+    // sa_common.h) in front of the first launch: the
     // consecutive launches of a large batch share nothing, so nothing depends on how a memset between two of them is
     // ordered (a shared region re-zeroed between the launches gave wrong picks in frames of the SECOND launch when the
     // call was replayed from a hipGraph beside other streams' kernels -- round 4, tools/archive/dbg_pipe.py)
     unsigned long long *slots0 = (unsigned long long *)temp;
+#ifdef SA_COOP_MEMSET          // (variant builds only: the memset node of rounds 4-5, for tests/…does_not_read_what_its_exchange_words_held_before)
     if (hipMemsetAsync(slots0, 0, (size_t)b * 2 * G * sizeof(unsigned long long), stream) != hipSuccess) return SA_ERR_LAUNCH;
+#else
+    if (sa::zero_async(slots0, (size_t)b * 2 * G * sizeof(unsigned long long), stream) != hipSuccess) return SA_ERR_LAUNCH;
+#endif
     for (int f0 = 0; f0 < b; f0 += per_launch) {
         const int nf = b - f0 < per_launch ? b - f0 : per_launch;
         unsigned long long *slots = slots0 + (size_t)f0 * 2 * G;

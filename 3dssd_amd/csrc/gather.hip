@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(long total, int c
 template <bool NEG1_SKIP>
 int launch_scatter(int b, int n, int c, long rows_per_batch, const float *g, const int *idx, float *dst,
                    hipStream_t stream) {
-    if (hipMemsetAsync(dst, 0, (size_t)b * n * c * sizeof(float), stream) != hipSuccess) return SA_ERR_LAUNCH;
+    if (sa::zero_async(dst, (size_t)b * n * c * sizeof(float), stream) != hipSuccess) return SA_ERR_LAUNCH;
     const long total = (long)b * rows_per_batch * c;
     long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;

@@ -33,6 +33,27 @@ int *coop_error_word() {
     }
     return w;
 }
+
+namespace {
+__global__ __launch_bounds__(256) void zero_words_kernel(unsigned *p, size_t nwords) {
+    const size_t stride = (size_t)gridDim.x * 256 * 4;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < nwords; i += stride) {
+        if (i + 4 <= nwords && ((uintptr_t)(p + i) & 15) == 0) {
+            *(uint4 *)(p + i) = make_uint4(0u, 0u, 0u, 0u);
+        } else {
+            for (size_t j = i; j < nwords && j < i + 4; ++j) p[j] = 0u;
+        }
+    }
+}
+}  // namespace
+hipError_t zero_async(void *p, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return hipSuccess;
+    const size_t nwords = bytes / 4;
+    size_t blocks = (nwords + 1023) / 1024;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (unsigned *)p, nwords);
+    return hipGetLastError();
+}
 }  // namespace sa
 
 // The sticky word: 0 = fine; bit 0 = a multi-workgroup D-FPS (fps_coop.hip), bit 1 = an on-the-fly F-FPS (ffps_fly.hip)

@@ -127,7 +127,7 @@ extern "C" int sa_k_interpolate(int b, int m, int c, int n, int k, const float *
 extern "C" int sa_k_interpolate_grad(int b, int n, int c, int m, int k, const float *grad_out, const int *idx,
                                      const float *weight, float *grad_points, hipStream_t stream) {
     if (b <= 0 || m <= 0 || c <= 0 || n <= 0 || k <= 0 || !grad_out || !idx || !weight || !grad_points) return SA_ERR_INVALID;
-    if (hipMemsetAsync(grad_points, 0, (size_t)b * m * c * sizeof(float), stream) != hipSuccess) return SA_ERR_LAUNCH;
+    if (sa::zero_async(grad_points, (size_t)b * m * c * sizeof(float), stream) != hipSuccess) return SA_ERR_LAUNCH;
     const long total = (long)b * n * c;
     const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
     hipLaunchKernelGGL(interpolate_grad_kernel, dim3(grid), dim3(256), 0, stream, total, m, c, n, k, grad_out, idx, weight,

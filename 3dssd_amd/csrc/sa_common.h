@@ -36,6 +36,14 @@ namespace sa {
 // of such a sampler (or sa_coop_error_state) reports SA_ERR_PARTNERS.  nullptr when the word could not be allocated.
 int *coop_error_word();
 constexpr int kCoopErrFps = 1, kCoopErrFfps = 2;
+
+// Zero `bytes` (a multiple of 4, `p` 4-byte aligned) with a KERNEL on `stream` (hostutil.hip); hipSuccess or the launch
+// error.  Not hipMemsetAsync: captured into a hipGraph, a memset node was not reliably ordered in front of the kernel
+// node behind it on ROCm 7.2 -- the multi-workgroup sampler then read whatever the region held (scratch of a later stage
+// of the previous replay) as its partners' exchange words and, where 16 bits of that matched the pick number, picked
+// differently in 2-10 % of the replays, without any time-out (round 6, tools/verify_layers.py; round 4 saw the same with
+// a memset BETWEEN two launches).  Kernel -> kernel edges are what every captured pass of this library relies on.
+hipError_t zero_async(void *p, size_t bytes, hipStream_t stream);
 __device__ __forceinline__ void coop_raise(int *word, int code) {
     // a plain system-scope store (not a fetch-or: an atomic RMW on host memory needs PCIe AtomicOps routing); two kinds of
     // failure in flight at once would leave the later code -- non-zero either way

@@ -160,14 +160,17 @@ int sa_query_ball_point_multi(int b, int n, int m, int nbands, const float *rmin
                               int *const *idx, int *const *cnt, sa_stream_t stream);
 
 /* The same through a uniform x-z grid built per frame (3dssd_amd/csrc/ballquery_grid.hip): identical outputs,
- * ~10x fewer distance evaluations on large frames.  workspace: caller-owned device memory of
- * sa_query_ball_point_grid_ws_bytes(b, n, m) bytes; nbands <= 4. */
+ * ~10x fewer distance evaluations on large frames.  workspace: caller-owned, 16-byte aligned device memory of
+ * sa_query_ball_point_grid_ws_bytes(b, n, m) bytes (the frames' grids, then -- round 6 -- one 48-byte record per query:
+ * the size depends on m); nbands <= 4.  sum(ns) <= 192 runs the sorting form of the query kernel, larger sums the list
+ * form, ns[i] > 256 the scan kernels: identical outputs. */
 unsigned long sa_query_ball_point_grid_ws_bytes(int b, int n, int m);
 int sa_query_ball_point_grid(int b, int n, int m, int nbands, const float *rmin, const float *rmax, const int *ns,
                              int dilated, const float *xyz1, const float *xyz2, int *const *idx, int *const *cnt,
                              void *workspace, sa_stream_t stream);
 /* flags bit 0: `workspace` still holds the grid an earlier, stream-ordered call built over the SAME xyz1 contents (same
- * b, n): kept if its cells are wide enough for these radii (decided on the device), rebuilt otherwise.  The per-band
+ * b, n; the workspace sized for an m at least as large): kept if its cells are wide enough for these radii (decided on
+ * the device), rebuilt otherwise; the query records are rewritten by every call.  The per-band
  * calls of the reference's stand-alone ops over one point set (tf_grouping.py:53-83) share one grid this way. */
 int sa_query_ball_point_grid_ex(int b, int n, int m, int nbands, const float *rmin, const float *rmax, const int *ns,
                                 int dilated, const float *xyz1, const float *xyz2, int *const *idx, int *const *cnt,

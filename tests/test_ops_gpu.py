@@ -1333,6 +1333,50 @@ def test_multi_workgroup_sampler_under_capture_is_opt_in(gpu, oracle):
     assert np.array_equal(outs[0], ref) and np.array_equal(outs[1], ref)
 
 
+def test_captured_multi_workgroup_sampler_does_not_read_what_its_exchange_words_held_before(gpu, oracle):
+    # round 6 (tools/verify_layers.py): captured into a hipGraph, the hipMemsetAsync that zeroed the partners' exchange words
+    # was not reliably ordered in front of the sampler's kernel node -- the workgroups then read whatever the region held
+    # (in the executor: scratch of a later stage of the previous replay) and, where 16 bits of that matched the pick number,
+    # disagreed about a winner: different picks in 2-10 % of the configs[4] replays, no time-out.  The words are now zeroed
+    # by a KERNEL node (sa::zero_async).  Here the region is poisoned inside the graph, right in front of the sampler, with
+    # words that pass for the partners' words of EVERY early pick; every replay must equal the oracle.  (On its own this graph
+    # replays correctly with the memset node too -- the misordering needs the executor's stage graphs on three streams:
+    # tests/test_pipeline_gpu.py::test_configs4_frames_replay_after_replay_equal_eager is the test that fails on that build.)
+    lib = pkg("utils._native").lib()
+    rng = np.random.default_rng(66)
+    b, n, m = 4, 40000, 48                                            # 16 workgroups per frame
+    p = rng.normal(0, 1, (b, n, 3)).astype(np.float32)
+    x = _t(p, gpu)
+    ref = oracle.farthest_point_sample(m, p)
+    temp = torch.empty((b, n), dtype=torch.float32, device=gpu)
+    words = temp.view(torch.int64).view(-1)[:b * 32]                  # 2 x 16 exchange words per frame
+    # {value bits | pick number << 16 | tie key}: a huge value with the pick number of the word's parity slot
+    poison = torch.tensor([(0x7F000000 << 32) | ((1 + (i // 16) % 2) << 16) | (i % 1024) for i in range(b * 32)],
+                          dtype=torch.int64, device=gpu)
+    out = torch.zeros((b, m), dtype=torch.int32, device=gpu)
+    side = torch.cuda.Stream(device=gpu)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        words.copy_(poison)                                           # a kernel node in front of the sampler's nodes
+        st = lib.sa_fps_ex3(b, n, 3, m, x.data_ptr(), 0, temp.data_ptr(), out.data_ptr(), m, 0, None, 0, 1,
+                            torch.cuda.current_stream().cuda_stream)
+    assert st == 0
+    # (the misordering showed beside OTHER streams' kernels: a second stream keeps the chip busy during the replays)
+    busy = torch.cuda.Stream(device=gpu)
+    a = torch.randn((4096, 4096), device=gpu)
+    for _ in range(24):
+        out.zero_()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(busy):
+            for _ in range(6):
+                a = torch.tanh(a @ a) * 0.01
+        with torch.cuda.stream(side):
+            g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), ref)
+    assert lib.sa_coop_error_state(0) == 0
+
+
 @pytest.mark.gpu
 def test_stand_alone_band_calls_over_one_point_set_share_the_grid(gpu, oracle):
     """tf_grouping.query_ball_point keeps the grid of the last point set: the per-band calls of the reference's

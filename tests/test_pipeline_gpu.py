@@ -119,6 +119,38 @@ def test_frames_beyond_16384_points_are_captured_by_the_staged_executor(gpu):
         P.SAPipeline(arch, params, gpu, batch=1, points=20000, streams=2, mode="slots")
 
 
+def test_configs4_frames_replay_after_replay_equal_eager(gpu):
+    # round 6: at the configs[4] shape (65536-point frames: the multi-workgroup layer-1 sampler, launched plainly inside the
+    # captured stage A) 2-10 % of the replays picked different centres than the eager pass, without any time-out: the
+    # hipMemsetAsync that zeroed the partners' exchange words, captured as a memset node, was not reliably ordered in front
+    # of the sampler's kernel node, and the words still held scratch of the previous replay's stage B (tools/verify_layers.py
+    # found the layer; the build with the memset node differs in 8 of 96 batches at exactly this shape).  The words are
+    # zeroed by a kernel node now (csrc/sa_common.h, sa::zero_async): twelve rounds over all four slots, every batch bit-equal.
+    cfgs, syn = pkg("configs"), pkg("synthetic")
+    arch = cfgs.KITTI_3DSSD_ARCH
+    P = pkg("pipeline")
+    pipe = P.SAPipeline(arch, syn.random_backbone_params(arch), gpu, batch=4, points=65536, streams=4, coalesce=2,
+                        max_translate_range=cfgs.KITTI_MAX_TRANSLATE_RANGE, mode="staged")
+    assert pipe.graphs
+    dev = [torch.from_numpy(h).to(gpu) for h in _batches("default", 8, 4, first=40, n=65536)]
+    eager = []
+    for t in dev:
+        xl, fl, _ = pipe.forward_eager(t)
+        eager.append((xl[1].clone(), fl[-1].clone()))                 # the layer-1 centres, the backbone's features
+    torch.cuda.synchronize()
+    for rnd in range(12):
+        tickets = [pipe.submit(t, sync_source=False) for t in dev]
+        pipe.flush()
+        for i, tk in enumerate(tickets):
+            tk.wait()
+            r = tk._round
+            xl, fl, _ = r.slot.lists[r.size]
+            lo, hi = tk._part * 4, (tk._part + 1) * 4
+            assert torch.equal(xl[1][lo:hi], eager[i][0]), "layer-1 centres, round %d batch %d" % (rnd, i)
+            assert torch.equal(fl[-1][lo:hi], eager[i][1]), "features, round %d batch %d" % (rnd, i)
+    assert pkg("utils._native").lib().sa_coop_error_state(0) == 0
+
+
 @pytest.mark.parametrize("mode", ["staged", "slots"])
 def test_coalescing_slots_give_every_batch_its_own_eager_result(gpu, mode):
     # coalesce=3: a slot takes three consecutive batches and runs the backbone over all six frames in one pass.  Frames

@@ -19,13 +19,14 @@ def main():
     data = sys.argv[2] if len(sys.argv) > 2 else "default"
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 7
     check = len(sys.argv) > 4 and sys.argv[4] == "check"
+    npts = int(sys.argv[5]) if len(sys.argv) > 5 else 16384
     dev = torch.device("cuda:0")
     syn, N = pkg("synthetic"), pkg("utils._native")
     S = pkg("utils.tf_ops.sampling.tf_sampling")
     lib = N.lib()
-    x = torch.from_numpy(np.stack([syn.frame_of(data, f, 16384) for f in range(frames)])).to(dev)
+    x = torch.from_numpy(np.stack([syn.frame_of(data, f, npts) for f in range(frames)])).to(dev)
     xyz = x[:, :, :3].contiguous()
-    n, m = 16384, 4096
+    n, m = npts, 4096
     new_xyz = S.gather_point(xyz, S.farthest_point_sample(m, xyz)).contiguous()
     radii, nss = [0.2, 0.4, 0.8], [32, 32, 64]
     nb = 3
@@ -64,6 +65,15 @@ def main():
         torch.cuda.synchronize()
         ok = all(torch.equal(a, b) for a, b in zip(idx, idx2)) and all(torch.equal(a, b) for a, b in zip(cnt, cnt2))
         print("   idx / cnt equal to the scan kernel: %s" % ok)
+        if not ok:
+            for i in range(nb):
+                bad = (idx[i] != idx2[i]).any(-1) | (cnt[i] != cnt2[i])
+                w = bad.nonzero()
+                print("   band %d: %d queries differ; first %s" % (i, int(bad.sum()), w[:3].tolist()))
+                if len(w):
+                    f, q = int(w[0][0]), int(w[0][1])
+                    print("      grid cnt %d scan cnt %d" % (int(cnt[i][f, q]), int(cnt2[i][f, q])))
+                    print("      grid", idx[i][f, q].tolist()); print("      scan", idx2[i][f, q].tolist())
 
 
 if __name__ == "__main__":
