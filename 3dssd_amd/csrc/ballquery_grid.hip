@@ -69,11 +69,34 @@ __global__ __launch_bounds__(1024) void bq_grid_build_kernel(int n, float cell_m
     float *params = (float *)(sorted + n);
     if (reuse && params[3] >= cell_min) return;          // (the same word for every thread of the workgroup)
 
+    // Frames of at most 16384 points (every layer of 3dssd.yaml): a thread keeps its 16 points in registers for all passes,
+    // and the cell lists leave through LDS (round 6).  The direct scatter below wrote 16 bytes per point to a random place of
+    // the frame's 256 KB list: 45 of the kernel's 51 us on spread-out frames (5 us on `dense` ones, whose few cells make the
+    // same writes consecutive).  Here every point's position is taken first (the same LDS cursors), then the list is
+    // assembled in LDS a quarter (4096 points = the 64 KB the counters no longer need) at a time and copied out in whole
+    // 1 KB pieces.  The order INSIDE a cell may differ from the scatter's (both are arbitrary: atomics); no reader depends on it.
+    const bool small = n <= 16 * 1024;
+    float qx[16], qy[16], qz[16];
+    if (small) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int k = min(tid + u * 1024, n - 1);
+            qx[u] = p[k * 3 + 0]; qy[u] = p[k * 3 + 1]; qz[u] = p[k * 3 + 2];
+        }
+    }
     float mnx = 3e38f, mxx = -3e38f, mnz = 3e38f, mxz = -3e38f;
-    for (int k = tid; k < n; k += 1024) {
-        const float x = p[k * 3 + 0], z = p[k * 3 + 2];
-        mnx = sa::fmin_nn(mnx, x); mxx = sa::fmax_nn(mxx, x);
-        mnz = sa::fmin_nn(mnz, z); mxz = sa::fmax_nn(mxz, z);
+    if (small) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {                         // (a repeated point n - 1 changes no extreme)
+            mnx = sa::fmin_nn(mnx, qx[u]); mxx = sa::fmax_nn(mxx, qx[u]);
+            mnz = sa::fmin_nn(mnz, qz[u]); mxz = sa::fmax_nn(mxz, qz[u]);
+        }
+    } else {
+        for (int k = tid; k < n; k += 1024) {
+            const float x = p[k * 3 + 0], z = p[k * 3 + 2];
+            mnx = sa::fmin_nn(mnx, x); mxx = sa::fmax_nn(mxx, x);
+            mnz = sa::fmin_nn(mnz, z); mxz = sa::fmax_nn(mxz, z);
+        }
     }
     mnx = wave_allmin_f(mnx); mxx = sa::wave_allmax(mxx);
     mnz = wave_allmin_f(mnz); mxz = sa::wave_allmax(mxz);
@@ -95,10 +118,21 @@ __global__ __launch_bounds__(1024) void bq_grid_build_kernel(int n, float cell_m
         sorted[n + 1] = make_float4(1e30f, 1e30f, 1e30f, 0.0f);
     }
 
-    for (int k = tid; k < n; k += 1024) {
-        const int cx = min(kNX - 1, max(0, (int)((p[k * 3 + 0] - mnx) * inv)));
-        const int cz = min(kNX - 1, max(0, (int)((p[k * 3 + 2] - mnz) * inv)));
-        atomicAdd(&s_cnt[cz * kNX + cx], 1);
+    int cell[16];
+    if (small) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int cx = min(kNX - 1, max(0, (int)((qx[u] - mnx) * inv)));
+            const int cz = min(kNX - 1, max(0, (int)((qz[u] - mnz) * inv)));
+            cell[u] = cz * kNX + cx;
+            if (tid + u * 1024 < n) atomicAdd(&s_cnt[cell[u]], 1);
+        }
+    } else {
+        for (int k = tid; k < n; k += 1024) {
+            const int cx = min(kNX - 1, max(0, (int)((p[k * 3 + 0] - mnx) * inv)));
+            const int cz = min(kNX - 1, max(0, (int)((p[k * 3 + 2] - mnz) * inv)));
+            atomicAdd(&s_cnt[cz * kNX + cx], 1);
+        }
     }
     __syncthreads();
     // exclusive scan of the 16384 counters: 16 consecutive cells per thread
@@ -124,6 +158,26 @@ __global__ __launch_bounds__(1024) void bq_grid_build_kernel(int n, float cell_m
     }
     if (tid == 1023) cell_start[kNC] = run;
     __syncthreads();
+    if (small) {
+        int pos[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) pos[u] = tid + u * 1024 < n ? atomicAdd(&s_cnt[cell[u]], 1) : -1;
+        __syncthreads();                                       // every cursor was read: the counters' 64 KB become the staging buffer
+        float4 *stage = (float4 *)s_cnt;
+        for (int q = 0; q * 4096 < n; ++q) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if ((pos[u] >> 12) == q) stage[pos[u] & 4095] = make_float4(qx[u], qy[u], qz[u], __int_as_float(tid + u * 1024));
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int at = q * 4096 + i * 1024 + tid;
+                if (at < n) sorted[at] = stage[i * 1024 + tid];
+            }
+            __syncthreads();
+        }
+        return;
+    }
     for (int k = tid; k < n; k += 1024) {
         const int cx = min(kNX - 1, max(0, (int)((p[k * 3 + 0] - mnx) * inv)));
         const int cz = min(kNX - 1, max(0, (int)((p[k * 3 + 2] - mnz) * inv)));
