@@ -52,13 +52,17 @@ __device__ __forceinline__ float wave_allmin_f(float x) { return -sa::wave_allma
 // query's last candidate read -- its distance is +inf, no band takes it; round 6).  Round 5: the cell lists hold the POINTS, not their indices -- a query's
 // chain was bounds -> sorted index -> point (a scattered 12-byte gather); it is now bounds -> one coalesced 16-byte read.
 constexpr int kCellInts = kNC + 4;
+constexpr int kPrepInts = 12;            // dwords of a query's record (bq_grid_prep_kernel)
 __host__ __device__ __forceinline__ size_t ws_stride(int n) { return (size_t)kCellInts + 4 * (size_t)n + 8; }
 
 // reuse != 0: the workspace is stated to hold the grid of these very points from an earlier call; it is kept if its cells
 // are at least cell_min wide (params[3] = the cell size it was built with), rebuilt otherwise -- decided here, on the
 // device, because the cell size depends on the frame's extent.
+// prep != nullptr (round 6): the workgroup also writes the records of its frame's m queries (kPrepInts dwords each, see
+// bq_grid_prep_kernel) straight from the cell starts it holds in LDS -- one launch less per call.
 __global__ __launch_bounds__(1024) void bq_grid_build_kernel(int n, float cell_min, int reuse, const float *__restrict__ xyz1,
-                                                             int *__restrict__ ws) {
+                                                             int *__restrict__ ws, int m, const float *__restrict__ xyz2,
+                                                             int *__restrict__ prep) {
     __shared__ int s_cnt[kNC];
     __shared__ float s_red[4][16];
     __shared__ int s_wsum[16];
@@ -158,6 +162,32 @@ __global__ __launch_bounds__(1024) void bq_grid_build_kernel(int n, float cell_m
     }
     if (tid == 1023) cell_start[kNC] = run;
     __syncthreads();
+    if (prep) {                                            // s_cnt holds the cell starts (and cell kNC starts at n)
+        for (int q = tid; q < m; q += 1024) {
+            const size_t qi = (size_t)b * m + q;
+            const float x2 = xyz2[qi * 3 + 0], y2 = xyz2[qi * 3 + 1], z2 = xyz2[qi * 3 + 2];
+            const int cx = min(kNX - 1, max(0, (int)((x2 - mnx) * inv)));
+            const int cz = min(kNX - 1, max(0, (int)((z2 - mnz) * inv)));
+            const int x_lo = max(cx - 1, 0), x_hi = min(cx + 1, kNX - 1);
+            int rs[3], rc[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int iz = cz - 1 + r;
+                const bool in = iz >= 0 && iz < kNX;
+                const int izc = in ? iz : cz;
+                const int ie = izc * kNX + x_hi + 1;
+                const int st = s_cnt[izc * kNX + x_lo], e = ie < kNC ? s_cnt[ie] : n;
+                rs[r] = st;
+                rc[r] = in ? e - st : 0;
+            }
+            const int c01 = rc[0] + rc[1], T = c01 + rc[2];
+            int4 *o = (int4 *)(prep + qi * kPrepInts);
+            o[0] = make_int4(__float_as_int(x2), __float_as_int(y2), __float_as_int(z2), rs[0]);
+            o[1] = make_int4(rs[1] - rc[0], rs[2] - c01, rc[0], c01);
+            o[2] = make_int4(T, 0, 0, 0);
+        }
+        __syncthreads();                                   // (the cursors move next)
+    }
     if (small) {
         int pos[16];
 #pragma unroll
@@ -515,7 +545,6 @@ __device__ __forceinline__ unsigned key_cand_off(int j, int rc0, int c01, int T,
 // two dependent scalar-load round trips per query when the query's WAVE did them (the kernel is bound by instruction
 // issue: 0.87 of the scalar pipe on sparse frames).  Record (12 dwords, behind the frames' grids in the workspace):
 //   x, y, z | offA, offB, offC (candidate j lives at sorted[j + off], off by range) | rc0, c01, T (range ends) | 3 unused
-constexpr int kPrepInts = 12;
 __global__ __launch_bounds__(256) void bq_grid_prep_kernel(int n, int m, const float *__restrict__ xyz2,
                                                            const int *__restrict__ ws, int *__restrict__ prep) {
     const int b = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
@@ -840,8 +869,7 @@ extern "C" int sa_query_ball_point_grid_ex(int b, int n, int m, int nbands, cons
         if (on && rmax[i] > rmax_all) rmax_all = rmax[i];
     }
     const float cell_min = rmax_all * 1.0001f + 1e-6f;
-    hipLaunchKernelGGL(bq_grid_build_kernel, dim3(b), dim3(1024), 0, stream, n, cell_min, flags & 1, xyz1, (int *)workspace);
-    SA_CHECK_LAUNCH();
+    // (launched further down: with the sorting form and no kept grid it also writes the queries' records)
     // queries per wave: a wave's set-up (block -> frame mapping, the frame's grid parameters: a dependent scalar load) is
     // paid once per wave; with enough work to fill the chip several times over, a wave takes kQPW queries
     static const int qpw = SA_KNOB("SA_BQ_QPW", 8);
@@ -863,7 +891,13 @@ extern "C" int sa_query_ball_point_grid_ex(int b, int n, int m, int nbands, cons
     for (int i = 0; i < nbands; ++i) ns_max = ns[i] > ns_max ? ns[i] : ns_max;
     const bool sorting = sort_on && ns_sum <= kSortCap - 64 && (size_t)b * m * ns_max * 4 < ((size_t)1 << 32);
     int *prep = (int *)workspace + (size_t)b * ws_stride(n);
-    if (sorting) {
+    // a kept grid (flags bit 0) may or may not be rebuilt -- decided on the device -- so its queries' records come from the
+    // pass of their own; otherwise the build writes them
+    const bool fused_prep = sorting && !(flags & 1);
+    hipLaunchKernelGGL(bq_grid_build_kernel, dim3(b), dim3(1024), 0, stream, n, cell_min, flags & 1, xyz1, (int *)workspace, m, xyz2,
+                       fused_prep ? prep : (int *)nullptr);
+    SA_CHECK_LAUNCH();
+    if (sorting && !fused_prep) {
         hipLaunchKernelGGL(bq_grid_prep_kernel, dim3((m + 255) / 256, b), dim3(256), 0, stream, n, m, xyz2, (const int *)workspace, prep);
         SA_CHECK_LAUNCH();
     }
