@@ -112,3 +112,16 @@ def test_prob_sample_name_exists_and_says_why_it_is_not_provided():
     s = pkg("utils.tf_ops.sampling.tf_sampling")
     with pytest.raises(NotImplementedError, match="outside the set-abstraction path"):
         s.prob_sample(None, None)
+
+
+def test_ball_query_workspace_holds_the_grids_and_one_record_per_query():
+    # round 6 (csrc/ballquery_grid.hip): behind the frames' grids (128 x 128 cell starts, the cell lists as 16-byte points,
+    # parameters, one far point) the workspace holds one 48-byte record per query -- its size depends on m; a host-only call
+    lib = ctypes.CDLL(pkg("utils._native").LIB_PATH)
+    f = lib.sa_query_ball_point_grid_ws_bytes
+    f.argtypes, f.restype = [ctypes.c_int] * 3, ctypes.c_size_t
+    assert f(0, 16384, 4096) == 0 and f(2, 0, 4096) == 0 and f(2, 16384, 0) == 0
+    base = f(3, 16384, 1)
+    assert f(3, 16384, 4097) - f(3, 16384, 1) == 3 * 4096 * 48
+    assert base - 3 * 48 == 3 * 4 * (128 * 128 + 4 + 4 * 16384 + 8)
+    assert f(3, 16384, 4096) % 16 == 0 and (f(1, 1000, 7) - 7 * 48) % 16 == 0        # 16-byte aligned pieces
