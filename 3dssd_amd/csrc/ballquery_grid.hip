@@ -710,14 +710,13 @@ __global__ __launch_bounds__(kQWaves * 64, 8) void bq_grid_sort_kernel(int n, in
                 nlist += (int)__popcll(hm);
             }
         };
-        // the walk, two steps' candidates in flight (a step's 40 instructions do not cover a load's round trip: with one
-        // step ahead a wave waited ~a microsecond per step); lanes / steps past T read the far point.  A list about to
-        // overflow leaves the inner loop, is cut, and the walk resumes (reloading) where it stopped.
         // The walk, in blocks of up to four steps whose candidates are requested together (a step's ~35 instructions do
         // not cover a load's round trip).  Wherever the next 256 candidates lie inside ONE of the three ranges (near the
         // sensor; `dense` frames: thousands of candidates) they are four loads off one address (immediate offsets) and the
         // steps need no range select, bounds test or far-point select.  A list about to overflow is cut at the top of
-        // the loop (ONE site: the cut is 600 instructions) and the walk resumes where it stopped.
+        // the loop (ONE site) and the walk resumes where it stopped.
+        // (SA_BQ_DBG_NOCUT / _NOSORT / _NOOUT: ablation switches of variant builds, tools/build_variant.sh -- results are wrong
+        //  with any of them; profiles/r06_ballquery_sort_ab.txt has what each stage costs.)
         int base = 0;
         if (T <= 64) {                                        // sparse frames: one step, no loop (and no cut: <= 64 keys)
             step(*(const float4 *)(sorted + key_cand_off(lane, rc0, c01, T, offA, offB, offC, sent)));
