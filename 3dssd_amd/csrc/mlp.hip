@@ -1968,7 +1968,7 @@ extern "C" int sa_dense(long rows, int K, int N, const float *x, const void *wpa
     P.L.KS = roundup(K, 16) / 16;
     P.L.NT = roundup(N, 32) / 32;
     // layers with enough rows to give every CU a 128-row block: the 128-row kernel (same bits).  128-column blocks with
-    // three chunks of lookahead where the shape allows, 64-column blocks with two for the narrow 128 -> 64 layer
+    // three chunks of lookahead where the shape allows, 64-column blocks with two (four waves) for the narrow 128 -> 64 layer
     if (rows < (1l << 31) && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {      // 16-byte row pieces in and out
         const long blocks = (rows + 127) / 128;
         // 256-column blocks (round 6; a wave = one column tile x FOUR row tiles, two chunks of lookahead: 212 registers): a
@@ -1993,10 +1993,15 @@ extern "C" int sa_dense(long rows, int K, int N, const float *x, const void *wpa
             return SA_OK;
         }
         if (K % (kD128KC * 2) == 0 && N % 64 == 0 && N % 128 != 0 && blocks * (N / 64) >= 512) {
-            auto kern = dense128_kernel<8, 2, 2>;
+            // FOUR waves (a wave = one column tile x two row tiles) since round 6: the eight-wave form needs 200 registers per
+            // lane, i.e. ONE workgroup per CU, and with two chunks per block (K = 128) nothing overlaps one block's loads with
+            // another's matrix work and stores; two independent four-wave workgroups per CU do: 140 -> 109 us at 524288 x 128
+            // -> 64 (128 frames), bit-identical.  (Wider layers: the 64-column form reads and converts the rows once per 64
+            // columns -- 131072 x 384 -> 128 100 -> 104 us with it: they keep the eight-wave forms above.)
+            auto kern = dense128_kernel<4, 2, 2>;
             (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kD128Lds);
             (void)hipGetLastError();
-            hipLaunchKernelGGL(kern, dim3((unsigned)blocks, N / 64), dim3(512), kD128Lds, stream, P);
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks, N / 64), dim3(256), kD128Lds, stream, P);
             SA_CHECK_LAUNCH();
             return SA_OK;
         }
